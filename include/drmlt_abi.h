@@ -1,0 +1,256 @@
+/*
+ * drmlt_abi.h -- C-ABI of the MI355X-native DRMLT hot path.
+ *
+ * This is the drop-in boundary: a thin Mitsuba `Integrator` adaptor (see
+ * INTEGRATION.md and drmlt-mitsuba_amd/host/) fills the POD structs below
+ * from the public Scene/Sensor/Film accessors and calls these entry points
+ * from `DRMLT::render()`. Nothing here uses C++ or torch types.
+ *
+ * Each entry point cites the reference interface it replaces
+ * (paths relative to the reference checkout):
+ *
+ *   drmlt_create      DRMLT::DRMLT(props) + DRMLTRenderer::prepare
+ *                     src/integrators/drmlt/drmlt.cpp:178-351,
+ *                     src/integrators/drmlt/drmlt_proc.cpp:84-154
+ *   drmlt_seed        PathSampler::generateSeeds + seed replay
+ *                     src/libbidir/pathsampler.cpp:859-960,
+ *                     src/integrators/drmlt/drmlt.cpp:498-546,
+ *                     src/integrators/drmlt/drmlt_proc.cpp:467-514
+ *   drmlt_run         DRMLTRenderer::process / processMixture (the chain loop)
+ *                     src/integrators/drmlt/drmlt_proc.cpp:161-380,386-771
+ *   drmlt_develop     DRMLTProcess::develop
+ *                     src/integrators/drmlt/drmlt_proc.cpp:813-854
+ *   drmlt_stats       the StatsCounter block
+ *                     src/integrators/drmlt/drmlt_proc.cpp:34-49
+ *   drmlt_eval_paths  PathSampler::sampleSplats (EUnidirectional)
+ *                     include/mitsuba/bidir/pathsampler.h:124,
+ *                     src/libbidir/pathsampler.cpp:529-567
+ *   drmlt_film_*      ImageBlock accumulation  (m_accum)
+ *                     src/integrators/drmlt/drmlt_proc.cpp:856-867
+ *   drmlt_destroy     ~DRMLT / ref<> release
+ *
+ * The same structs are consumed by the CPU oracle (oracle/, test
+ * infrastructure only) so that parity tests feed both sides identical
+ * inputs.
+ */
+#ifndef DRMLT_ABI_H
+#define DRMLT_ABI_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DRMLT_ABI_VERSION 1
+
+/* ---- enums (values are ABI) ------------------------------------------- */
+
+/* PathSampler::ETechnique, include/mitsuba/bidir/pathsampler.h */
+enum { DRMLT_TECH_PATH = 0, DRMLT_TECH_BDPT = 1, DRMLT_TECH_MMLT = 2 };
+
+/* DRMLTConfiguration::EType, src/integrators/drmlt/drmlt.h:70-74 */
+enum { DRMLT_TYPE_GREEN = 0, DRMLT_TYPE_MIRA = 1, DRMLT_TYPE_ORBITAL = 2 };
+
+/* which chain loop: drmlt_proc.cpp (0) or pssmlt_proc.cpp (1, oracle only) */
+enum { DRMLT_ALGO_DRMLT = 0, DRMLT_ALGO_PSSMLT = 1 };
+
+enum { DRMLT_SHAPE_TRIANGLE = 0, DRMLT_SHAPE_RECTANGLE = 1, DRMLT_SHAPE_SPHERE = 2 };
+
+enum {
+    DRMLT_BSDF_DIFFUSE = 0,        /* src/bsdfs/diffuse.cpp        */
+    DRMLT_BSDF_DIELECTRIC = 1,     /* src/bsdfs/dielectric.cpp     */
+    DRMLT_BSDF_ROUGHCONDUCTOR = 2, /* src/bsdfs/roughconductor.cpp */
+    DRMLT_BSDF_CONDUCTOR = 3       /* src/bsdfs/conductor.cpp      */
+};
+
+enum { DRMLT_EMITTER_AREA = 0 };   /* src/emitters/area.cpp */
+
+enum { DRMLT_FILTER_BOX = 0, DRMLT_FILTER_GAUSSIAN = 1 };
+
+/* error codes (0 = ok, negative = failure; message in the err buffer /
+ * drmlt_last_error) */
+enum {
+    DRMLT_OK = 0,
+    DRMLT_E_INVALID = -1,     /* bad argument / unsupported configuration     */
+    DRMLT_E_DEVICE = -2,      /* HIP error                                    */
+    DRMLT_E_STATE = -3,       /* call order violated (e.g. run before seed)   */
+    DRMLT_E_ZERO_LUM = -4,    /* "average image luminance appears to be zero" */
+    DRMLT_E_REPLAY = -5,      /* seed replay luminance mismatch               */
+    DRMLT_E_CANCELLED = -6    /* *stop became non-zero                        */
+};
+
+/* ---- configuration: names/defaults follow drmlt.cpp:193-349 ------------ */
+
+typedef struct drmlt_config {
+    uint32_t struct_size;        /* = sizeof(drmlt_config)                         */
+    int32_t  algo;               /* DRMLT_ALGO_*                                   */
+    int32_t  technique;          /* "technique"        (required)                  */
+    int32_t  type;               /* "type"             (required)                  */
+    int32_t  max_depth;          /* "maxDepth"         default -1 (path: finite)   */
+    int32_t  rr_depth;           /* "rrDepth"          default 5                   */
+    int32_t  direct_samples;     /* "directSamples"    default 16; <0: MLT does it */
+    int32_t  luminance_samples;  /* "luminanceSamples" default 100000              */
+    int32_t  work_units;         /* "workUnits"        default -1 (derived)        */
+    int32_t  sample_count;       /* sensor sampler's sampleCount = mutations/pixel */
+    float    p_large;            /* "pLarge"           default 0.3                 */
+    float    sigma;              /* "sigma"            default 1/64                */
+    float    scale_second;       /* "scaleSecond"      default 0.1 (error if > 1)  */
+    float    average_luminance;  /* "averageLuminance" default -1                  */
+    int32_t  acceptance_map;     /* "acceptanceMap"    default 0                   */
+    int32_t  timid_after_large;  /* "timidAfterLarge"  default 0                   */
+    int32_t  fix_emitter_path;   /* "fixEmitterPath"   default 0 (mmlt only)       */
+    int32_t  use_mixture;        /* "useMixture"       default 0                   */
+    int32_t  kelemen_style_weights;  /* pssmlt: Kelemen weights (default 1)        */
+    int32_t  kelemen_style_mutation; /* pssmlt: Kelemen (1) or Gaussian (0)        */
+    int32_t  reserved[8];
+} drmlt_config;
+
+/* ---- flat scene description -------------------------------------------- */
+
+/* One primitive. `data` by type:
+ *   TRIANGLE   p0.xyz p1.xyz p2.xyz            (face normal = (p1-p0)x(p2-p0))
+ *   RECTANGLE  row-major 3x4 objectToWorld of Mitsuba's rectangle
+ *              (local [-1,1]^2 in the z=0 plane, normal +z; rectangle.cpp:80-112)
+ *   SPHERE     center.xyz radius
+ */
+typedef struct drmlt_shape {
+    int32_t type;
+    int32_t bsdf;        /* index into bsdfs                         */
+    int32_t emitter;     /* index into emitters, or -1               */
+    int32_t reserved;
+    float   data[12];
+} drmlt_shape;
+
+/* DIFFUSE: rgb = reflectance.
+ * DIELECTRIC: p[0]=intIOR p[1]=extIOR, rgb unused (specular refl/trans = 1).
+ * ROUGHCONDUCTOR: rgb = specularReflectance, p[0]=alpha, p[1..3]=eta rgb,
+ *                 p[4..6]=k rgb, p[7]: 0=beckmann 1=ggx.
+ * CONDUCTOR: rgb = specularReflectance, p[1..3]=eta, p[4..6]=k. */
+typedef struct drmlt_bsdf {
+    int32_t type;
+    float   rgb[3];
+    float   p[8];
+} drmlt_bsdf;
+
+typedef struct drmlt_emitter {
+    int32_t type;        /* DRMLT_EMITTER_AREA                        */
+    int32_t shape;       /* index of the shape carrying this emitter */
+    float   radiance[3];
+    float   sampling_weight; /* Emitter::getSamplingWeight, default 1 */
+} drmlt_emitter;
+
+/* perspective pinhole (src/sensors/perspective.cpp) + hdrfilm size/filter */
+typedef struct drmlt_camera {
+    float   to_world[16];   /* row-major 4x4 camera-to-world (no scale)       */
+    float   fov_x_deg;      /* horizontal field of view in degrees            */
+    float   near_clip;      /* default 1e-2                                   */
+    float   far_clip;       /* default 1e4                                    */
+    int32_t width, height;  /* film (= crop) size                             */
+    int32_t filter;         /* DRMLT_FILTER_*                                 */
+    float   filter_param;   /* box: radius (0.5); gaussian: stddev (0.5)      */
+} drmlt_camera;
+
+typedef struct drmlt_scene {
+    uint32_t struct_size;       /* = sizeof(drmlt_scene) */
+    int32_t  n_shapes;
+    int32_t  n_bsdfs;
+    int32_t  n_emitters;
+    const drmlt_shape   *shapes;
+    const drmlt_bsdf    *bsdfs;
+    const drmlt_emitter *emitters;
+    drmlt_camera camera;
+} drmlt_scene;
+
+/* ---- statistics: numerators / denominators of drmlt_proc.cpp:34-49 ----- */
+
+typedef struct drmlt_stats {
+    uint64_t first_acc,  first_base;        /* "Accepted 1st-stage mutations"            */
+    uint64_t large_acc,  large_base;        /* "... large mutations in the 1st stage"    */
+    uint64_t bold_acc,   bold_base;         /* "... bold mutation in the 1st stage"      */
+    uint64_t second_acc, second_base;       /* "Accepted 2nd-stage mutations"            */
+    uint64_t second_large_acc, second_large_base; /* "... after large mutation"          */
+    uint64_t second_bold_acc,  second_bold_base;  /* "... after bold mutation"           */
+    uint64_t overall_acc, overall_base;     /* "Overall acceptance rate"                 */
+    uint64_t mutations;          /* chain-loop iterations (++mutationCtr, :541)          */
+    uint64_t path_evals;         /* sampleSplats calls (stage 1 + stage 2 + reverse)     */
+    uint64_t rays;               /* closest-hit + shadow rays traced                     */
+    uint64_t accepted;           /* iterations that changed the chain state              */
+    double   kernel_ms;          /* device time inside the chain kernels (HIP events)    */
+    double   seed_ms;            /* device+host time of drmlt_seed                       */
+    uint32_t n_chains;
+    uint32_t max_dim;            /* findMaxDimensions(...).sensor                        */
+    uint64_t launches;           /* chain-kernel launches so far                         */
+} drmlt_stats;
+
+/* one evaluated PSS point: SplatList of pathsampler.cpp:529-567 (one splat) */
+typedef struct drmlt_splat {
+    float luminance;
+    float x, y;          /* sample position in fractional pixel coordinates */
+    float rgb[3];        /* un-normalised contribution                      */
+    int32_t n_dims;      /* PSS components consumed                         */
+    int32_t n_rays;
+} drmlt_splat;
+
+typedef struct drmlt_ctx drmlt_ctx;
+
+typedef void (*drmlt_progress_cb)(uint64_t done_mutations, uint64_t total_mutations, void *user);
+
+/* Create a context on HIP device `device`. Validates config + scene the way
+ * the DRMLT ctor / PathSampler ctor do and fails (NULL, message in err) on
+ * anything unsupported -- never silently approximates. */
+drmlt_ctx *drmlt_create(const drmlt_config *cfg, const drmlt_scene *scene,
+                        int device, char *err, size_t errlen);
+
+/* Bootstrap: luminance samples, b = mean luminance, luminance-proportional
+ * seed resampling, replay of every seed into its chain (with the luminance
+ * sanity check). chain ids are [chain_offset, chain_offset + work_units):
+ * ranks of a multi-GPU job pass disjoint offsets. */
+int drmlt_seed(drmlt_ctx *ctx, uint64_t seed, uint32_t chain_offset, double *b_out);
+
+/* Run `total_mutations` chain-loop iterations spread evenly over the
+ * chains (total / work_units each, as drmlt.cpp:475-476). `stop` is polled
+ * between kernel launches (may be NULL). */
+int drmlt_run(drmlt_ctx *ctx, uint64_t total_mutations, volatile int *stop,
+              drmlt_progress_cb cb, void *user);
+
+/* out_rgb (host, W*H*3 floats) = accum * (b / mean_lum(accum)) + direct. */
+int drmlt_develop(drmlt_ctx *ctx, const float *direct_rgb_or_null, float *out_rgb);
+
+int drmlt_stats_get(drmlt_ctx *ctx, drmlt_stats *out);
+
+/* f(u): evaluate n PSS points (row-major n x dim floats in [0,1], host). */
+int drmlt_eval_paths(drmlt_ctx *ctx, const float *u, uint32_t n, uint32_t dim,
+                     drmlt_splat *out);
+
+/* Raw accumulated film (W*H*3 floats, un-normalised), host copy / reset. */
+int drmlt_film_read(drmlt_ctx *ctx, float *out_rgb);
+int drmlt_film_clear(drmlt_ctx *ctx);
+/* Device pointer of the film (W*H*3 fp32) so the caller can reduce it across
+ * GPUs (RCCL) without a host round trip; and the override of b used by
+ * develop once the per-rank estimates have been averaged (drmlt.cpp:544). */
+void *drmlt_film_device_ptr(drmlt_ctx *ctx);
+int drmlt_set_luminance(drmlt_ctx *ctx, double b);
+/* Launch all kernels of this context on a caller-owned hipStream_t. */
+int drmlt_set_stream(drmlt_ctx *ctx, void *hip_stream);
+/* Timing of the dominant kernel for bench.py's roofline (HIP events on the
+ * launch stream): average ms per launch over the launches since last reset. */
+int drmlt_kernel_time(drmlt_ctx *ctx, double *avg_ms, uint64_t *launches, int reset);
+
+/* Plain independent-sample path tracing of the same integrand
+ * (test utility: equal-expectation reference for the MLT image). */
+int drmlt_render_pt(drmlt_ctx *ctx, uint32_t spp, uint64_t seed, float *out_rgb);
+
+/* Chain state dump for parity tests: lum/x/y/rgb of chain's current state and
+ * the first `dim` PSS components (u is n_chains x dim, may be NULL). */
+int drmlt_chain_state(drmlt_ctx *ctx, drmlt_splat *cur, float *u, uint32_t dim);
+
+const char *drmlt_last_error(drmlt_ctx *ctx);
+uint32_t drmlt_abi_version(void);
+void drmlt_destroy(drmlt_ctx *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DRMLT_ABI_H */

@@ -1,0 +1,207 @@
+"""ORACLE -- TEST INFRASTRUCTURE ONLY.
+
+ctypes loader for oracle/liboracle.so (the CPU restatement of the reference's DRMLT path).
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def build(native=False):
+    target = "liboracle_native.so" if native else "liboracle.so"
+    subprocess.check_call(["make", "-C", _HERE, target], stdout=subprocess.DEVNULL)
+    return os.path.join(_HERE, target)
+
+
+_libs = {}
+
+
+def lib(native=False):
+    if native not in _libs:
+        path = os.path.join(_HERE, "liboracle_native.so" if native else "liboracle.so")
+        if not os.path.exists(path):
+            build(native)
+        L = C.CDLL(path)
+        L.oracle_create.restype = C.c_void_p
+        L.oracle_create.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_char_p, C.c_size_t]
+        L.oracle_destroy.argtypes = [C.c_void_p]
+        L.oracle_last_error.restype = C.c_char_p
+        L.oracle_last_error.argtypes = [C.c_void_p]
+        L.oracle_eval_paths.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
+        L.oracle_seed.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, C.POINTER(C.c_double)]
+        L.oracle_run.argtypes = [C.c_void_p, C.c_uint64, C.c_int]
+        L.oracle_film_read.argtypes = [C.c_void_p, C.c_void_p]
+        L.oracle_develop.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.oracle_stats_get.argtypes = [C.c_void_p, C.c_void_p]
+        L.oracle_chain_state.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]
+        L.oracle_render_pt.argtypes = [C.c_void_p, C.c_uint32, C.c_uint64, C.c_int, C.c_void_p]
+        L.oracle_bootstrap_lum.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_void_p]
+        L.oracle_philox.argtypes = [C.c_uint32] * 6 + [C.c_void_p]
+        L.oracle_uniforms.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
+                                      C.c_void_p]
+        L.oracle_kernel_sample.argtypes = [C.c_int, C.c_double, C.c_double, C.c_int, C.c_uint64, C.c_uint32,
+                                           C.c_void_p]
+        L.oracle_kernel_pdf.argtypes = [C.c_int, C.c_double, C.c_double, C.c_int, C.c_uint32, C.c_void_p,
+                                        C.c_void_p, C.c_void_p]
+        L.oracle_sampler_trace.argtypes = [C.c_int, C.c_double, C.c_double, C.c_int, C.c_uint64, C.c_uint32,
+                                           C.c_uint32, C.c_int, C.c_uint32, C.c_uint32] + [C.c_void_p] * 7
+        L.oracle_toy_run.argtypes = [C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_uint64,
+                                     C.c_uint32, C.c_uint64, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        L.oracle_toy_target.restype = C.c_double
+        L.oracle_toy_target.argtypes = [C.c_double, C.c_double]
+        L.oracle_film_put.argtypes = [C.c_int, C.c_int, C.c_int, C.c_double, C.c_uint32, C.c_void_p, C.c_void_p,
+                                      C.c_void_p]
+        L.oracle_find_max_dim.argtypes = [C.c_int, C.c_int]
+        _libs[native] = L
+    return _libs[native]
+
+
+class OracleError(RuntimeError):
+    pass
+
+
+class Oracle:
+    """Mirrors drmlt_amd.Context so parity tests read the same on both sides."""
+
+    def __init__(self, abi, cfg, scene_data, precision=64, native=False):
+        self.abi = abi
+        self.L = lib(native)
+        self.cfg = cfg
+        self.scene_data = scene_data
+        self._scene = scene_data.struct()
+        err = C.create_string_buffer(512)
+        self.h = self.L.oracle_create(C.byref(cfg), C.byref(self._scene), precision, err, 512)
+        if not self.h:
+            raise OracleError(err.value.decode())
+        self.width, self.height = scene_data.camera.width, scene_data.camera.height
+
+    def close(self):
+        if self.h:
+            self.L.oracle_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise OracleError("%d: %s" % (rc, self.L.oracle_last_error(self.h).decode()))
+
+    def eval_paths(self, u):
+        u = np.ascontiguousarray(u, dtype=np.float32)
+        n, dim = u.shape
+        out = (self.abi.Splat * n)()
+        self._chk(self.L.oracle_eval_paths(self.h, u.ctypes.data, n, dim, out))
+        return np.frombuffer(out, dtype=SPLAT_DTYPE).copy()
+
+    def seed(self, seed, chain_offset=0):
+        b = C.c_double()
+        self._chk(self.L.oracle_seed(self.h, seed, chain_offset, C.byref(b)))
+        return b.value
+
+    def run(self, total_mutations, nthreads=1):
+        self._chk(self.L.oracle_run(self.h, total_mutations, nthreads))
+
+    def film(self):
+        out = np.empty((self.height, self.width, 3), dtype=np.float32)
+        self._chk(self.L.oracle_film_read(self.h, out.ctypes.data))
+        return out
+
+    def develop(self, direct=None):
+        out = np.empty((self.height, self.width, 3), dtype=np.float32)
+        d = None if direct is None else np.ascontiguousarray(direct, dtype=np.float32).ctypes.data
+        self._chk(self.L.oracle_develop(self.h, d, out.ctypes.data))
+        return out
+
+    def stats(self):
+        s = self.abi.Stats()
+        self._chk(self.L.oracle_stats_get(self.h, C.byref(s)))
+        return s
+
+    def chain_state(self, dim):
+        n = self.cfg.work_units
+        cur = (self.abi.Splat * n)()
+        u = np.empty((n, dim), dtype=np.float32)
+        self._chk(self.L.oracle_chain_state(self.h, cur, u.ctypes.data, dim))
+        return np.frombuffer(cur, dtype=SPLAT_DTYPE).copy(), u
+
+    def render_pt(self, spp, seed=1, nthreads=1):
+        out = np.empty((self.height, self.width, 3), dtype=np.float32)
+        self._chk(self.L.oracle_render_pt(self.h, spp, seed, nthreads, out.ctypes.data))
+        return out
+
+    def bootstrap_lum(self, seed, stream, n):
+        out = np.empty(n, dtype=np.float32)
+        self._chk(self.L.oracle_bootstrap_lum(self.h, seed, stream, n, out.ctypes.data))
+        return out
+
+
+SPLAT_DTYPE = np.dtype([("luminance", "<f4"), ("x", "<f4"), ("y", "<f4"), ("rgb", "<f4", (3,)),
+                        ("n_dims", "<i4"), ("n_rays", "<i4")])
+
+
+def philox(k0, k1, c0, c1, c2, c3):
+    out = np.zeros(4, dtype=np.uint32)
+    lib().oracle_philox(k0, k1, c0, c1, c2, c3, out.ctypes.data)
+    return out
+
+
+def uniforms(seed, chain, tag, major, idx0, n):
+    out = np.zeros(n, dtype=np.float32)
+    lib().oracle_uniforms(seed, chain, tag, major, idx0, n, out.ctypes.data)
+    return out
+
+
+def kernel_sample(kind, p0, p1, precision, seed, n):
+    out = np.zeros(n, dtype=np.float64)
+    lib().oracle_kernel_sample(kind, p0, p1, precision, seed, n, out.ctypes.data)
+    return out
+
+
+def kernel_pdf(kind, p0, p1, precision, du):
+    du = np.ascontiguousarray(du, dtype=np.float64)
+    pdf = np.zeros_like(du)
+    logpdf = np.zeros_like(du)
+    lib().oracle_kernel_pdf(kind, p0, p1, precision, du.size, du.ctypes.data, pdf.ctypes.data, logpdf.ctypes.data)
+    return pdf, logpdf
+
+
+def sampler_trace(type_, sigma, scale_second, precision, seed, chain, mutation, large, x, used):
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    dim = x.size
+    y, z, ystar = (np.zeros(used) for _ in range(3))
+    acc1, acc2 = np.zeros(dim), np.zeros(dim)
+    ratio = C.c_double(1.0)
+    rc = lib().oracle_sampler_trace(type_, sigma, scale_second, precision, seed, chain, mutation, int(large), dim,
+                                    used, x.ctypes.data, y.ctypes.data, z.ctypes.data, ystar.ctypes.data,
+                                    C.addressof(ratio), acc1.ctypes.data, acc2.ctypes.data)
+    if rc != 0:
+        raise OracleError("sampler_trace failed")
+    return dict(y=y, z=z, ystar=ystar, ratio=ratio.value, acc1=acc1, acc2=acc2)
+
+
+def toy_run(abi, type_, mixture, timid, p_large, sigma, scale_second, seed, n_chains, n_mut, w, h):
+    hist = np.zeros((h, w), dtype=np.float64)
+    st = abi.Stats()
+    rc = lib().oracle_toy_run(type_, int(mixture), int(timid), p_large, sigma, scale_second, seed, n_chains, n_mut,
+                              w, h, hist.ctypes.data, C.addressof(st))
+    if rc != 0:
+        raise OracleError("toy_run failed: %d" % rc)
+    return hist, st
+
+
+def toy_target(x, y):
+    return lib().oracle_toy_target(x, y)
+
+
+def film_put(w, h, filt, param, xy, rgb):
+    xy = np.ascontiguousarray(xy, dtype=np.float32)
+    rgb = np.ascontiguousarray(rgb, dtype=np.float32)
+    out = np.zeros((h, w, 3), dtype=np.float32)
+    lib().oracle_film_put(w, h, filt, param, xy.shape[0], xy.ctypes.data, rgb.ctypes.data, out.ctypes.data)
+    return out

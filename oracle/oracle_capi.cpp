@@ -1,0 +1,360 @@
+// ORACLE -- TEST INFRASTRUCTURE ONLY (see oracle_math.hpp header).
+//
+// C entry points over the templated restatement (float and double builds),
+// loaded by tests/ through ctypes. Consumes the same POD structs as the product
+// ABI (include/drmlt_abi.h) so both sides see identical inputs.
+#include "oracle_process.hpp"
+#include <atomic>
+#include <cstdio>
+#include <thread>
+
+using namespace oracle;
+
+namespace {
+
+template <typename F> struct ArraySampler : Sampler<F> {
+    const float *u;
+    size_t n;
+    ArraySampler(const float *p, size_t cnt) : u(p), n(cnt) {}
+    F next1D() override {
+        size_t k = this->sampleIndex++;
+        if (k >= n) throw std::runtime_error("ArraySampler: out of dimensions");
+        return (F) u[k];
+    }
+};
+
+struct CtxBase {
+    virtual ~CtxBase() = default;
+    virtual int evalPaths(const float *u, uint32_t n, uint32_t dim, drmlt_splat *out) = 0;
+    virtual int seed(uint64_t seed, uint32_t chainOffset, double *b) = 0;
+    virtual int run(uint64_t total, int nthreads) = 0;
+    virtual int filmRead(float *out) = 0;
+    virtual int developImage(const float *direct, float *out) = 0;
+    virtual int stats(drmlt_stats *out) = 0;
+    virtual int chainState(drmlt_splat *cur, float *u, uint32_t dim) = 0;
+    virtual int renderPT(uint32_t spp, uint64_t seed, int nthreads, float *out) = 0;
+    virtual int bootstrapLum(uint64_t seed, uint32_t stream, uint32_t n, float *out) = 0;
+    std::string error;
+};
+
+template <typename F> struct Ctx : CtxBase {
+    drmlt_config cfg;
+    Config<F> c;
+    Scene<F> scene;
+    SceneEvaluator<F> eval;
+    std::vector<std::unique_ptr<DRChain<F, SceneEvaluator<F>>>> chains;
+    std::vector<std::unique_ptr<PSSMLTChain<F, SceneEvaluator<F>>>> pchains;
+    std::vector<double> accum;
+    Stats st;
+    double b = 0;
+    bool seeded = false;
+
+    std::string init(const drmlt_config &in, const drmlt_scene &s) {
+        cfg = in;
+        if (in.technique != DRMLT_TECH_PATH) return "oracle: only technique=path is restated";
+        if (in.max_depth <= 0) return "technique=path requires a finite maxDepth (pssmlt_utils.h:63)";
+        if (in.scale_second > 1) return "scaleSecond is bigger than the first stage";
+        if (in.work_units <= 0) return "work_units must be positive";
+        std::string e = scene.load(s);
+        if (!e.empty()) return e;
+        c.algo = in.algo; c.type = in.type; c.maxDepth = in.max_depth; c.rrDepth = in.rr_depth;
+        c.separateDirect = in.direct_samples >= 0;
+        c.acceptanceMap = in.acceptance_map != 0; c.timidAfterLarge = in.timid_after_large != 0;
+        c.useMixture = in.use_mixture != 0; c.kelemenWeights = in.kelemen_style_weights != 0;
+        c.kelemenMutation = in.kelemen_style_mutation != 0;
+        c.pLarge = in.p_large; c.sigma = in.sigma; c.scaleSecond = in.scale_second;
+        c.maxDim = findMaxDimensionsPath(in.max_depth, in.rr_depth);
+        if (c.acceptanceMap && scene.filterType != DRMLT_FILTER_BOX) return "Box filter required for acceptance map!";
+        eval = SceneEvaluator<F>{&scene, c.maxDepth, c.rrDepth, c.separateDirect};
+        accum.assign((size_t) scene.width * scene.height * 3, 0.0);
+        return "";
+    }
+
+    int evalPaths(const float *u, uint32_t n, uint32_t dim, drmlt_splat *out) override {
+        for (uint32_t i = 0; i < n; ++i) {
+            ArraySampler<F> s(u + (size_t) i * dim, dim);
+            SplatList<F> l;
+            eval(s, l, nullptr);
+            out[i].luminance = (float) l.luminance;
+            out[i].x = (float) l.px; out[i].y = (float) l.py;
+            out[i].rgb[0] = (float) l.value.x; out[i].rgb[1] = (float) l.value.y; out[i].rgb[2] = (float) l.value.z;
+            out[i].n_dims = l.nDims; out[i].n_rays = l.nRays;
+        }
+        return 0;
+    }
+
+    int bootstrapLum(uint64_t seedv, uint32_t stream, uint32_t n, float *out) override {
+        Random boot(seedv, stream);
+        ReplayableSampler<F> s(&boot);
+        SplatList<F> l;
+        for (uint32_t i = 0; i < n; ++i) {
+            s.setSampleIndex(i);
+            eval(s, l, nullptr);
+            out[i] = (float) l.luminance;
+        }
+        return 0;
+    }
+
+    int seed(uint64_t seedv, uint32_t chainOffset, double *bOut) override {
+        Random boot(seedv, chainOffset);
+        std::vector<PathSeed> seeds;
+        size_t lumSamples = (size_t) std::max(cfg.luminance_samples, cfg.work_units * 10); // drmlt.cpp:454-466
+        b = generateSeeds<F>(eval, boot, lumSamples, (size_t) cfg.work_units, seeds);
+        if (b == 0) { error = "The average image luminance appears to be zero!"; return DRMLT_E_ZERO_LUM; }
+        if (cfg.acceptance_map) b = 1.0;                               // drmlt.cpp:550-552
+        else if (cfg.average_luminance != -1.0f) b = cfg.average_luminance; // :555-558
+        c.luminance = (F) b;
+        chains.clear(); pchains.clear();
+        for (int i = 0; i < cfg.work_units; ++i) {
+            bool ok;
+            if (cfg.algo == DRMLT_ALGO_PSSMLT) {
+                pchains.emplace_back(new PSSMLTChain<F, SceneEvaluator<F>>(c, eval, seedv, chainOffset + i, chainOffset));
+                ok = pchains.back()->init(seeds[i]);
+            } else {
+                chains.emplace_back(new DRChain<F, SceneEvaluator<F>>(c, eval, seedv, chainOffset + i, chainOffset));
+                ok = chains.back()->init(seeds[i]);
+            }
+            if (!ok) { error = "Error when reconstructing a seed path"; return DRMLT_E_REPLAY; }
+        }
+        seeded = true;
+        if (bOut) *bOut = b;
+        return 0;
+    }
+
+    int run(uint64_t total, int nthreads) override {
+        if (!seeded) { error = "run before seed"; return DRMLT_E_STATE; }
+        uint64_t perChain = total / (uint64_t) cfg.work_units; // drmlt.cpp:475-476
+        nthreads = std::max(1, nthreads);
+        std::vector<Stats> tstats(nthreads);
+        std::vector<std::unique_ptr<Film<F>>> films;
+        for (int t = 0; t < nthreads; ++t)
+            films.emplace_back(new Film<F>(scene.width, scene.height, scene.filterType, scene.filterParam));
+        std::atomic<int> next(0);
+        auto work = [&](int t) {
+            for (;;) {
+                int i = next.fetch_add(1);
+                if (i >= cfg.work_units) break;
+                if (cfg.algo == DRMLT_ALGO_PSSMLT) pchains[i]->run(perChain, *films[t], tstats[t]);
+                else chains[i]->run(perChain, *films[t], tstats[t]);
+            }
+        };
+        std::vector<std::thread> th;
+        for (int t = 1; t < nthreads; ++t) th.emplace_back(work, t);
+        work(0);
+        for (auto &x : th) x.join();
+        for (int t = 0; t < nthreads; ++t) { films[t]->accumulateInto(accum); st.add(tstats[t]); }
+        return 0;
+    }
+
+    int filmRead(float *out) override {
+        for (size_t i = 0; i < accum.size(); ++i) out[i] = (float) accum[i];
+        return 0;
+    }
+    int developImage(const float *direct, float *out) override {
+        develop(accum, scene.width, scene.height, b, cfg.acceptance_map != 0, direct, out);
+        return 0;
+    }
+    int stats(drmlt_stats *o) override {
+        std::memset(o, 0, sizeof(*o));
+        std::memcpy(&o->first_acc, &st.first_acc, sizeof(uint64_t) * 18);
+        o->n_chains = (uint32_t) cfg.work_units;
+        o->max_dim = (uint32_t) c.maxDim;
+        return 0;
+    }
+    int chainState(drmlt_splat *cur, float *u, uint32_t dim) override {
+        for (int i = 0; i < cfg.work_units; ++i) {
+            const SplatList<F> &l = cfg.algo == DRMLT_ALGO_PSSMLT ? pchains[i]->current() : chains[i]->current();
+            const std::vector<F> &x = cfg.algo == DRMLT_ALGO_PSSMLT ? pchains[i]->state() : chains[i]->state();
+            if (cur) {
+                cur[i].luminance = (float) l.luminance; cur[i].x = (float) l.px; cur[i].y = (float) l.py;
+                cur[i].rgb[0] = (float) l.value.x; cur[i].rgb[1] = (float) l.value.y; cur[i].rgb[2] = (float) l.value.z;
+                cur[i].n_dims = l.nDims; cur[i].n_rays = l.nRays;
+            }
+            if (u) for (uint32_t k = 0; k < dim; ++k) u[(size_t) i * dim + k] = k < x.size() ? (float) x[k] : 0.f;
+        }
+        return 0;
+    }
+
+    // independent-sample rendering of the same integrand f(u): mean over spp*W*H
+    // uniform PSS points, splatted through the same film, scaled to radiance units.
+    int renderPT(uint32_t spp, uint64_t seedv, int nthreads, float *out) override {
+        nthreads = std::max(1, nthreads);
+        uint64_t total = (uint64_t) spp * scene.width * scene.height;
+        std::vector<std::unique_ptr<Film<F>>> films;
+        for (int t = 0; t < nthreads; ++t)
+            films.emplace_back(new Film<F>(scene.width, scene.height, scene.filterType, scene.filterParam));
+        auto work = [&](int t) {
+            Random r(seedv, (uint32_t) t);
+            ReplayableSampler<F> s(&r);
+            SplatList<F> l;
+            for (uint64_t i = (uint64_t) t; i < total; i += (uint64_t) nthreads) {
+                r.seek(TAG_PT, (uint32_t) (i / (uint64_t) nthreads), 0);
+                s.sampleIndex = 0;
+                eval(s, l, nullptr);
+                if (l.luminance > 0 && spectrumValid(l.value)) films[t]->put(l.px, l.py, l.value);
+            }
+        };
+        std::vector<std::thread> th;
+        for (int t = 1; t < nthreads; ++t) th.emplace_back(work, t);
+        work(0);
+        for (auto &x : th) x.join();
+        std::vector<double> acc((size_t) scene.width * scene.height * 3, 0.0);
+        for (auto &f : films) f->accumulateInto(acc);
+        // E[f(u) on pixel p] * (W*H) = pixel radiance estimate (samplePos uniform over the film)
+        double scale = 1.0 / (double) spp;
+        for (size_t i = 0; i < acc.size(); ++i) out[i] = (float) (acc[i] * scale);
+        return 0;
+    }
+};
+
+} // namespace
+
+namespace {
+template <typename F> std::unique_ptr<TransitionKernel<F>> makeKernel(int kind, double p0, double p1) {
+    switch (kind) {
+        case 0: return std::make_unique<GaussianKernel<F>>((F) p0);
+        case 1: return std::make_unique<KelemenKernel<F>>((F) p0, (F) p1);
+        case 2: return std::make_unique<IdentityKernel<F>>();
+        default: return std::make_unique<WrappedCauchyKernel<F>>((F) p0);
+    }
+}
+} // namespace
+
+extern "C" {
+
+void *oracle_create(const drmlt_config *cfg, const drmlt_scene *scene, int precision, char *err, size_t errlen) {
+    std::string e;
+    CtxBase *ctx = nullptr;
+    try {
+        if (precision == 32) { auto *c = new Ctx<float>(); e = c->init(*cfg, *scene); ctx = c; }
+        else { auto *c = new Ctx<double>(); e = c->init(*cfg, *scene); ctx = c; }
+    } catch (const std::exception &ex) { e = ex.what(); }
+    if (!e.empty()) {
+        if (err && errlen) std::snprintf(err, errlen, "%s", e.c_str());
+        delete ctx;
+        return nullptr;
+    }
+    return ctx;
+}
+void oracle_destroy(void *p) { delete static_cast<CtxBase *>(p); }
+const char *oracle_last_error(void *p) { return static_cast<CtxBase *>(p)->error.c_str(); }
+
+#define GUARD(expr) try { return (expr); } catch (const std::exception &ex) { static_cast<CtxBase *>(p)->error = ex.what(); return DRMLT_E_INVALID; }
+
+int oracle_eval_paths(void *p, const float *u, uint32_t n, uint32_t dim, drmlt_splat *out) { GUARD(static_cast<CtxBase *>(p)->evalPaths(u, n, dim, out)) }
+int oracle_seed(void *p, uint64_t seed, uint32_t chain_offset, double *b) { GUARD(static_cast<CtxBase *>(p)->seed(seed, chain_offset, b)) }
+int oracle_run(void *p, uint64_t total, int nthreads) { GUARD(static_cast<CtxBase *>(p)->run(total, nthreads)) }
+int oracle_film_read(void *p, float *out) { GUARD(static_cast<CtxBase *>(p)->filmRead(out)) }
+int oracle_develop(void *p, const float *direct, float *out) { GUARD(static_cast<CtxBase *>(p)->developImage(direct, out)) }
+int oracle_stats_get(void *p, drmlt_stats *out) { GUARD(static_cast<CtxBase *>(p)->stats(out)) }
+int oracle_chain_state(void *p, drmlt_splat *cur, float *u, uint32_t dim) { GUARD(static_cast<CtxBase *>(p)->chainState(cur, u, dim)) }
+int oracle_render_pt(void *p, uint32_t spp, uint64_t seed, int nthreads, float *out) { GUARD(static_cast<CtxBase *>(p)->renderPT(spp, seed, nthreads, out)) }
+int oracle_bootstrap_lum(void *p, uint64_t seed, uint32_t stream, uint32_t n, float *out) { GUARD(static_cast<CtxBase *>(p)->bootstrapLum(seed, stream, n, out)) }
+
+// ---- unit-level entry points ------------------------------------------------
+
+void oracle_philox(uint32_t k0, uint32_t k1, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t *out) {
+    auto r = Philox::block(k0, k1, c0, c1, c2, c3);
+    for (int i = 0; i < 4; ++i) out[i] = r[i];
+}
+
+// uniforms of the addressed stream: out[i] = U(seed, chain, tag, major, idx0 + i)
+void oracle_uniforms(uint64_t seed, uint32_t chain, uint32_t tag, uint32_t major, uint32_t idx0, uint32_t n, float *out) {
+    Random r(seed, chain);
+    r.seek(tag, major, idx0);
+    for (uint32_t i = 0; i < n; ++i) out[i] = r.nextFloat();
+}
+
+// kind: 0 gaussian(sigma) 1 kelemen(s1,s2) 2 identity 3 wrappedcauchy(rho). Samples n values drawing
+// from the addressed stream (seed, chain=0, TAG_S1, major=0) sequentially; precision 32|64.
+void oracle_kernel_sample(int kind, double p0, double p1, int precision, uint64_t seed, uint32_t n, double *out) {
+    Random r(seed, 0);
+    r.seek(TAG_S1, 0, 0);
+    if (precision == 32) { auto k = makeKernel<float>(kind, p0, p1); for (uint32_t i = 0; i < n; ++i) out[i] = k->sample(&r); }
+    else { auto k = makeKernel<double>(kind, p0, p1); for (uint32_t i = 0; i < n; ++i) out[i] = k->sample(&r); }
+}
+void oracle_kernel_pdf(int kind, double p0, double p1, int precision, uint32_t n, const double *du, double *pdf, double *logpdf) {
+    if (precision == 32) { auto k = makeKernel<float>(kind, p0, p1); for (uint32_t i = 0; i < n; ++i) { pdf[i] = k->pdf((float) du[i]); logpdf[i] = k->logPdf((float) du[i]); } }
+    else { auto k = makeKernel<double>(kind, p0, p1); for (uint32_t i = 0; i < n; ++i) { pdf[i] = k->pdf(du[i]); logpdf[i] = k->logPdf(du[i]); } }
+}
+
+// Sampler trace: one DRMLTSampler of `dim` dims with current state x; returns the wrapped
+// first-stage proposal y, the second-stage proposal z, Green's y*, and Mira's kernel ratio.
+// `used` = number of dims consumed by each stage evaluation.
+int oracle_sampler_trace(int type, double sigma, double scaleSecond, int precision, uint64_t seed, uint32_t chain,
+                         uint32_t mutation, int largeStep, uint32_t dim, uint32_t used, const double *x, double *y,
+                         double *z, double *ystar, double *ratio, double *xAcc1, double *xAcc2) {
+    auto body = [&](auto tag) {
+        using F = decltype(tag);
+        Random r(seed, chain);
+        DRMLTSampler<F> s((DRType) type, (F) sigma, (F) scaleSecond, &r);
+        s.setMaxDim(dim);
+        for (uint32_t k = 0; k < dim; ++k) s.uCurrent.push_back((F) x[k]);
+        s.setMutation(mutation);
+        s.setLargeStep(largeStep != 0);
+        for (uint32_t k = 0; k < used; ++k) y[k] = s.next1D();
+        if (!largeStep) {
+            s.nextStage();
+            for (uint32_t k = 0; k < used; ++k) z[k] = s.next1D();
+            if (type == EGreen) {
+                s.setReverse(true);
+                for (uint32_t k = 0; k < used; ++k) ystar[k] = s.next1D();
+                s.setReverse(false);
+            }
+            *ratio = s.getTransitionRatio();
+            std::vector<F> first = s.uFirst, second = s.uSecond;
+            for (uint32_t k = 0; k < dim; ++k) { xAcc1[k] = DRMLTSampler<F>::wrap(first[k]); xAcc2[k] = DRMLTSampler<F>::wrap(second[k]); }
+        } else {
+            std::vector<F> first = s.uFirst;
+            for (uint32_t k = 0; k < dim; ++k) xAcc1[k] = DRMLTSampler<F>::wrap(first[k]);
+        }
+    };
+    try {
+        if (precision == 32) body(float(0)); else body(double(0));
+    } catch (const std::exception &) { return -1; }
+    return 0;
+}
+
+// Toy-target chains (analytic 2-D density) through the SAME acceptance code:
+// returns the W x H histogram of expectation-weighted splats (sum over chains).
+int oracle_toy_run(int type, int useMixture, int timidAfterLarge, double pLarge, double sigma, double scaleSecond,
+                   uint64_t seed, uint32_t nChains, uint64_t nMutations, int w, int h, double *hist, drmlt_stats *stats) {
+    using F = double;
+    Config<F> c{};
+    c.algo = 0; c.type = type; c.maxDepth = 1; c.rrDepth = 1; c.separateDirect = false; c.acceptanceMap = false;
+    c.timidAfterLarge = timidAfterLarge != 0; c.useMixture = useMixture != 0; c.kelemenWeights = false; c.kelemenMutation = true;
+    c.pLarge = pLarge; c.sigma = sigma; c.scaleSecond = scaleSecond; c.maxDim = 2;
+    ToyEvaluator<F> eval{w, h};
+    Film<F> film(w, h, DRMLT_FILTER_BOX, 0.5);
+    Stats st;
+    try {
+        Random boot(seed, 0);
+        std::vector<PathSeed> seeds;
+        generateSeeds<F>(eval, boot, 4096, nChains, seeds);
+        for (uint32_t i = 0; i < nChains; ++i) {
+            DRChain<F, ToyEvaluator<F>> chain(c, eval, seed, i, 0);
+            if (!chain.init(seeds[i])) return DRMLT_E_REPLAY;
+            chain.run(nMutations, film, st);
+        }
+    } catch (const std::exception &) { return -1; }
+    std::vector<double> acc((size_t) w * h * 3, 0.0);
+    film.accumulateInto(acc);
+    for (size_t i = 0; i < (size_t) w * h; ++i) hist[i] = acc[i * 3];
+    if (stats) { std::memset(stats, 0, sizeof(*stats)); std::memcpy(&stats->first_acc, &st.first_acc, sizeof(uint64_t) * 18); }
+    return 0;
+}
+double oracle_toy_target(double x, double y) { return ToyEvaluator<double>::target(x, y); }
+
+// ImageBlock::put through the discretised filter: splat n samples, return interior W x H x 3
+int oracle_film_put(int w, int h, int filter, double param, uint32_t n, const float *xy, const float *rgb, float *out) {
+    Film<float> film(w, h, filter, (float) param);
+    for (uint32_t i = 0; i < n; ++i) film.put(xy[2 * i], xy[2 * i + 1], V3<float>(rgb[3 * i], rgb[3 * i + 1], rgb[3 * i + 2]));
+    std::vector<double> acc((size_t) w * h * 3, 0.0);
+    film.accumulateInto(acc);
+    for (size_t i = 0; i < acc.size(); ++i) out[i] = (float) acc[i];
+    return 0;
+}
+
+int oracle_find_max_dim(int maxDepth, int rrDepth) { return findMaxDimensionsPath(maxDepth, rrDepth); }
+
+} // extern "C"
