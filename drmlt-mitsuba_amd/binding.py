@@ -1,9 +1,177 @@
-"""placeholder"""
+"""ctypes host binding of libdrmlt_amd.so (the C-ABI of include/drmlt_abi.h).
+
+`Context` mirrors the call sequence of the reference's DRMLT::render
+(src/integrators/drmlt/drmlt.cpp:393-611): create -> seed -> run -> develop. There is no
+CPU fallback: if the HIP library is missing or no GPU is visible, construction raises.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from . import abi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libdrmlt_amd.so")
+_lib = None
+
+SPLAT_DTYPE = np.dtype([("luminance", "<f4"), ("x", "<f4"), ("y", "<f4"), ("rgb", "<f4", (3,)),
+                        ("n_dims", "<i4"), ("n_rays", "<i4")])
+
+# every symbol include/drmlt_abi.h declares
+ABI_SYMBOLS = (
+    "drmlt_create", "drmlt_seed", "drmlt_run", "drmlt_develop", "drmlt_stats_get", "drmlt_eval_paths",
+    "drmlt_film_read", "drmlt_film_clear", "drmlt_film_device_ptr", "drmlt_set_luminance", "drmlt_set_stream",
+    "drmlt_kernel_time", "drmlt_render_pt", "drmlt_chain_state", "drmlt_last_error", "drmlt_abi_version",
+    "drmlt_destroy",
+)
+
+
 class DrmltError(RuntimeError):
-    pass
-class Context:
-    pass
-def build_native(force=False):
-    pass
+    def __init__(self, code, msg):
+        super().__init__("drmlt error %d: %s" % (code, msg))
+        self.code = code
+
+
 def library_path():
-    return None
+    return _LIB_PATH
+
+
+def build_native(force=False):
+    """Compile the HIP kernels + C-ABI for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    src = os.path.join(_HERE, "csrc")
+    args = ["make", "-C", src]
+    if force:
+        args.append("-B")
+    subprocess.check_call(args, stdout=subprocess.DEVNULL)
+    return _LIB_PATH
+
+
+def load_library():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_LIB_PATH):
+        raise DrmltError(abi.E_DEVICE, "libdrmlt_amd.so is not built (run __graft_entry__.build()); "
+                                       "the DRMLT path has no CPU fallback")
+    L = C.CDLL(_LIB_PATH)
+    L.drmlt_create.restype = C.c_void_p
+    L.drmlt_create.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_char_p, C.c_size_t]
+    L.drmlt_seed.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, C.POINTER(C.c_double)]
+    L.drmlt_run.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.drmlt_develop.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    L.drmlt_stats_get.argtypes = [C.c_void_p, C.c_void_p]
+    L.drmlt_eval_paths.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
+    L.drmlt_film_read.argtypes = [C.c_void_p, C.c_void_p]
+    L.drmlt_film_clear.argtypes = [C.c_void_p]
+    L.drmlt_film_device_ptr.restype = C.c_void_p
+    L.drmlt_film_device_ptr.argtypes = [C.c_void_p]
+    L.drmlt_set_luminance.argtypes = [C.c_void_p, C.c_double]
+    L.drmlt_set_stream.argtypes = [C.c_void_p, C.c_void_p]
+    L.drmlt_kernel_time.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.c_int]
+    L.drmlt_render_pt.argtypes = [C.c_void_p, C.c_uint32, C.c_uint64, C.c_void_p]
+    L.drmlt_chain_state.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]
+    L.drmlt_last_error.restype = C.c_char_p
+    L.drmlt_last_error.argtypes = [C.c_void_p]
+    L.drmlt_abi_version.restype = C.c_uint32
+    L.drmlt_destroy.argtypes = [C.c_void_p]
+    _lib = L
+    return L
+
+
+class Context:
+    def __init__(self, cfg, scene_data, device=0):
+        self.L = load_library()
+        self.cfg = cfg
+        self.scene_data = scene_data
+        self._scene = scene_data.struct()
+        err = C.create_string_buffer(512)
+        self.h = self.L.drmlt_create(C.byref(cfg), C.byref(self._scene), device, err, 512)
+        if not self.h:
+            raise DrmltError(abi.E_INVALID, err.value.decode())
+        self.width, self.height = scene_data.camera.width, scene_data.camera.height
+        self._cb = None
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.drmlt_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise DrmltError(rc, self.L.drmlt_last_error(self.h).decode())
+
+    # -- DRMLT::render sequence
+    def seed(self, seed, chain_offset=0):
+        b = C.c_double()
+        self._chk(self.L.drmlt_seed(self.h, seed, chain_offset, C.byref(b)))
+        return b.value
+
+    def run(self, total_mutations, stop=None, progress=None):
+        cb = abi.PROGRESS_CB(lambda d, t, u: progress(d, t)) if progress else None
+        self._cb = cb
+        stop_p = C.cast(C.pointer(stop), C.c_void_p) if stop is not None else None
+        self._chk(self.L.drmlt_run(self.h, total_mutations, stop_p, C.cast(cb, C.c_void_p) if cb else None, None))
+
+    def develop(self, direct=None):
+        out = np.empty((self.height, self.width, 3), dtype=np.float32)
+        d = None if direct is None else np.ascontiguousarray(direct, dtype=np.float32).ctypes.data
+        self._chk(self.L.drmlt_develop(self.h, d, out.ctypes.data))
+        return out
+
+    def stats(self):
+        s = abi.Stats()
+        self._chk(self.L.drmlt_stats_get(self.h, C.byref(s)))
+        return s
+
+    # -- PathSampler::sampleSplats on explicit PSS points
+    def eval_paths(self, u):
+        u = np.ascontiguousarray(u, dtype=np.float32)
+        n, dim = u.shape
+        out = (abi.Splat * n)()
+        self._chk(self.L.drmlt_eval_paths(self.h, u.ctypes.data, n, dim, out))
+        return np.frombuffer(out, dtype=SPLAT_DTYPE).copy()
+
+    def film(self):
+        out = np.empty((self.height, self.width, 3), dtype=np.float32)
+        self._chk(self.L.drmlt_film_read(self.h, out.ctypes.data))
+        return out
+
+    def film_clear(self):
+        self._chk(self.L.drmlt_film_clear(self.h))
+
+    def film_device_ptr(self):
+        return self.L.drmlt_film_device_ptr(self.h)
+
+    def set_luminance(self, b):
+        self._chk(self.L.drmlt_set_luminance(self.h, b))
+
+    def set_stream(self, stream_handle):
+        self._chk(self.L.drmlt_set_stream(self.h, stream_handle))
+
+    def kernel_time(self, reset=False):
+        ms, n = C.c_double(), C.c_uint64()
+        self._chk(self.L.drmlt_kernel_time(self.h, C.byref(ms), C.byref(n), int(reset)))
+        return ms.value, n.value
+
+    def render_pt(self, spp, seed=1):
+        out = np.empty((self.height, self.width, 3), dtype=np.float32)
+        self._chk(self.L.drmlt_render_pt(self.h, spp, seed, out.ctypes.data))
+        return out
+
+    def chain_state(self, dim):
+        n = self.stats().n_chains
+        cur = (abi.Splat * n)()
+        u = np.empty((n, dim), dtype=np.float32)
+        self._chk(self.L.drmlt_chain_state(self.h, cur, u.ctypes.data, dim))
+        return np.frombuffer(cur, dtype=SPLAT_DTYPE).copy(), u

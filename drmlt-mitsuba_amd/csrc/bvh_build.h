@@ -1,0 +1,134 @@
+// Host-side builder of the 2-wide BVH the kernels traverse (binned SAH, leaves <= 4 prims).
+// The reference uses a SAH kd-tree (src/librender/skdtree.cpp, sahkdtree3.h); a closest-hit
+// query returns the same primitive through either structure, so the builder is free to pick
+// the layout that suits the GPU: one 64 B node = both child boxes, fetched as one line.
+#pragma once
+#include "device_types.h"
+
+#include <algorithm>
+#include <cfloat>
+#include <vector>
+
+struct PrimBounds {
+    float lo[3], hi[3];
+};
+
+namespace bvh_detail {
+
+struct Box {
+    float lo[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, hi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+    void grow(const PrimBounds &b) {
+        for (int k = 0; k < 3; ++k) { lo[k] = std::min(lo[k], b.lo[k]); hi[k] = std::max(hi[k], b.hi[k]); }
+    }
+    void grow(const Box &b) {
+        for (int k = 0; k < 3; ++k) { lo[k] = std::min(lo[k], b.lo[k]); hi[k] = std::max(hi[k], b.hi[k]); }
+    }
+    float area() const {
+        float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+        if (dx < 0 || dy < 0 || dz < 0) return 0.f;
+        return 2.f * (dx * dy + dy * dz + dz * dx);
+    }
+};
+
+constexpr int kLeafMax = 4;
+constexpr int kBins = 16;
+
+struct Builder {
+    const std::vector<PrimBounds> &pb;
+    std::vector<int> &order; // primitive indices, leaf ranges are contiguous
+    std::vector<DBvhNode> &nodes;
+
+    Box range_box(int first, int count) const {
+        Box b;
+        for (int i = 0; i < count; ++i) b.grow(pb[order[first + i]]);
+        return b;
+    }
+
+    // returns split position (number of prims going left), reorders order[first, first+count)
+    int split(int first, int count, const Box &bounds) {
+        Box cb;
+        for (int i = 0; i < count; ++i) {
+            const PrimBounds &p = pb[order[first + i]];
+            for (int k = 0; k < 3; ++k) { float c = 0.5f * (p.lo[k] + p.hi[k]); cb.lo[k] = std::min(cb.lo[k], c); cb.hi[k] = std::max(cb.hi[k], c); }
+        }
+        int bestAxis = -1, bestBin = -1;
+        float bestCost = FLT_MAX;
+        for (int axis = 0; axis < 3; ++axis) {
+            float ext = cb.hi[axis] - cb.lo[axis];
+            if (!(ext > 0.f)) continue;
+            Box bins[kBins];
+            int cnt[kBins] = {0};
+            float scale = kBins / ext;
+            for (int i = 0; i < count; ++i) {
+                const PrimBounds &p = pb[order[first + i]];
+                int b = std::min(kBins - 1, (int) ((0.5f * (p.lo[axis] + p.hi[axis]) - cb.lo[axis]) * scale));
+                bins[b].grow(p);
+                cnt[b]++;
+            }
+            float rightArea[kBins];
+            int rightCnt[kBins];
+            Box acc;
+            int c = 0;
+            for (int b = kBins - 1; b > 0; --b) { acc.grow(bins[b]); c += cnt[b]; rightArea[b] = acc.area(); rightCnt[b] = c; }
+            Box left;
+            int lc = 0;
+            for (int b = 0; b < kBins - 1; ++b) {
+                left.grow(bins[b]);
+                lc += cnt[b];
+                if (lc == 0 || rightCnt[b + 1] == 0) continue;
+                float cost = left.area() * lc + rightArea[b + 1] * rightCnt[b + 1];
+                if (cost < bestCost) { bestCost = cost; bestAxis = axis; bestBin = b; }
+            }
+        }
+        if (bestAxis < 0) return count / 2; // all centroids coincide: split in the middle
+        float ext = cb.hi[bestAxis] - cb.lo[bestAxis], scale = kBins / ext;
+        auto mid = std::partition(order.begin() + first, order.begin() + first + count, [&](int idx) {
+            const PrimBounds &p = pb[idx];
+            int b = std::min(kBins - 1, (int) ((0.5f * (p.lo[bestAxis] + p.hi[bestAxis]) - cb.lo[bestAxis]) * scale));
+            return b <= bestBin;
+        });
+        int nl = (int) (mid - (order.begin() + first));
+        if (nl == 0 || nl == count) return count / 2;
+        (void) bounds;
+        return nl;
+    }
+
+    // builds the subtree over order[first, first+count) (count > kLeafMax) and returns its node index
+    int build(int first, int count) {
+        int self = (int) nodes.size();
+        nodes.emplace_back();
+        Box bounds = range_box(first, count);
+        int nl = split(first, count, bounds);
+        int nr = count - nl;
+        Box bl = range_box(first, nl), br = range_box(first + nl, nr);
+        int c0, c1, n0 = 0, n1 = 0;
+        if (nl <= kLeafMax) { c0 = ~first; n0 = nl; } else { c0 = build(first, nl); }
+        if (nr <= kLeafMax) { c1 = ~(first + nl); n1 = nr; } else { c1 = build(first + nl, nr); }
+        DBvhNode &N = nodes[self];
+        for (int k = 0; k < 3; ++k) { N.lo0[k] = bl.lo[k]; N.hi0[k] = bl.hi[k]; N.lo1[k] = br.lo[k]; N.hi1[k] = br.hi[k]; }
+        N.c0 = c0; N.c1 = c1; N.n0 = n0; N.n1 = n1;
+        return self;
+    }
+};
+
+} // namespace bvh_detail
+
+// nodes[0] is the root. `order[i]` = original index of the primitive stored in slot i.
+inline void build_bvh(const std::vector<PrimBounds> &pb, std::vector<DBvhNode> &nodes, std::vector<int> &order) {
+    using namespace bvh_detail;
+    const int n = (int) pb.size();
+    order.resize(n);
+    for (int i = 0; i < n; ++i) order[i] = i;
+    nodes.clear();
+    Builder b{pb, order, nodes};
+    if (n <= kLeafMax) {
+        // single leaf under a root whose second child is empty
+        nodes.emplace_back();
+        Box box = b.range_box(0, n);
+        DBvhNode &N = nodes[0];
+        for (int k = 0; k < 3; ++k) { N.lo0[k] = box.lo[k]; N.hi0[k] = box.hi[k]; N.lo1[k] = FLT_MAX; N.hi1[k] = -FLT_MAX; }
+        N.c0 = ~0; N.n0 = n; N.c1 = ~0; N.n1 = 0;
+        return;
+    }
+    b.build(0, n);
+}

@@ -1,0 +1,552 @@
+// Device code of the DRMLT hot path: PSS samplers (transition kernels evaluated lazily as
+// pure functions of the addressed RNG), ray queries, and the unidirectional estimator as a
+// resumable state machine with exactly one ray query per step.
+//
+// Reference behaviour restated here (paths relative to the reference checkout):
+//   transition kernels       src/integrators/drmlt/tools/transition.h:54-190
+//   fillSpace / wrap         src/integrators/drmlt/drmlt_sampler.cpp:313-394, drmlt_sampler.h:140-144
+//   sampleSplats (path)      src/libbidir/pathsampler.cpp:529-567
+//   MIPathTracer::Li         src/integrators/path/path.cpp:123-321
+//   ray epsilons             src/librender/skdtree.cpp:125-129,213-218, scene.cpp:891-893
+//   emitter sampling         src/librender/scene.cpp:879-904, shape.cpp:102-127, area.cpp:111-189
+//   diffuse / dielectric     src/bsdfs/diffuse.cpp:110-149, dielectric.cpp:228-333
+//   perspective sensor       src/sensors/perspective.cpp:271-300
+#pragma once
+#include "device_math.h"
+#include "device_types.h"
+
+// Current PSS states of the 64 chains of this wave, [dim][lane]: lane-contiguous rows, so any
+// per-lane dimension pattern is bank-conflict free (64 == 0 mod 32 banks). Addressed directly
+// (ds_read), never through a generic pointer: LDS offset 0 casts to the flat null pointer.
+extern __shared__ float lds_x[];
+
+// ------------------------------------------------------------------ PSS sampler
+enum { SM_BOOT = 0, SM_ARRAY = 1, SM_STAGE1 = 2, SM_STAGE2 = 3, SM_REVERSE = 4, SM_PT = 5 };
+
+DEV float wrap01(float y) { return y > 1.f ? 2.f - y : (y <= 0.f ? fabsf(y) : y); } // drmlt_sampler.h:140-144
+
+#define KELEMEN_S1 (1.0f / 1024.0f)
+#define KELEMEN_S2 (1.0f / 64.0f)
+#define ORBITAL_SCALE 1.9f
+#define LOG2_S1_OVER_S2 (-4.0f) // log2((1/1024)/(1/64))
+// wrapped Cauchy: rho = exp(-1/4), dispersion c = 2 rho / (1 + rho^2)
+#define WC_DISPERSION 0.96954361f
+
+// Kelemen kernel (transition.h:97-111): sign * s2 * (s1/s2)^(1 - xi')
+DEV float kelemen_sample(float xi, float s2) {
+    float sign = 1.f;
+    if (xi < 0.5f) { xi *= 2.f; } else { sign = -1.f; xi = 2.f * (xi - 0.5f); }
+    return sign * s2 * fast_exp2((1.f - xi) * LOG2_S1_OVER_S2);
+}
+// Gaussian kernel (transition.h:61-66), Box-Muller cosine branch
+DEV float gaussian_sample(float u1, float u2, float sigma) {
+    float tmp = sqrtf(-1.3862943611198906f * fast_log2(1.f - u1)); // -2 ln(v) = -2 ln2 log2(v)
+    return tmp * cos_rev(u2) * sigma;
+}
+// log pdf of the (unscaled) Kelemen kernel, transition.h:113-122
+DEV float kelemen_logpdf(float du) {
+    float d = fabsf(du);
+    if (d < KELEMEN_S1 || d > KELEMEN_S2) return -INFINITY;
+    return -__logf(2.f * d * 2.772588722239781f); // ln(s2/s1) = ln 16
+}
+
+struct Sampler {
+    // addressing
+    uint32_t key0, key1, chain, major; // major: mutation index (chains) or sample index (boot / pt)
+    int mode, type;
+    bool large;
+    float sigma2;
+    uint32_t lane;    // chain state lives in LDS: x[k] = lds_x[k * 64 + lane]
+    const float *arr; // SM_ARRAY: explicit PSS vector
+    // one-block caches
+    u4 b1, b2;
+    uint32_t b1_idx, b2_idx;
+    // orbital pair cache
+    uint32_t pair_base;
+    float pair_y0, pair_y1, pair_z0, pair_z1;
+    bool pair_has_z;
+
+    DEV void reset_caches() { b1_idx = b2_idx = 0xffffffffu; pair_base = 0xffffffffu; }
+
+    DEV float u_boot(uint32_t k, uint32_t tag) {
+        uint32_t blk = k >> 2;
+        if (blk != b1_idx) { b1 = philox4x32_10(key0, key1, blk, major, chain, tag); b1_idx = blk; }
+        return pick4(b1, k & 3u);
+    }
+    DEV float u_s1(uint32_t idx) {
+        uint32_t blk = idx >> 2;
+        if (blk != b1_idx) { b1 = philox4x32_10(key0, key1, blk, major, chain, TAG_S1); b1_idx = blk; }
+        return pick4(b1, idx & 3u);
+    }
+    DEV float u_s2(uint32_t idx) {
+        uint32_t blk = idx >> 2;
+        if (blk != b2_idx) { b2 = philox4x32_10(key0, key1, blk, major, chain, TAG_S2); b2_idx = blk; }
+        return pick4(b2, idx & 3u);
+    }
+    DEV float x(uint32_t k) const { return lds_x[k * 64u + lane]; }
+
+    // first-stage proposal, unwrapped (fillSpace with isFirst = true)
+    DEV float y_raw(uint32_t k) {
+        if (large) return u_s1(k);
+        if (type != 2 /*orbital*/) return x(k) + kelemen_sample(u_s1(k), KELEMEN_S2);
+        ensure_pair(k & ~1u, false);
+        return (k & 1u) ? pair_y1 : pair_y0;
+    }
+    // second-stage proposal, unwrapped (fillSpace with isFirst = false)
+    DEV float z_raw(uint32_t k) {
+        // second stage of a large step (timidAfterLarge): the reference's fillSpace takes its
+        // uniform branch again (drmlt_sampler.cpp:319-321 behind a debug-only assertion)
+        if (large) return u_s2(k);
+        if (type != 2) return x(k) + gaussian_sample(u_s2(2u * k), u_s2(2u * k + 1u), sigma2);
+        ensure_pair(k & ~1u, true);
+        return (k & 1u) ? pair_z1 : pair_z0;
+    }
+    // orbital pair (k0, k0+1): y = x + d (cos a, sin a); z = y + R(theta) (x - y)
+    DEV void ensure_pair(uint32_t k0, bool need_z) {
+        if (pair_base != k0) {
+            pair_base = k0;
+            float x0 = x(k0), x1 = x(k0 + 1u);
+            if (large) {
+                pair_y0 = u_s1(k0);
+                pair_y1 = u_s1(k0 + 1u);
+            } else {
+                float d = kelemen_sample(u_s1(k0), KELEMEN_S2 * ORBITAL_SCALE);
+                float a = u_s1(k0 + 1u);
+                pair_y0 = fmaf(d, cos_rev(a), x0);
+                pair_y1 = fmaf(d, sin_rev(a), x1);
+            }
+            pair_has_z = false;
+        }
+        if (need_z && !pair_has_z) {
+            pair_has_z = true;
+            float x0 = x(k0), x1 = x(k0 + 1u);
+            // theta ~ wrapped Cauchy by inverse CDF (transition.h:157-173): cos(theta) = A
+            float xi = u_s2(k0 >> 1);
+            float sign = 1.f;
+            if (xi < 0.5f) { xi *= 2.f; } else { sign = -1.f; xi = 2.f * (xi - 0.5f); }
+            float V = cos_rev(xi);
+            float A = fminf(1.f, fmaxf(-1.f, (V + WC_DISPERSION) / (1.f + WC_DISPERSION * V)));
+            float ct = A, st = sign * sqrtf(fmaxf(0.f, 1.f - A * A));
+            // (x - y) rotated by theta about y: identical to y + |x-y| (cos, sin)(theta + mu),
+            // mu the polar angle of x - y (drmlt_sampler.cpp:374-391), without the acos round trip
+            float dx0 = x0 - pair_y0, dx1 = x1 - pair_y1;
+            pair_z0 = pair_y0 + (ct * dx0 - st * dx1);
+            pair_z1 = pair_y1 + (st * dx0 + ct * dx1);
+        }
+    }
+
+    // value handed to the path code for PSS dimension k (primarySample)
+    DEV float next(uint32_t k) {
+        switch (mode) {
+            case SM_BOOT: return u_boot(k, TAG_BOOT);
+            case SM_PT: return u_boot(k, TAG_PT);
+            case SM_ARRAY: return arr[k];
+            case SM_STAGE1: return wrap01(y_raw(k));
+            case SM_STAGE2: return wrap01(z_raw(k));
+            default: { // Green reverse: y* = z - (y - x)
+                float du = y_raw(k) - x(k);
+                return wrap01(z_raw(k) - du);
+            }
+        }
+    }
+};
+
+// ------------------------------------------------------------------ ray queries
+struct Hit {
+    int prim;
+    float t, u, v;
+};
+
+// One primitive against one ray. `P` is wave-uniform in the brute-force loop (SGPR operands).
+DEV void intersect_prim(const DPrim &P, int idx, f3 o, f3 d, float tmin, Hit &h) {
+    f3 lo = mk3(fmaf(P.m[0], o.x, fmaf(P.m[1], o.y, fmaf(P.m[2], o.z, P.m[3]))),
+                fmaf(P.m[4], o.x, fmaf(P.m[5], o.y, fmaf(P.m[6], o.z, P.m[7]))),
+                fmaf(P.m[8], o.x, fmaf(P.m[9], o.y, fmaf(P.m[10], o.z, P.m[11]))));
+    f3 ld = mk3(fmaf(P.m[0], d.x, fmaf(P.m[1], d.y, P.m[2] * d.z)), fmaf(P.m[4], d.x, fmaf(P.m[5], d.y, P.m[6] * d.z)),
+                fmaf(P.m[8], d.x, fmaf(P.m[9], d.y, P.m[10] * d.z)));
+    if (P.type != PRIM_SPHERE) {
+        float t = -lo.z * fast_rcp(ld.z);
+        float u = fmaf(t, ld.x, lo.x), v = fmaf(t, ld.y, lo.y);
+        bool inside = (P.type == PRIM_TRIANGLE) ? (u >= 0.f && v >= 0.f && u + v <= 1.f)
+                                                : (fabsf(u) <= 1.f && fabsf(v) <= 1.f);
+        if (inside && t >= tmin && t <= h.t) { h.prim = idx; h.t = t; h.u = u; h.v = v; }
+    } else {
+        // unit sphere; discriminant from the closest-approach vector (stable in fp32)
+        float A = dot3(ld, ld), invA = fast_rcp(A);
+        float b = dot3(lo, ld);
+        f3 l = fma3(ld, -b * invA, lo);
+        float disc = A * (1.f - dot3(l, l));
+        if (disc >= 0.f) {
+            float sq = sqrtf(disc);
+            float q = (b < 0.f) ? -(b - sq) : -(b + sq); // = -0.5 (B -/+ sqrt(discrim)) with B = 2b
+            float c = dot3(lo, lo) - 1.f;
+            float t0 = q * invA, t1 = c / q;
+            float nearT = fminf(t0, t1), farT = fmaxf(t0, t1);
+            // sphere.cpp:176-188
+            if (nearT <= h.t && farT >= tmin) {
+                float t = nearT;
+                bool ok = true;
+                if (nearT < tmin) { t = farT; ok = farT <= h.t; }
+                if (ok) { h.prim = idx; h.t = t; h.u = 0.f; h.v = 0.f; }
+            }
+        }
+    }
+}
+
+// closest hit in [tmin, tmax] over all primitives (the loop index is wave-uniform, so the
+// 64 B primitive record arrives through the scalar cache and feeds VALU ops as SGPRs)
+DEV Hit trace_brute(const DParams &P, f3 o, f3 d, float tmin, float tmax) {
+    Hit h{-1, tmax, 0.f, 0.f};
+    const int n = P.n_prims;
+    for (int i = 0; i < n; ++i) intersect_prim(P.prims[i], i, o, d, tmin, h);
+    return h;
+}
+
+// 2-wide BVH traversal with a short per-lane stack; leaves index into the prim array.
+DEV Hit trace_bvh(const DParams &P, f3 o, f3 d, float tmin, float tmax, bool any_hit) {
+    Hit h{-1, tmax, 0.f, 0.f};
+    f3 inv = mk3(1.f / d.x, 1.f / d.y, 1.f / d.z);
+    int stack[24];
+    int sp = 0;
+    int node = 0;
+    for (;;) {
+        const DBvhNode N = P.bvh[node];
+        float t0x = (N.lo0[0] - o.x) * inv.x, t1x = (N.hi0[0] - o.x) * inv.x;
+        float t0y = (N.lo0[1] - o.y) * inv.y, t1y = (N.hi0[1] - o.y) * inv.y;
+        float t0z = (N.lo0[2] - o.z) * inv.z, t1z = (N.hi0[2] - o.z) * inv.z;
+        float nearA = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fmaxf(fminf(t0z, t1z), tmin));
+        float farA = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fminf(fmaxf(t0z, t1z), h.t));
+        t0x = (N.lo1[0] - o.x) * inv.x; t1x = (N.hi1[0] - o.x) * inv.x;
+        t0y = (N.lo1[1] - o.y) * inv.y; t1y = (N.hi1[1] - o.y) * inv.y;
+        t0z = (N.lo1[2] - o.z) * inv.z; t1z = (N.hi1[2] - o.z) * inv.z;
+        float nearB = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fmaxf(fminf(t0z, t1z), tmin));
+        float farB = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fminf(fmaxf(t0z, t1z), h.t));
+        bool hitA = nearA <= farA, hitB = nearB <= farB;
+        int next = -1;
+        // leaves are intersected immediately; inner children are pushed far-first
+        int cA = N.c0, cB = N.c1, nA = N.n0, nB = N.n1;
+        if (hitA && cA < 0) {
+            int first = ~cA;
+            for (int i = 0; i < nA; ++i) intersect_prim(P.prims[first + i], first + i, o, d, tmin, h);
+            hitA = false;
+        }
+        if (hitB && cB < 0) {
+            int first = ~cB;
+            if (nearB <= h.t)
+                for (int i = 0; i < nB; ++i) intersect_prim(P.prims[first + i], first + i, o, d, tmin, h);
+            hitB = false;
+        }
+        if (any_hit && h.prim >= 0) return h;
+        if (hitA && hitB) {
+            bool aFirst = nearA <= nearB;
+            next = aFirst ? cA : cB;
+            if (sp < 24) stack[sp++] = aFirst ? cB : cA;
+        } else if (hitA) {
+            next = cA;
+        } else if (hitB) {
+            next = cB;
+        }
+        if (next < 0) {
+            if (sp == 0) break;
+            next = stack[--sp];
+        }
+        node = next;
+    }
+    return h;
+}
+
+DEV Hit trace(const DParams &P, f3 o, f3 d, float tmin, float tmax, bool any_hit) {
+    if (P.use_bvh) return trace_bvh(P, o, d, tmin, tmax, any_hit);
+    return trace_brute(P, o, d, tmin, tmax);
+}
+
+// ------------------------------------------------------------------ estimator state machine
+// MIPathTracer::Li + the sampleSplats prologue as a resumable machine. One call of path_step
+// consumes the result of the ray query issued by the previous call and issues the next one.
+// All PSS components a step needs are drawn at ONE site (the `next` loop below): the sampler
+// code (Philox + transition kernels) is the bulk of the instruction footprint, so it is
+// instantiated once per kernel instead of once per consumer.
+enum { PH_DONE = 0, PH_BEGIN = 1, PH_CLOSEST = 2, PH_SHADOW = 3 };
+
+struct PathState {
+    f3 o, d;          // ray to trace next (o doubles as the current surface point)
+    float tmin, tmax;
+    f3 thr, Li;
+    f3 n, s, wi;      // shading frame (t = n x s) and local incident direction at the current vertex
+    f3 nee;           // NEE contribution pending on the shadow ray
+    f3 bweight;       // BSDF sample weight pending on the bounce ray
+    float bpdf, beta_eta, eta;
+    float bx, by;     // BSDF sample components, drawn together with the NEE ones
+    float px, py;     // film position of this sample
+    int phase, depth, bsdf;
+    uint32_t k;       // next PSS dimension
+    uint32_t nrays;
+    bool non_specular, direct_on, has_bounce, bdelta, refn_zero;
+};
+
+DEV float ray_eps_closest(f3 o) { // skdtree.cpp:125-129
+    return EPSILON_F * fmaxf(fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fabsf(o.z)), EPSILON_F);
+}
+DEV float ray_eps_shadow(f3 o) { // skdtree.cpp:213-218
+    return EPSILON_F * fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fabsf(o.z));
+}
+
+// warp.cpp:81-102 + :43-52 (angles expressed in revolutions for v_sin/v_cos)
+DEV f3 square_to_cosine_hemisphere(float sx, float sy) {
+    float r1 = 2.f * sx - 1.f, r2 = 2.f * sy - 1.f;
+    float r, rev;
+    if (r1 == 0.f && r2 == 0.f) { r = 0.f; rev = 0.f; }
+    else if (r1 * r1 > r2 * r2) { r = r1; rev = 0.125f * (r2 / r1); }
+    else { r = r2; rev = 0.25f - 0.125f * (r1 / r2); }
+    float px = r * cos_rev(rev), py = r * sin_rev(rev);
+    float z = sqrtf(fmaxf(0.f, 1.f - px * px - py * py));
+    if (z == 0.f) z = 1e-10f;
+    return mk3(px, py, z);
+}
+
+// util.cpp:659-689
+DEV float fresnel_dielectric_ext(float cosThetaI_, float &cosThetaT_, float eta) {
+    if (eta == 1.f) { cosThetaT_ = -cosThetaI_; return 0.f; }
+    float scale = (cosThetaI_ > 0.f) ? 1.f / eta : eta;
+    float cosThetaTSqr = 1.f - (1.f - cosThetaI_ * cosThetaI_) * (scale * scale);
+    if (cosThetaTSqr <= 0.f) { cosThetaT_ = 0.f; return 1.f; }
+    float cosThetaI = fabsf(cosThetaI_), cosThetaT = sqrtf(cosThetaTSqr);
+    float Rs = (cosThetaI - eta * cosThetaT) / (cosThetaI + eta * cosThetaT);
+    float Rp = (eta * cosThetaI - cosThetaT) / (eta * cosThetaI + cosThetaT);
+    cosThetaT_ = (cosThetaI_ > 0.f) ? -cosThetaT : cosThetaT;
+    return 0.5f * (Rs * Rs + Rp * Rp);
+}
+
+DEV void path_init(const DParams &P, PathState &ps) {
+    ps.phase = PH_BEGIN;
+    ps.k = 0u;
+    ps.nrays = 0u;
+    ps.thr = mk3(1.f, 1.f, 1.f);
+    ps.Li = mk3(0.f, 0.f, 0.f);
+    ps.eta = 1.f;
+    ps.depth = 1;
+    ps.non_specular = false;
+    ps.direct_on = P.exclude_direct == 0; // pathsampler.cpp:558-561
+    ps.has_bounce = false;
+    ps.refn_zero = false;
+    ps.px = ps.py = 0.f;
+}
+
+// Consume the result of the ray query issued for `ps` (none in PH_BEGIN) and either issue the
+// next ray (PH_CLOSEST / PH_SHADOW) or finish the path (PH_DONE, radiance in ps.Li).
+DEV void path_step(const DParams &P, PathState &ps, Sampler &smp, const Hit &hit) {
+    // ---------------- part 1: digest the ray query, decide which PSS components are needed
+    bool want_rr = false, want_nee = false;
+    int need = 0;
+    float rr_q = 1.f;
+    f3 p = ps.o, n = ps.n, s = ps.s;
+    DBsdf B;
+    if (ps.phase == PH_BEGIN) {
+        need = 2; // film position, pathsampler.cpp:538-543
+    } else if (ps.phase == PH_SHADOW) {
+        if (hit.prim < 0) ps.Li = ps.Li + ps.nee; // unoccluded
+        B = P.bsdfs[ps.bsdf];
+    } else {
+        if (hit.prim < 0) { ps.phase = PH_DONE; return; } // no environment emitter
+        const DShade S = P.shade[hit.prim];
+        const int ptype = P.prims[hit.prim].type;
+        // surface point + shading frame (skdtree.h:340-429, rectangle.cpp:155-168, sphere.cpp:207-255)
+        if (ptype != PRIM_SPHERE) {
+            p = fma3(ld3(S.eu), hit.u, fma3(ld3(S.ev), hit.v, ld3(S.origin)));
+            n = ld3(S.n);
+            s = ld3(S.eu) * S.inv_len_eu;
+        } else {
+            f3 c = ld3(S.origin);
+            f3 local = normalize3(fma3(ps.d, hit.t, ps.o) - c);
+            p = fma3(local, S.eu[0], c);
+            n = local;
+            float zrad2 = local.x * local.x + local.y * local.y;
+            float inv = rsqrtf(zrad2);
+            s = zrad2 > 0.f ? mk3(-local.y * inv, local.x * inv, 0.f) : mk3(1.f, 0.f, 0.f);
+        }
+        if (ps.has_bounce) {
+            ps.thr = ps.thr * ps.bweight;
+            ps.eta *= ps.beta_eta;
+            // emitter hit by the BSDF-sampled ray: MIS against direct sampling (path.cpp:269-285)
+            if (S.emitter >= 0 && ps.direct_on && ps.non_specular) {
+                const DEmitter E = P.emitters[S.emitter];
+                float dn = dot3(ps.d, n);
+                if (dn < 0.f) { // AreaLight::eval: dot(n, -d) > 0
+                    float lumPdf = 0.f;
+                    if (!ps.bdelta) { // pdfEmitterDirect: refN belongs to the PREVIOUS vertex (ps.n) or is 0
+                        float dr = ps.refn_zero ? 0.f : dot3(ps.d, ps.n);
+                        if (dr >= 0.f) lumPdf = S.inv_area * hit.t * hit.t / fabsf(dn) * (E.cdf_hi - E.cdf_lo);
+                    }
+                    float a = ps.bpdf * ps.bpdf, b = lumPdf * lumPdf;
+                    ps.Li = fma3(ps.thr * ld3(E.radiance), a / (a + b), ps.Li);
+                }
+            }
+            ps.direct_on = true;                   // rRec.type = ERadianceNoEmission
+            want_rr = ps.depth++ >= P.rr_depth;    // russian roulette, path.cpp:297-307
+        }
+        // `depth >= maxDepth` ends the path whatever the roulette draw says, so test it first
+        if (ps.depth >= P.max_depth && P.max_depth > 0) {
+            if (want_rr) ps.k++;
+            ps.phase = PH_DONE;
+            return;
+        }
+        if (want_rr) rr_q = fminf(max3(ps.thr) * ps.eta * ps.eta, 0.95f);
+        // adopt the new vertex
+        f3 t = cross3(n, s);
+        f3 md = -ps.d;
+        ps.wi = mk3(dot3(md, s), dot3(md, t), dot3(md, n));
+        ps.o = p; ps.n = n; ps.s = s;
+        ps.bsdf = S.bsdf;
+        B = P.bsdfs[S.bsdf];
+        ps.refn_zero = B.type == 1; // transmissive / two-sided: DirectSamplingRecord(its) zeroes refN
+        want_nee = ps.direct_on && (B.type == 0 || B.type == 2);
+        need = (want_rr ? 1 : 0) + (want_nee ? 2 : 0) + 2;
+    }
+
+    // ---------------- part 2: the one place PSS components are drawn
+    float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f, v4 = 0.f;
+#pragma nounroll
+    for (int j = 0; j < need; ++j) {
+        float v = smp.next(ps.k + (uint32_t) j);
+        if (j == 0) v0 = v; else if (j == 1) v1 = v; else if (j == 2) v2 = v; else if (j == 3) v3 = v; else v4 = v;
+    }
+
+    // ---------------- part 3: use them
+    if (ps.phase == PH_BEGIN) {
+        // sampleRayDifferential, perspective.cpp:271-286
+        ps.k = 2u;
+        ps.px = v0 * (float) P.width;
+        ps.py = v1 * (float) P.height;
+        f3 nearP = mk3((1.f - 2.f * v0) * P.tan_half_fov * P.near_clip, (1.f - 2.f * v1) * P.tan_half_fov * P.inv_aspect * P.near_clip,
+                       P.near_clip);
+        f3 dl = normalize3(nearP);
+        float invZ = 1.f / dl.z;
+        ps.tmin = P.near_clip * invZ;
+        ps.tmax = P.far_clip * invZ;
+        ps.o = mk3(P.cam[3], P.cam[7], P.cam[11]);
+        ps.d = mk3(fmaf(P.cam[0], dl.x, fmaf(P.cam[1], dl.y, P.cam[2] * dl.z)), fmaf(P.cam[4], dl.x, fmaf(P.cam[5], dl.y, P.cam[6] * dl.z)),
+                   fmaf(P.cam[8], dl.x, fmaf(P.cam[9], dl.y, P.cam[10] * dl.z)));
+        ps.phase = PH_CLOSEST;
+        ps.nrays = 1u;
+        return;
+    }
+    if (ps.phase == PH_CLOSEST) {
+        if (want_rr) {
+            ps.k++;
+            if (v0 >= rr_q) { ps.phase = PH_DONE; return; }
+            ps.thr = ps.thr * (1.f / rr_q);
+        }
+        float sx = want_rr ? v1 : v0, sy = want_rr ? v2 : v1;
+        const int bpos = (want_rr ? 1 : 0) + (want_nee ? 2 : 0);
+        ps.bx = bpos == 0 ? v0 : (bpos == 1 ? v1 : (bpos == 2 ? v2 : v3));
+        ps.by = bpos == 0 ? v1 : (bpos == 1 ? v2 : (bpos == 2 ? v3 : v4));
+        // direct illumination sampling (path.cpp:187-218, scene.cpp:879-904)
+        if (want_nee) {
+            ps.k += 2u;
+            f3 t = cross3(n, s);
+            int ei = 0; // DiscreteDistribution::sample (lower_bound semantics)
+            for (int i = 1; i < P.n_emitters; ++i)
+                if (P.emitters[i].cdf_lo < sx) ei = i;
+            const DEmitter E = P.emitters[ei];
+            float emPdf = E.cdf_hi - E.cdf_lo;
+            sx = (sx - E.cdf_lo) / emPdf; // sampleReuse
+            const DShade L = P.shade[E.prim];
+            f3 lp;
+            if (P.prims[E.prim].type == PRIM_RECTANGLE) { // rectangle.cpp:210-216
+                lp = fma3(ld3(L.eu), sx * 2.f - 1.f, fma3(ld3(L.ev), sy * 2.f - 1.f, ld3(L.origin)));
+            } else { // single triangle: squareToUniformTriangle
+                float a = sqrtf(fmaxf(0.f, 1.f - sx));
+                lp = fma3(ld3(L.eu), 1.f - a, fma3(ld3(L.ev), a * sy, ld3(L.origin)));
+            }
+            f3 ln = ld3(L.n);
+            f3 dv = lp - p;
+            float dist2 = dot3(dv, dv), dist = sqrtf(dist2);
+            f3 dd = dv * (1.f / dist);
+            float dln = dot3(dd, ln);
+            float pdf = dln != 0.f ? L.inv_area * dist2 / fabsf(dln) : 0.f; // Shape::sampleDirect
+            float dr = ps.refn_zero ? 0.f : dot3(dd, n);
+            if (dr >= 0.f && dln < 0.f && pdf != 0.f) { // AreaLight::sampleDirect
+                f3 wo = mk3(dot3(dd, s), dot3(dd, t), dot3(dd, n));
+                // diffuse eval / pdf (diffuse.cpp:110-127)
+                if (ps.wi.z > 0.f && wo.z > 0.f) {
+                    f3 bsdfVal = ld3(B.rgb) * (INV_PI_F * wo.z);
+                    float bsdfPdf = INV_PI_F * wo.z;
+                    float lpdf = pdf * emPdf;
+                    float a = lpdf * lpdf, b = bsdfPdf * bsdfPdf;
+                    f3 value = ld3(E.radiance) * (1.f / lpdf);
+                    f3 c = ps.thr * value * bsdfVal * (a / (a + b));
+                    if (!is_zero3(c)) {
+                        ps.nee = c;
+                        ps.d = dd;
+                        ps.tmin = ray_eps_shadow(p);
+                        ps.tmax = dist * (1.f - SHADOW_EPSILON_F);
+                        ps.phase = PH_SHADOW;
+                        ps.nrays++;
+                        return;
+                    }
+                }
+            }
+        }
+    }
+    // ---------------- BSDF sampling (path.cpp:224-245), reached from PH_CLOSEST and PH_SHADOW
+    ps.k += 2u;
+    f3 wo;
+    if (B.type == 0) { // diffuse.cpp:139-149
+        if (!(ps.wi.z > 0.f)) { ps.phase = PH_DONE; return; }
+        wo = square_to_cosine_hemisphere(ps.bx, ps.by);
+        ps.bpdf = INV_PI_F * wo.z;
+        ps.bweight = ld3(B.rgb);
+        ps.beta_eta = 1.f;
+        ps.bdelta = false;
+    } else if (B.type == 1) { // dielectric.cpp:270-306
+        float eta = B.p[0], invEta = B.p[1];
+        float cosThetaT;
+        float F = fresnel_dielectric_ext(ps.wi.z, cosThetaT, eta);
+        ps.bdelta = true;
+        if (ps.bx <= F) {
+            wo = mk3(-ps.wi.x, -ps.wi.y, ps.wi.z);
+            ps.bpdf = F;
+            ps.bweight = mk3(1.f, 1.f, 1.f);
+            ps.beta_eta = 1.f;
+        } else {
+            float scale = -(cosThetaT < 0.f ? invEta : eta);
+            wo = mk3(scale * ps.wi.x, scale * ps.wi.y, cosThetaT);
+            ps.beta_eta = cosThetaT < 0.f ? eta : invEta;
+            ps.bpdf = 1.f - F;
+            float factor = cosThetaT < 0.f ? invEta : eta;
+            ps.bweight = mk3(factor * factor, factor * factor, factor * factor);
+        }
+    } else {
+        ps.phase = PH_DONE;
+        return;
+    }
+    if (is_zero3(ps.bweight)) { ps.phase = PH_DONE; return; }
+    ps.non_specular = ps.non_specular || !ps.bdelta;
+    f3 t = cross3(ps.n, ps.s);
+    ps.d = fma3(ps.s, wo.x, fma3(t, wo.y, ps.n * wo.z));
+    ps.tmin = ray_eps_closest(ps.o);
+    ps.tmax = INFINITY;
+    ps.has_bounce = true;
+    ps.phase = PH_CLOSEST;
+    ps.nrays++;
+}
+
+// Run one full PSS evaluation (one wave-divergent loop; every step issues at most one ray query).
+DEV DSplat eval_path(const DParams &P, Sampler &smp, uint32_t &nrays, uint32_t &ndims) {
+    PathState ps;
+    smp.reset_caches();
+    path_init(P, ps);
+    Hit h{-1, 0.f, 0.f, 0.f};
+    for (;;) {
+        if (ps.phase != PH_BEGIN) h = trace(P, ps.o, ps.d, ps.tmin, ps.tmax, ps.phase == PH_SHADOW);
+        path_step(P, ps, smp, h);
+        if (ps.phase == PH_DONE) break;
+    }
+    DSplat out;
+    out.px = ps.px; out.py = ps.py;
+    out.r = ps.Li.x; out.g = ps.Li.y; out.b = ps.Li.z;
+    out.lum = luminance3(ps.Li);
+    nrays = ps.nrays;
+    ndims = ps.k;
+    return out;
+}

@@ -1,0 +1,91 @@
+// Device-side data layout of the DRMLT hot path (gfx950). Plain structs shared by the
+// host-side C-ABI (drmlt_capi.cpp) and the kernels (kernels.hip).
+//
+// HBM layout (all fp32 unless noted), n = chains on this GPU, D = PSS dims kept per chain:
+//   x        [D][n]   current PSS state, SoA: lane-contiguous 256 B rows per dimension
+//   cur_*    [n]      current state's luminance, splat position, normalised RGB
+//   film     [H][W][3] accumulation film, float atomics (ImageBlock semantics, border dropped)
+//   prims    [P] x 64 B  intersection records (wave-uniform scalar loads in the brute-force loop)
+//   shade    [P] x 64 B  shading records (per-lane gathers after a hit)
+//   bvh      [N] x 64 B  2-wide BVH nodes (both child boxes in one 64 B line)
+#pragma once
+#include <stdint.h>
+
+#define DRMLT_MAX_LDS_PRIMS 96
+
+enum { PRIM_TRIANGLE = 0, PRIM_RECTANGLE = 1, PRIM_SPHERE = 2 };
+
+// World -> primitive space affine map (rows), so that one transform serves all three
+// primitive kinds: triangle -> barycentric (u,v,w); rectangle -> Mitsuba object space
+// ([-1,1]^2, z=0); sphere -> unit sphere. The ray parameter t is preserved by an affine map.
+struct DPrim {
+    float m[12];
+    int32_t type;
+    int32_t pad[3];
+};
+
+struct DShade {
+    float origin[3]; // tri: p0; rect: centre; sphere: centre
+    float eu[3];     // tri: p1-p0; rect: objectToWorld column 0; sphere: eu[0] = radius
+    float ev[3];     // tri: p2-p0; rect: objectToWorld column 1
+    float n[3];      // unit geometric (= shading) normal of flat primitives
+    float inv_len_eu;
+    int32_t bsdf;
+    int32_t emitter; // -1: none
+    float inv_area;
+};
+
+struct DBsdf {
+    int32_t type;
+    float rgb[3];
+    float p[8]; // dielectric: p[0] = eta (int/ext), p[1] = 1/eta
+};
+
+struct DEmitter {
+    float radiance[3];
+    int32_t prim;
+    float cdf_lo, cdf_hi; // DiscreteDistribution entries (normalised)
+    float pad[2];
+};
+
+struct DBvhNode {      // 64 B
+    float lo0[3], hi0[3]; // child 0 box
+    float lo1[3], hi1[3]; // child 1 box
+    int32_t c0, c1;       // >= 0: inner node index; < 0: leaf, ~c = first prim slot
+    int32_t n0, n1;       // leaf primitive counts (0 for inner children)
+};
+
+struct DParams {
+    // scene
+    const DPrim *prims;
+    const DShade *shade;
+    const DBsdf *bsdfs;
+    const DEmitter *emitters;
+    const DBvhNode *bvh;
+    const float *filter_lut; // 32 entries (MTS_FILTER_RESOLUTION + 1)
+    int32_t n_prims, n_emitters, n_bvh_nodes, use_bvh;
+    // sensor + film
+    float cam[12]; // camera-to-world rows (3x4)
+    float tan_half_fov, inv_aspect, near_clip, far_clip;
+    int32_t width, height;
+    float filter_radius, filter_scale;
+    float *film;
+    // configuration
+    int32_t type, max_depth, rr_depth, exclude_direct;
+    int32_t acceptance_map, timid_after_large, use_mixture, max_dim, eff_dim;
+    float p_large, sigma2; // sigma2 = scaleSecond * sigma
+    // rng
+    uint32_t key0, key1, chain_offset, boot_stream;
+    // chains
+    uint32_t n_chains;
+    float *x;
+    float *cur_lum, *cur_px, *cur_py, *cur_r, *cur_g, *cur_b;
+    unsigned long long *stats; // 18 counters, layout of drmlt_stats
+    int32_t *error_flag;
+    int32_t debug; // DRMLT_DEBUG bit mask (diagnostics only)
+};
+
+// result of one PSS evaluation, SoA-friendly
+struct DSplat {
+    float lum, px, py, r, g, b;
+};

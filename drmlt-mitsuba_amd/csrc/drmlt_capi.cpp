@@ -1,0 +1,692 @@
+// C-ABI of the MI355X-native DRMLT hot path (include/drmlt_abi.h): context management,
+// scene flattening, bootstrap/seeding host logic and kernel orchestration. Everything that
+// touches path evaluation runs in the HIP kernels of kernels.hip; there is no CPU fallback.
+#include "../../include/drmlt_abi.h"
+#include "bvh_build.h"
+#include "device_types.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+// launchers defined in kernels.hip
+void launch_bootstrap(const DParams &P, uint32_t n, float *lum_out, hipStream_t st);
+void launch_init_chains(const DParams &P, const uint32_t *seed_index, const float *seed_lum, hipStream_t st);
+void launch_mutate(const DParams &P, uint32_t n_mut, uint32_t mut_base, hipStream_t st);
+void launch_eval_paths(const DParams &P, const float *u, uint32_t n, uint32_t dim, float *out8, hipStream_t st);
+void launch_render_pt(const DParams &P, uint64_t n_samples, uint32_t stream, float scale, hipStream_t st);
+void launch_lum_sum(const float *film, uint32_t n_pixels, double *sum, hipStream_t st);
+void launch_develop(const float *film, const float *direct, float factor, uint32_t n, float *out, hipStream_t st);
+
+namespace {
+
+constexpr uint32_t TAG_SEEDSEL = 1;
+
+// host Philox4x32-10 (seed selection draws; same function as device_math.h)
+void philox_host(uint32_t k0, uint32_t k1, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t out[4]) {
+    for (int r = 0; r < 10; ++r) {
+        uint64_t p0 = (uint64_t) 0xD2511F53u * c0, p1 = (uint64_t) 0xCD9E8D57u * c2;
+        uint32_t n0 = (uint32_t) (p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t) p1, n2 = (uint32_t) (p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t) p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t bytes = 0;
+    ~DevBuf() { if (p) (void) hipFree(p); }
+    hipError_t alloc(size_t n) {
+        if (p) { (void) hipFree(p); p = nullptr; }
+        bytes = n;
+        return n ? hipMalloc(&p, n) : hipSuccess;
+    }
+    template <typename T> T *as() const { return static_cast<T *>(p); }
+};
+
+} // namespace
+
+struct drmlt_ctx {
+    drmlt_config cfg{};
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    DParams P{};
+    std::string error;
+
+    DevBuf d_prims, d_shade, d_bsdfs, d_emitters, d_bvh, d_lut, d_film, d_x, d_cur, d_stats, d_err, d_scratch;
+    std::vector<DPrim> prims;
+    std::vector<DShade> shade;
+
+    uint32_t n_chains = 0, mutation_base = 0, chain_offset = 0;
+    bool seeded = false;
+    double b = 0.0;
+    // accounting
+    uint64_t mutations = 0, launches = 0, accepted_dummy = 0;
+    double kernel_ms = 0.0, seed_ms = 0.0;
+    double kt_ms = 0.0; uint64_t kt_launches = 0; // drmlt_kernel_time window
+    uint64_t host_counters[9] = {0};
+    int slice = 256;
+
+    ~drmlt_ctx() {
+        if (own_stream && stream) (void) hipStreamDestroy(stream);
+    }
+    int fail(int code, const char *fmt, ...) {
+        char buf[512];
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(buf, sizeof buf, fmt, ap);
+        va_end(ap);
+        error = buf;
+        return code;
+    }
+};
+
+#define HIP_TRY(ctx, expr)                                                                         \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess) return (ctx)->fail(DRMLT_E_DEVICE, "%s: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+namespace {
+
+bool invert3x4(const double *m, double *o) {
+    double a = m[0], b = m[1], c = m[2], d = m[4], e = m[5], f = m[6], g = m[8], h = m[9], i = m[10];
+    double det = a * (e * i - f * h) - b * (d * i - f * g) + c * (d * h - e * g);
+    if (det == 0 || !std::isfinite(det)) return false;
+    double id = 1.0 / det;
+    o[0] = (e * i - f * h) * id; o[1] = (c * h - b * i) * id; o[2] = (b * f - c * e) * id;
+    o[4] = (f * g - d * i) * id; o[5] = (a * i - c * g) * id; o[6] = (c * d - a * f) * id;
+    o[8] = (d * h - e * g) * id; o[9] = (b * g - a * h) * id; o[10] = (a * e - b * d) * id;
+    for (int r = 0; r < 3; ++r) o[r * 4 + 3] = -(o[r * 4] * m[3] + o[r * 4 + 1] * m[7] + o[r * 4 + 2] * m[11]);
+    return true;
+}
+
+// Flatten the scene into intersection + shading records. Returns "" or an error.
+std::string build_scene(drmlt_ctx *ctx, const drmlt_scene &s, std::vector<DBsdf> &bsdfs, std::vector<DEmitter> &emitters,
+                        std::vector<PrimBounds> &bounds) {
+    if (s.n_shapes <= 0) return "scene has no shapes";
+    if (s.n_emitters <= 0) return "scene has no emitters";
+    for (int i = 0; i < s.n_bsdfs; ++i) {
+        const drmlt_bsdf &in = s.bsdfs[i];
+        DBsdf b{};
+        b.type = in.type;
+        for (int k = 0; k < 3; ++k) b.rgb[k] = in.rgb[k];
+        if (in.type == DRMLT_BSDF_DIFFUSE) {
+        } else if (in.type == DRMLT_BSDF_DIELECTRIC) {
+            if (!(in.p[0] > 0.f) || !(in.p[1] > 0.f)) return "dielectric: IORs must be positive";
+            b.p[0] = in.p[0] / in.p[1];
+            b.p[1] = 1.f / b.p[0];
+        } else {
+            return "unsupported BSDF type " + std::to_string(in.type) + " (supported: diffuse, dielectric)";
+        }
+        bsdfs.push_back(b);
+    }
+    ctx->prims.clear(); ctx->shade.clear();
+    for (int i = 0; i < s.n_shapes; ++i) {
+        const drmlt_shape &in = s.shapes[i];
+        if (in.bsdf < 0 || in.bsdf >= s.n_bsdfs) return "shape references an invalid bsdf";
+        if (in.emitter >= s.n_emitters) return "shape references an invalid emitter";
+        DPrim g{};
+        DShade sh{};
+        PrimBounds pb;
+        sh.bsdf = in.bsdf;
+        sh.emitter = in.emitter < 0 ? -1 : in.emitter;
+        double m[12], inv[12];
+        if (in.type == DRMLT_SHAPE_TRIANGLE) {
+            double p0[3], e1[3], e2[3], n[3];
+            for (int k = 0; k < 3; ++k) { p0[k] = in.data[k]; e1[k] = (double) in.data[3 + k] - p0[k]; e2[k] = (double) in.data[6 + k] - p0[k]; }
+            n[0] = e1[1] * e2[2] - e1[2] * e2[1]; n[1] = e1[2] * e2[0] - e1[0] * e2[2]; n[2] = e1[0] * e2[1] - e1[1] * e2[0];
+            double len = std::sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
+            if (!(len > 0)) return "degenerate triangle";
+            for (int k = 0; k < 3; ++k) n[k] /= len;
+            for (int r = 0; r < 3; ++r) { m[r * 4] = e1[r]; m[r * 4 + 1] = e2[r]; m[r * 4 + 2] = n[r]; m[r * 4 + 3] = p0[r]; }
+            if (!invert3x4(m, inv)) return "degenerate triangle";
+            g.type = PRIM_TRIANGLE;
+            for (int k = 0; k < 3; ++k) { sh.origin[k] = (float) p0[k]; sh.eu[k] = (float) e1[k]; sh.ev[k] = (float) e2[k]; sh.n[k] = (float) n[k]; }
+            sh.inv_len_eu = (float) (1.0 / std::sqrt(e1[0] * e1[0] + e1[1] * e1[1] + e1[2] * e1[2]));
+            sh.inv_area = (float) (1.0 / (0.5 * len));
+            for (int k = 0; k < 3; ++k) {
+                double a = p0[k], b = p0[k] + e1[k], c = p0[k] + e2[k];
+                pb.lo[k] = (float) std::min(a, std::min(b, c)); pb.hi[k] = (float) std::max(a, std::max(b, c));
+            }
+        } else if (in.type == DRMLT_SHAPE_RECTANGLE) {
+            for (int k = 0; k < 12; ++k) m[k] = in.data[k];
+            if (!invert3x4(m, inv)) return "rectangle: singular toWorld";
+            double eu[3] = {m[0], m[4], m[8]}, ev[3] = {m[1], m[5], m[9]};
+            double lu = std::sqrt(eu[0] * eu[0] + eu[1] * eu[1] + eu[2] * eu[2]), lv = std::sqrt(ev[0] * ev[0] + ev[1] * ev[1] + ev[2] * ev[2]);
+            double sdot = (eu[0] * ev[0] + eu[1] * ev[1] + eu[2] * ev[2]) / (lu * lv);
+            if (std::fabs(sdot) > 1e-4) return "Error: 'toWorld' transformation contains shear!"; // rectangle.cpp:107-108
+            // normal: objectToWorld(Normal(0,0,1)) = third row of the inverse, normalised
+            double n[3] = {inv[8], inv[9], inv[10]};
+            double ln = std::sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
+            g.type = PRIM_RECTANGLE;
+            for (int k = 0; k < 3; ++k) {
+                sh.origin[k] = (float) m[k * 4 + 3]; sh.eu[k] = (float) eu[k]; sh.ev[k] = (float) ev[k]; sh.n[k] = (float) (n[k] / ln);
+            }
+            sh.inv_len_eu = (float) (1.0 / lu);
+            sh.inv_area = (float) (1.0 / (4.0 * lu * lv)); // |dpdu| |dpdv| with dpdu = 2 eu
+            for (int k = 0; k < 3; ++k) {
+                double c = m[k * 4 + 3], ext = std::fabs(eu[k]) + std::fabs(ev[k]);
+                pb.lo[k] = (float) (c - ext); pb.hi[k] = (float) (c + ext);
+            }
+        } else if (in.type == DRMLT_SHAPE_SPHERE) {
+            double r = in.data[3];
+            if (!(r > 0)) return "sphere: radius must be positive";
+            if (in.emitter >= 0) return "sphere emitters are not supported yet";
+            for (int k = 0; k < 12; ++k) inv[k] = 0;
+            for (int k = 0; k < 3; ++k) { inv[k * 4 + k] = 1.0 / r; inv[k * 4 + 3] = -(double) in.data[k] / r; }
+            g.type = PRIM_SPHERE;
+            for (int k = 0; k < 3; ++k) { sh.origin[k] = in.data[k]; pb.lo[k] = (float) (in.data[k] - r); pb.hi[k] = (float) (in.data[k] + r); }
+            sh.eu[0] = (float) r;
+            sh.inv_area = (float) (1.0 / (4.0 * M_PI * r * r));
+        } else {
+            return "unknown shape type " + std::to_string(in.type);
+        }
+        for (int k = 0; k < 12; ++k) g.m[k] = (float) inv[k];
+        ctx->prims.push_back(g);
+        ctx->shade.push_back(sh);
+        bounds.push_back(pb);
+    }
+    // emitters + DiscreteDistribution over sampling weights (scene.cpp m_emitterPDF, pmf.h:109-121)
+    double total = 0;
+    for (int i = 0; i < s.n_emitters; ++i) {
+        const drmlt_emitter &e = s.emitters[i];
+        if (e.type != DRMLT_EMITTER_AREA) return "unsupported emitter type";
+        if (e.shape < 0 || e.shape >= s.n_shapes || s.shapes[e.shape].emitter != i) return "emitter/shape link mismatch";
+        if (!(e.sampling_weight >= 0)) return "negative emitter sampling weight";
+        total += e.sampling_weight;
+    }
+    if (!(total > 0)) return "emitter sampling weights sum to zero";
+    float cdf = 0.f, norm = 1.0f / (float) total;
+    std::vector<float> raw(s.n_emitters + 1, 0.f);
+    for (int i = 0; i < s.n_emitters; ++i) { cdf += s.emitters[i].sampling_weight; raw[i + 1] = cdf; }
+    for (int i = 1; i <= s.n_emitters; ++i) raw[i] *= norm;
+    raw[s.n_emitters] = 1.f;
+    for (int i = 0; i < s.n_emitters; ++i) {
+        DEmitter e{};
+        for (int k = 0; k < 3; ++k) e.radiance[k] = s.emitters[i].radiance[k];
+        e.prim = s.emitters[i].shape;
+        e.cdf_lo = raw[i]; e.cdf_hi = raw[i + 1];
+        emitters.push_back(e);
+    }
+    return "";
+}
+
+// ReconstructionFilter::configure (rfilter.cpp:37-55) for box.cpp / gaussian.cpp
+void build_filter(int type, float param, float lut[32], float &radius, float &scale) {
+    const int res = 31;
+    bool gauss = type == DRMLT_FILTER_GAUSSIAN;
+    float stddev = param;
+    radius = gauss ? 4.f * stddev : param + 1e-5f;
+    float sum = 0.f;
+    for (int i = 0; i < res; ++i) {
+        float x = (radius * i) / res, v;
+        if (!gauss) v = std::fabs(x) <= radius ? 1.f : 0.f;
+        else {
+            float alpha = -1.f / (2.f * stddev * stddev);
+            v = std::max(0.f, std::exp(alpha * x * x) - std::exp(alpha * radius * radius));
+        }
+        lut[i] = v;
+        sum += v;
+    }
+    lut[res] = 0.f;
+    scale = res / radius;
+    sum *= 2.f * radius / res;
+    float normalization = 1.f / sum;
+    for (int i = 0; i < res; ++i) lut[i] *= normalization;
+}
+
+int find_max_dim_path(int maxDepth, int rrDepth) { // pssmlt_utils.h:62-68 (no media, no rough dielectric)
+    int maxDim = (maxDepth + 2) * (4 + (rrDepth < maxDepth ? 1 : 0));
+    if (maxDim % 2 == 1) ++maxDim;
+    return maxDim;
+}
+// dimensions MIPathTracer::Li can actually consume: 2 (film) + 4 per scattering event at depth
+// 1..maxDepth-1 + one roulette draw per event at depth >= rrDepth; rounded up to a full pair
+int effective_dim_path(int maxDepth, int rrDepth) {
+    int events = maxDepth - 1;
+    int rr = std::max(0, maxDepth - std::max(rrDepth, 1));
+    int d = 2 + 4 * events + rr;
+    if (d % 2 == 1) ++d;
+    return d;
+}
+
+} // namespace
+
+extern "C" {
+
+uint32_t drmlt_abi_version(void) { return DRMLT_ABI_VERSION; }
+
+const char *drmlt_last_error(drmlt_ctx *ctx) { return ctx ? ctx->error.c_str() : "null context"; }
+
+drmlt_ctx *drmlt_create(const drmlt_config *cfg, const drmlt_scene *scene, int device, char *err, size_t errlen) {
+    auto bail = [&](drmlt_ctx *c, const std::string &msg) -> drmlt_ctx * {
+        if (err && errlen) snprintf(err, errlen, "%s", msg.c_str());
+        delete c;
+        return nullptr;
+    };
+    if (!cfg || !scene) return bail(nullptr, "null config or scene");
+    if (cfg->struct_size != sizeof(drmlt_config) || scene->struct_size != sizeof(drmlt_scene))
+        return bail(nullptr, "struct_size mismatch (ABI version skew)");
+    // ---- parameter checks of the DRMLT ctor / PathSampler ctor (drmlt.cpp:193-349, pathsampler.cpp:57-71)
+    if (cfg->algo != DRMLT_ALGO_DRMLT) return bail(nullptr, "algo: only the drmlt chain loop runs on the device (pssmlt is config 1, CPU reference only)");
+    if (cfg->technique != DRMLT_TECH_PATH && cfg->technique != DRMLT_TECH_BDPT && cfg->technique != DRMLT_TECH_MMLT)
+        return bail(nullptr, "Unknown technique type");
+    if (cfg->type < DRMLT_TYPE_GREEN || cfg->type > DRMLT_TYPE_ORBITAL) return bail(nullptr, "Unknown implementation type");
+    if (cfg->technique == DRMLT_TECH_MMLT && cfg->max_depth == -1) return bail(nullptr, "Impossible to use MMLT with no max depth");
+    if (cfg->fix_emitter_path && cfg->technique != DRMLT_TECH_MMLT) return bail(nullptr, "Impossible to use fixEmitterPath without MMLT");
+    if (cfg->scale_second > 1.0f) return bail(nullptr, "scaleSecond is bigger than the first stage");
+    if (cfg->technique != DRMLT_TECH_PATH) return bail(nullptr, "technique: only `path` has a device implementation so far (bdpt/mmlt: SURVEY 8f)");
+    if (cfg->max_depth <= 0) return bail(nullptr, "technique=path needs a finite maxDepth (pssmlt_utils.h:63)");
+    if (cfg->sample_count <= 0) return bail(nullptr, "sample_count must be positive");
+    if (!(cfg->p_large >= 0.f && cfg->p_large <= 1.f)) return bail(nullptr, "pLarge must be in [0,1]");
+    const drmlt_camera &cam = scene->camera;
+    if (cam.width <= 0 || cam.height <= 0) return bail(nullptr, "film size must be positive");
+    if (cam.filter != DRMLT_FILTER_BOX && cam.filter != DRMLT_FILTER_GAUSSIAN) return bail(nullptr, "unsupported reconstruction filter");
+    if (cfg->acceptance_map && !(cam.filter == DRMLT_FILTER_BOX && cam.filter_param + 1e-5f - 0.500010f <= 1e-6f))
+        return bail(nullptr, "Box filter required for acceptance map!"); // drmlt_proc.cpp:76-79
+
+    drmlt_ctx *ctx = new drmlt_ctx();
+    ctx->cfg = *cfg;
+    ctx->device = device;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return bail(ctx, "no HIP device available (the DRMLT kernels have no CPU fallback)");
+    if (device < 0 || device >= ndev) return bail(ctx, "invalid device index");
+    if (hipSetDevice(device) != hipSuccess) return bail(ctx, "hipSetDevice failed");
+    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) return bail(ctx, "hipStreamCreate failed");
+    ctx->own_stream = true;
+    if (const char *e = getenv("DRMLT_SLICE")) ctx->slice = std::max(1, std::min(32768, atoi(e)));
+
+    std::vector<DBsdf> bsdfs;
+    std::vector<DEmitter> emitters;
+    std::vector<PrimBounds> bounds;
+    std::string e = build_scene(ctx, *scene, bsdfs, emitters, bounds);
+    if (!e.empty()) return bail(ctx, e);
+
+    // ---- acceleration structure: brute force over wave-uniform records for tiny scenes, BVH otherwise
+    DParams &P = ctx->P;
+    int bvh_threshold = 48;
+    if (const char *t = getenv("DRMLT_BVH_THRESHOLD")) bvh_threshold = atoi(t);
+    std::vector<DBvhNode> nodes;
+    P.use_bvh = (int) ctx->prims.size() > bvh_threshold ? 1 : 0;
+    if (P.use_bvh) {
+        std::vector<int> order;
+        build_bvh(bounds, nodes, order);
+        // reorder primitives into leaf order; remap emitter -> prim links
+        std::vector<DPrim> np(order.size());
+        std::vector<DShade> ns(order.size());
+        std::vector<int> where(order.size());
+        for (size_t i = 0; i < order.size(); ++i) { np[i] = ctx->prims[order[i]]; ns[i] = ctx->shade[order[i]]; where[order[i]] = (int) i; }
+        ctx->prims.swap(np); ctx->shade.swap(ns);
+        for (auto &em : emitters) em.prim = where[em.prim];
+    }
+
+    auto up = [&](DevBuf &b, const void *src, size_t bytes) -> bool {
+        if (b.alloc(std::max<size_t>(bytes, 64)) != hipSuccess) return false;
+        return hipMemcpy(b.p, src, bytes, hipMemcpyHostToDevice) == hipSuccess;
+    };
+    float lut[32], radius, scale;
+    build_filter(cam.filter, cam.filter_param, lut, radius, scale);
+    bool ok = up(ctx->d_prims, ctx->prims.data(), ctx->prims.size() * sizeof(DPrim)) &&
+              up(ctx->d_shade, ctx->shade.data(), ctx->shade.size() * sizeof(DShade)) &&
+              up(ctx->d_bsdfs, bsdfs.data(), bsdfs.size() * sizeof(DBsdf)) &&
+              up(ctx->d_emitters, emitters.data(), emitters.size() * sizeof(DEmitter)) &&
+              up(ctx->d_lut, lut, sizeof lut);
+    if (ok && P.use_bvh) ok = up(ctx->d_bvh, nodes.data(), nodes.size() * sizeof(DBvhNode));
+    if (!ok) return bail(ctx, "device allocation/upload of the scene failed");
+
+    // ---- derived quantities of DRMLT::render (drmlt.cpp:434-476)
+    const uint64_t budget = (uint64_t) cam.width * cam.height * (uint64_t) cfg->sample_count;
+    int work_units = cfg->work_units;
+    if (work_units <= 0) work_units = (int) std::max<uint64_t>(1, (budget + 200000 - 1) / 200000);
+    ctx->cfg.work_units = work_units;
+    ctx->n_chains = (uint32_t) work_units;
+
+    P.prims = ctx->d_prims.as<DPrim>(); P.shade = ctx->d_shade.as<DShade>(); P.bsdfs = ctx->d_bsdfs.as<DBsdf>();
+    P.emitters = ctx->d_emitters.as<DEmitter>(); P.bvh = ctx->d_bvh.as<DBvhNode>(); P.filter_lut = ctx->d_lut.as<float>();
+    P.n_prims = (int) ctx->prims.size(); P.n_emitters = (int) emitters.size(); P.n_bvh_nodes = (int) nodes.size();
+    for (int r = 0; r < 3; ++r) for (int c = 0; c < 4; ++c) P.cam[r * 4 + c] = cam.to_world[r * 4 + c];
+    P.tan_half_fov = (float) std::tan(0.5 * (double) cam.fov_x_deg * M_PI / 180.0);
+    P.inv_aspect = (float) cam.height / (float) cam.width;
+    P.near_clip = cam.near_clip; P.far_clip = cam.far_clip;
+    P.width = cam.width; P.height = cam.height;
+    P.filter_radius = radius; P.filter_scale = scale;
+    P.type = cfg->type; P.max_depth = cfg->max_depth; P.rr_depth = cfg->rr_depth;
+    P.exclude_direct = cfg->direct_samples >= 0 ? 1 : 0; // separateDirect, drmlt.cpp:242
+    P.acceptance_map = cfg->acceptance_map; P.timid_after_large = cfg->timid_after_large; P.use_mixture = cfg->use_mixture;
+    P.max_dim = find_max_dim_path(cfg->max_depth, cfg->rr_depth);
+    P.eff_dim = std::min(P.max_dim, effective_dim_path(cfg->max_depth, cfg->rr_depth));
+    P.p_large = cfg->p_large; P.sigma2 = cfg->scale_second * cfg->sigma;
+    P.n_chains = ctx->n_chains;
+
+    const size_t film_bytes = (size_t) cam.width * cam.height * 3 * sizeof(float);
+    ok = ctx->d_film.alloc(film_bytes) == hipSuccess && ctx->d_x.alloc((size_t) P.eff_dim * ctx->n_chains * sizeof(float)) == hipSuccess &&
+         ctx->d_cur.alloc((size_t) 6 * ctx->n_chains * sizeof(float)) == hipSuccess && ctx->d_stats.alloc(32 * sizeof(unsigned long long)) == hipSuccess &&
+         ctx->d_err.alloc(64) == hipSuccess;
+    if (!ok) return bail(ctx, "device allocation of chain state / film failed");
+    (void) hipMemset(ctx->d_film.p, 0, film_bytes);
+    (void) hipMemset(ctx->d_stats.p, 0, 32 * sizeof(unsigned long long));
+    (void) hipMemset(ctx->d_err.p, 0, 64);
+    P.film = ctx->d_film.as<float>();
+    P.x = ctx->d_x.as<float>();
+    float *cur = ctx->d_cur.as<float>();
+    P.cur_lum = cur; P.cur_px = cur + ctx->n_chains; P.cur_py = cur + 2 * (size_t) ctx->n_chains;
+    P.cur_r = cur + 3 * (size_t) ctx->n_chains; P.cur_g = cur + 4 * (size_t) ctx->n_chains; P.cur_b = cur + 5 * (size_t) ctx->n_chains;
+    P.stats = ctx->d_stats.as<unsigned long long>();
+    P.error_flag = ctx->d_err.as<int32_t>();
+    P.debug = 0;
+    if (const char *d = getenv("DRMLT_DEBUG")) P.debug = atoi(d);
+    if (hipDeviceSynchronize() != hipSuccess) return bail(ctx, "device synchronisation failed after setup");
+    return ctx;
+}
+
+void drmlt_destroy(drmlt_ctx *ctx) {
+    if (!ctx) return;
+    (void) hipSetDevice(ctx->device);
+    (void) hipStreamSynchronize(ctx->stream);
+    delete ctx;
+}
+
+int drmlt_set_stream(drmlt_ctx *ctx, void *hip_stream) {
+    if (!ctx) return DRMLT_E_INVALID;
+    (void) hipStreamSynchronize(ctx->stream);
+    if (ctx->own_stream && ctx->stream) (void) hipStreamDestroy(ctx->stream);
+    ctx->stream = static_cast<hipStream_t>(hip_stream);
+    ctx->own_stream = false;
+    return DRMLT_OK;
+}
+
+int drmlt_seed(drmlt_ctx *ctx, uint64_t seed, uint32_t chain_offset, double *b_out) {
+    if (!ctx) return DRMLT_E_INVALID;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    DParams &P = ctx->P;
+    hipEvent_t e0, e1;
+    HIP_TRY(ctx, hipEventCreate(&e0));
+    HIP_TRY(ctx, hipEventCreate(&e1));
+    HIP_TRY(ctx, hipEventRecord(e0, ctx->stream));
+    P.key0 = (uint32_t) seed; P.key1 = (uint32_t) (seed >> 32);
+    P.chain_offset = chain_offset; P.boot_stream = chain_offset;
+    ctx->chain_offset = chain_offset;
+    // luminance sample floor: max(luminanceSamples, 10 * workUnits), drmlt.cpp:454-466
+    uint32_t n = (uint32_t) std::max<int64_t>(ctx->cfg.luminance_samples, (int64_t) ctx->n_chains * 10);
+    DevBuf d_lum;
+    HIP_TRY(ctx, d_lum.alloc((size_t) n * sizeof(float)));
+    launch_bootstrap(P, n, d_lum.as<float>(), ctx->stream);
+    HIP_TRY(ctx, hipGetLastError());
+    std::vector<float> lum(n);
+    HIP_TRY(ctx, hipMemcpyAsync(lum.data(), d_lum.p, (size_t) n * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+
+    // generateSeeds, pathsampler.cpp:879-954: mean over non-NaN samples, CDF over the non-zero ones
+    double sum = 0.0, tok = 0.0;
+    std::vector<uint32_t> idx;
+    std::vector<double> cdf(1, 0.0);
+    idx.reserve(n);
+    for (uint32_t i = 0; i < n; ++i) {
+        float l = lum[i];
+        if (std::isnan(l)) continue;
+        tok += 1.0;
+        sum += (double) l;
+        if (l != 0.f) { idx.push_back(i); cdf.push_back(cdf.back() + (double) l); }
+    }
+    double mean = tok > 0 ? sum / tok : 0.0;
+    if (!(mean > 0.0) || idx.empty())
+        return ctx->fail(DRMLT_E_ZERO_LUM, "The average image luminance appears to be zero! This could indicate a problem with the scene setup.");
+    const double norm = 1.0 / cdf.back();
+    for (size_t i = 1; i < cdf.size(); ++i) cdf[i] *= norm;
+    cdf.back() = 1.0;
+    std::vector<uint32_t> seed_index(ctx->n_chains);
+    for (uint32_t j = 0; j < ctx->n_chains; ++j) {
+        uint32_t r[4];
+        philox_host(P.key0, P.key1, 0u, j, P.boot_stream, TAG_SEEDSEL, r);
+        double xi = (double) ((float) (r[0] >> 8) * (1.0f / 16777216.0f));
+        auto entry = std::lower_bound(cdf.begin(), cdf.end(), xi);
+        size_t index = (size_t) std::max<ptrdiff_t>(0, (entry - cdf.begin()) - 1);
+        index = std::min(cdf.size() - 2, index);
+        while (cdf[index + 1] - cdf[index] == 0 && index < cdf.size() - 1) ++index;
+        seed_index[j] = idx[index];
+    }
+    std::sort(seed_index.begin(), seed_index.end()); // PathSeedSortPredicate
+    std::vector<float> seed_lum(ctx->n_chains);
+    for (uint32_t j = 0; j < ctx->n_chains; ++j) seed_lum[j] = lum[seed_index[j]];
+
+    DevBuf d_si, d_sl;
+    HIP_TRY(ctx, d_si.alloc(seed_index.size() * sizeof(uint32_t)));
+    HIP_TRY(ctx, d_sl.alloc(seed_lum.size() * sizeof(float)));
+    HIP_TRY(ctx, hipMemcpyAsync(d_si.p, seed_index.data(), seed_index.size() * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(d_sl.p, seed_lum.data(), seed_lum.size() * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_err.p, 0, 64, ctx->stream));
+    launch_init_chains(P, d_si.as<uint32_t>(), d_sl.as<float>(), ctx->stream);
+    HIP_TRY(ctx, hipGetLastError());
+    int32_t flag = 0;
+    HIP_TRY(ctx, hipMemcpyAsync(&flag, ctx->d_err.p, sizeof flag, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipEventRecord(e1, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    float ms = 0.f;
+    (void) hipEventElapsedTime(&ms, e0, e1);
+    ctx->seed_ms += ms;
+    (void) hipEventDestroy(e0); (void) hipEventDestroy(e1);
+    if (flag) return ctx->fail(DRMLT_E_REPLAY, "Error when reconstructing a seed path: luminance mismatch");
+
+    ctx->b = mean;
+    if (ctx->cfg.acceptance_map) ctx->b = 1.0;                                       // drmlt.cpp:550-552
+    else if (ctx->cfg.average_luminance != -1.0f) ctx->b = ctx->cfg.average_luminance; // drmlt.cpp:555-558
+    ctx->seeded = true;
+    ctx->mutation_base = 0;
+    if (b_out) *b_out = ctx->b;
+    return DRMLT_OK;
+}
+
+int drmlt_set_luminance(drmlt_ctx *ctx, double b) {
+    if (!ctx) return DRMLT_E_INVALID;
+    if (!(b > 0)) return ctx->fail(DRMLT_E_INVALID, "luminance must be positive");
+    ctx->b = b;
+    return DRMLT_OK;
+}
+
+int drmlt_run(drmlt_ctx *ctx, uint64_t total_mutations, volatile int *stop, drmlt_progress_cb cb, void *user) {
+    if (!ctx) return DRMLT_E_INVALID;
+    if (!ctx->seeded) return ctx->fail(DRMLT_E_STATE, "drmlt_run called before drmlt_seed");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const uint64_t per_chain = total_mutations / ctx->n_chains; // nMutations, drmlt.cpp:475-476
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> evs;
+    uint64_t done = 0;
+    int rc = DRMLT_OK;
+    while (done < per_chain) {
+        if (stop && *stop) { rc = DRMLT_E_CANCELLED; break; }
+        uint32_t n = (uint32_t) std::min<uint64_t>((uint64_t) ctx->slice, per_chain - done);
+        hipEvent_t a, b;
+        HIP_TRY(ctx, hipEventCreate(&a));
+        HIP_TRY(ctx, hipEventCreate(&b));
+        HIP_TRY(ctx, hipEventRecord(a, ctx->stream));
+        launch_mutate(ctx->P, n, ctx->mutation_base, ctx->stream);
+        HIP_TRY(ctx, hipGetLastError());
+        HIP_TRY(ctx, hipEventRecord(b, ctx->stream));
+        evs.emplace_back(a, b);
+        ctx->mutation_base += n;
+        done += n;
+        ctx->launches++;
+        if (stop || cb) {
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            if (cb) cb(done * ctx->n_chains, per_chain * ctx->n_chains, user);
+        }
+    }
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    for (auto &e : evs) {
+        float ms = 0.f;
+        (void) hipEventElapsedTime(&ms, e.first, e.second);
+        ctx->kernel_ms += ms;
+        ctx->kt_ms += ms;
+        ctx->kt_launches++;
+        (void) hipEventDestroy(e.first); (void) hipEventDestroy(e.second);
+    }
+    ctx->mutations += done * ctx->n_chains;
+    if (rc == DRMLT_E_CANCELLED) return ctx->fail(rc, "cancelled");
+    return rc;
+}
+
+int drmlt_kernel_time(drmlt_ctx *ctx, double *avg_ms, uint64_t *launches, int reset) {
+    if (!ctx) return DRMLT_E_INVALID;
+    if (avg_ms) *avg_ms = ctx->kt_launches ? ctx->kt_ms / (double) ctx->kt_launches : 0.0;
+    if (launches) *launches = ctx->kt_launches;
+    if (reset) { ctx->kt_ms = 0.0; ctx->kt_launches = 0; }
+    return DRMLT_OK;
+}
+
+int drmlt_develop(drmlt_ctx *ctx, const float *direct_rgb_or_null, float *out_rgb) {
+    if (!ctx || !out_rgb) return DRMLT_E_INVALID;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const uint32_t npix = (uint32_t) ctx->P.width * ctx->P.height, n = npix * 3;
+    DevBuf d_sum, d_out, d_direct;
+    HIP_TRY(ctx, d_sum.alloc(sizeof(double)));
+    HIP_TRY(ctx, d_out.alloc((size_t) n * sizeof(float)));
+    HIP_TRY(ctx, hipMemsetAsync(d_sum.p, 0, sizeof(double), ctx->stream));
+    launch_lum_sum(ctx->P.film, npix, d_sum.as<double>(), ctx->stream);
+    double sum = 0.0;
+    HIP_TRY(ctx, hipMemcpyAsync(&sum, d_sum.p, sizeof sum, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    double avg = sum / (double) npix;
+    double factor = ctx->cfg.acceptance_map ? 1.0 : ctx->b / avg; // drmlt_proc.cpp:834-839
+    if (direct_rgb_or_null) {
+        HIP_TRY(ctx, d_direct.alloc((size_t) n * sizeof(float)));
+        HIP_TRY(ctx, hipMemcpyAsync(d_direct.p, direct_rgb_or_null, (size_t) n * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    }
+    launch_develop(ctx->P.film, d_direct.as<float>(), (float) factor, n, d_out.as<float>(), ctx->stream);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipMemcpyAsync(out_rgb, d_out.p, (size_t) n * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return DRMLT_OK;
+}
+
+int drmlt_stats_get(drmlt_ctx *ctx, drmlt_stats *o) {
+    if (!ctx || !o) return DRMLT_E_INVALID;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    unsigned long long v[9];
+    HIP_TRY(ctx, hipMemcpyAsync(v, ctx->d_stats.p, sizeof v, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    memset(o, 0, sizeof *o);
+    const uint64_t M = ctx->mutations;
+    const uint64_t n_large = v[0], acc1_l = v[1], acc1_b = v[2], sec_l = v[3], sec_b = v[4], acc2_l = v[5], acc2_b = v[6], n_rev = v[7];
+    if (!ctx->cfg.use_mixture) { // drmlt_proc.cpp:715-768
+        o->first_base = M;                 o->first_acc = acc1_l + acc1_b;
+        o->large_base = n_large;           o->large_acc = acc1_l;
+        o->bold_base = M - n_large;        o->bold_acc = acc1_b;
+        o->second_base = sec_l + sec_b;    o->second_acc = acc2_l + acc2_b;
+        o->second_large_base = sec_l;      o->second_large_acc = acc2_l;
+        o->second_bold_base = sec_b;       o->second_bold_acc = acc2_b;
+        o->overall_base = M + sec_l + sec_b;
+        o->overall_acc = acc1_l + acc1_b + acc2_l + acc2_b;
+    } else { // drmlt_proc.cpp:342-377
+        o->second_base = sec_b;            o->second_acc = acc2_b;
+        o->first_base = M - sec_b;         o->first_acc = acc1_l + acc1_b;
+        o->large_base = n_large;           o->large_acc = acc1_l;
+        o->bold_base = M - n_large - sec_b; o->bold_acc = acc1_b;
+        o->overall_base = M;               o->overall_acc = acc1_l + acc1_b + acc2_b;
+    }
+    o->mutations = M;
+    o->path_evals = M + sec_l + sec_b + n_rev;
+    o->rays = v[8];
+    o->accepted = acc1_l + acc1_b + acc2_l + acc2_b;
+    o->kernel_ms = ctx->kernel_ms;
+    o->seed_ms = ctx->seed_ms;
+    o->n_chains = ctx->n_chains;
+    o->max_dim = (uint32_t) ctx->P.max_dim;
+    o->launches = ctx->launches;
+    return DRMLT_OK;
+}
+
+int drmlt_eval_paths(drmlt_ctx *ctx, const float *u, uint32_t n, uint32_t dim, drmlt_splat *out) {
+    if (!ctx || !u || !out) return DRMLT_E_INVALID;
+    if ((int) dim < ctx->P.eff_dim) return ctx->fail(DRMLT_E_INVALID, "eval_paths: need at least %d PSS dimensions per point", ctx->P.eff_dim);
+    if (n == 0) return DRMLT_OK;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    DevBuf d_u, d_o;
+    HIP_TRY(ctx, d_u.alloc((size_t) n * dim * sizeof(float)));
+    HIP_TRY(ctx, d_o.alloc((size_t) n * 8 * sizeof(float)));
+    HIP_TRY(ctx, hipMemcpyAsync(d_u.p, u, (size_t) n * dim * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    launch_eval_paths(ctx->P, d_u.as<float>(), n, dim, d_o.as<float>(), ctx->stream);
+    HIP_TRY(ctx, hipGetLastError());
+    std::vector<float> h((size_t) n * 8);
+    HIP_TRY(ctx, hipMemcpyAsync(h.data(), d_o.p, h.size() * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    for (uint32_t i = 0; i < n; ++i) {
+        const float *r = &h[(size_t) i * 8];
+        out[i].luminance = r[0]; out[i].x = r[1]; out[i].y = r[2];
+        out[i].rgb[0] = r[3]; out[i].rgb[1] = r[4]; out[i].rgb[2] = r[5];
+        memcpy(&out[i].n_dims, &r[6], 4);
+        memcpy(&out[i].n_rays, &r[7], 4);
+    }
+    return DRMLT_OK;
+}
+
+int drmlt_film_read(drmlt_ctx *ctx, float *out_rgb) {
+    if (!ctx || !out_rgb) return DRMLT_E_INVALID;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipMemcpyAsync(out_rgb, ctx->d_film.p, ctx->d_film.bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return DRMLT_OK;
+}
+
+int drmlt_film_clear(drmlt_ctx *ctx) {
+    if (!ctx) return DRMLT_E_INVALID;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_film.p, 0, ctx->d_film.bytes, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return DRMLT_OK;
+}
+
+void *drmlt_film_device_ptr(drmlt_ctx *ctx) { return ctx ? ctx->d_film.p : nullptr; }
+
+int drmlt_render_pt(drmlt_ctx *ctx, uint32_t spp, uint64_t seed, float *out_rgb) {
+    if (!ctx || !out_rgb || spp == 0) return DRMLT_E_INVALID;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    DParams P = ctx->P;
+    DevBuf film;
+    const size_t bytes = (size_t) P.width * P.height * 3 * sizeof(float);
+    HIP_TRY(ctx, film.alloc(bytes));
+    HIP_TRY(ctx, hipMemsetAsync(film.p, 0, bytes, ctx->stream));
+    P.film = film.as<float>();
+    P.key0 = (uint32_t) seed; P.key1 = (uint32_t) (seed >> 32);
+    const uint64_t n = (uint64_t) spp * P.width * P.height;
+    launch_render_pt(P, n, 0u, 1.0f / (float) spp, ctx->stream);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipMemcpyAsync(out_rgb, film.p, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return DRMLT_OK;
+}
+
+int drmlt_chain_state(drmlt_ctx *ctx, drmlt_splat *cur, float *u, uint32_t dim) {
+    if (!ctx) return DRMLT_E_INVALID;
+    if (!ctx->seeded) return ctx->fail(DRMLT_E_STATE, "chain_state before seed");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const uint32_t n = ctx->n_chains;
+    if (cur) {
+        std::vector<float> h((size_t) 6 * n);
+        HIP_TRY(ctx, hipMemcpyAsync(h.data(), ctx->d_cur.p, h.size() * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        for (uint32_t i = 0; i < n; ++i) {
+            cur[i].luminance = h[i]; cur[i].x = h[n + i]; cur[i].y = h[2 * (size_t) n + i];
+            cur[i].rgb[0] = h[3 * (size_t) n + i]; cur[i].rgb[1] = h[4 * (size_t) n + i]; cur[i].rgb[2] = h[5 * (size_t) n + i];
+            cur[i].n_dims = 0; cur[i].n_rays = 0;
+        }
+    }
+    if (u) {
+        std::vector<float> h((size_t) ctx->P.eff_dim * n);
+        HIP_TRY(ctx, hipMemcpyAsync(h.data(), ctx->d_x.p, h.size() * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        for (uint32_t i = 0; i < n; ++i)
+            for (uint32_t k = 0; k < dim; ++k) u[(size_t) i * dim + k] = k < (uint32_t) ctx->P.eff_dim ? h[(size_t) k * n + i] : 0.f;
+    }
+    return DRMLT_OK;
+}
+
+} // extern "C"

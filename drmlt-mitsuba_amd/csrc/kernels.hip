@@ -1,0 +1,313 @@
+// HIP kernels of the DRMLT hot path for gfx950 (MI355X). One Markov chain per lane.
+//
+//   k_bootstrap     luminance samples of PathSampler::generateSeeds (pathsampler.cpp:879-920)
+//   k_init_chains   seed replay + fillReplay + luminance sanity check (drmlt_proc.cpp:467-514)
+//   k_mutate        DRMLTRenderer::process / processMixture chain loop (drmlt_proc.cpp:161-380,518-770)
+//   k_eval_paths    PathSampler::sampleSplats on caller-supplied PSS points (pathsampler.cpp:529-567)
+//   k_render_pt     independent samples of the same integrand (validation image)
+//   k_lum_sum / k_develop   DRMLTProcess::develop (drmlt_proc.cpp:824-849)
+#include "device_path.h"
+
+#define CHAIN_BLOCK 64 // one wave per workgroup: no barriers anywhere on the chain path
+
+// ImageBlock::put (imageblock.h:150-216) through the 32-entry filter table (rfilter.h:76-77).
+// The reference's work-unit blocks carry a border that is dropped when merged into m_accum;
+// clamping the footprint to the film gives the same sums.
+DEV void film_put(const DParams &P, float px, float py, f3 v) {
+    if (P.debug & 1) return;
+    if (!(isfinite(v.x) && isfinite(v.y) && isfinite(v.z)) || v.x < 0.f || v.y < 0.f || v.z < 0.f) return;
+    float posx = px - 0.5f, posy = py - 0.5f;
+    int minx = max((int) ceilf(posx - P.filter_radius), 0), miny = max((int) ceilf(posy - P.filter_radius), 0);
+    int maxx = min((int) floorf(posx + P.filter_radius), P.width - 1), maxy = min((int) floorf(posy + P.filter_radius), P.height - 1);
+    for (int y = miny; y <= maxy; ++y) {
+        float wy = P.filter_lut[min((int) fabsf(((float) y - posy) * P.filter_scale), 31)];
+        for (int x = minx; x <= maxx; ++x) {
+            float w = P.filter_lut[min((int) fabsf(((float) x - posx) * P.filter_scale), 31)] * wy;
+            float *dst = P.film + ((size_t) y * P.width + x) * 3;
+            atomicAdd(dst + 0, w * v.x);
+            atomicAdd(dst + 1, w * v.y);
+            atomicAdd(dst + 2, w * v.z);
+        }
+    }
+}
+
+DEV void normalize_splat(DSplat &s) { // SplatList::normalize, pathsampler.cpp:1021-1027
+    if (s.lum > 0.f) {
+        float inv = 1.f / s.lum;
+        s.r *= inv; s.g *= inv; s.b *= inv;
+    }
+}
+
+DEV unsigned long long wave_sum(uint32_t v) {
+    unsigned long long s = v;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+    return s;
+}
+
+__global__ void __launch_bounds__(256) k_bootstrap(DParams P, uint32_t n, float *lum_out) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Sampler smp;
+    smp.key0 = P.key0; smp.key1 = P.key1; smp.chain = P.boot_stream; smp.major = i;
+    smp.mode = SM_BOOT; smp.type = P.type; smp.large = false; smp.sigma2 = P.sigma2; smp.lane = 0u; smp.arr = nullptr;
+    uint32_t nr, nd;
+    DSplat s = eval_path(P, smp, nr, nd);
+    lum_out[i] = s.lum;
+}
+
+__global__ void __launch_bounds__(256) k_init_chains(DParams P, const uint32_t *seed_index, const float *seed_lum) {
+    uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= P.n_chains) return;
+    Sampler smp;
+    smp.key0 = P.key0; smp.key1 = P.key1; smp.chain = P.boot_stream; smp.major = seed_index[c];
+    smp.mode = SM_BOOT; smp.type = P.type; smp.large = false; smp.sigma2 = P.sigma2; smp.lane = 0u; smp.arr = nullptr;
+    uint32_t nr, nd;
+    DSplat s = eval_path(P, smp, nr, nd);
+    // sanity check of drmlt_proc.cpp:509-512: same function, same inputs -> bit-equal on the device
+    if (!(s.lum == seed_lum[c])) atomicExch(P.error_flag, 1);
+    normalize_splat(s);
+    P.cur_lum[c] = s.lum; P.cur_px[c] = s.px; P.cur_py[c] = s.py;
+    P.cur_r[c] = s.r; P.cur_g[c] = s.g; P.cur_b[c] = s.b;
+    // replayed components + fillReplay top-up: dimension k of bootstrap sample i is U(BOOT, i, k)
+    smp.reset_caches();
+    for (uint32_t k = 0; k < (uint32_t) P.eff_dim; ++k) P.x[(size_t) k * P.n_chains + c] = smp.u_boot(k, TAG_BOOT);
+}
+
+DEV bool lum_invalid(float x) { return isnan(x) || isinf(x) || x <= 0.f; }        // drmlt_proc.cpp:428
+DEV bool lum_invalid_mix(float x) { return isnan(x) || isinf(x) || x < 0.f; }     // drmlt_proc.cpp:181
+
+// Per-lane event counters of one launch, packed 2 x 16 bit (launch length is capped at 32768).
+struct Counters {
+    uint32_t large_acc1l; // lo: large steps                hi: accepted first stage after large
+    uint32_t acc1b_secl;  // lo: accepted first stage, bold  hi: second stages after large
+    uint32_t secb_acc2l;  // lo: second stages after bold    hi: accepted second stage after large
+    uint32_t acc2b_rev;   // lo: accepted second, bold       hi: Green reverse evaluations
+    uint32_t rays;
+};
+
+__global__ void __launch_bounds__(CHAIN_BLOCK) k_mutate(DParams P, uint32_t n_mut, uint32_t mut_base) {
+    const uint32_t lane = threadIdx.x;
+    const uint32_t c = blockIdx.x * CHAIN_BLOCK + lane;
+    const bool live = c < P.n_chains;
+    const uint32_t cc = live ? c : P.n_chains - 1;
+    const int D = P.eff_dim;
+    for (int k = 0; k < D; ++k) lds_x[k * 64 + lane] = P.x[(size_t) k * P.n_chains + cc];
+
+    DSplat cur;
+    cur.lum = P.cur_lum[cc]; cur.px = P.cur_px[cc]; cur.py = P.cur_py[cc];
+    cur.r = P.cur_r[cc]; cur.g = P.cur_g[cc]; cur.b = P.cur_b[cc];
+
+    Sampler smp;
+    smp.key0 = P.key0; smp.key1 = P.key1; smp.chain = P.chain_offset + cc;
+    smp.type = P.type; smp.sigma2 = P.sigma2; smp.lane = lane; smp.arr = nullptr;
+    Counters ct = {0u, 0u, 0u, 0u, 0u};
+    const bool amap = P.acceptance_map != 0;
+
+    if (live && !(P.debug & 8)) for (uint32_t it = 0; it < n_mut; ++it) {
+        const uint32_t m = mut_base + it;
+        const u4 coins = philox4x32_10(P.key0, P.key1, 0u, m, smp.chain, TAG_COIN);
+        const bool large = u32_to_unit(coins.x) < P.p_large;
+        smp.major = m;
+        smp.large = large;
+        uint32_t nd1 = 0, nd2 = 0;
+        DSplat y, z;
+        y.lum = 0.f; y.px = y.py = y.r = y.g = y.b = 0.f;
+        z = y;
+        float a1 = 0.f, a2 = 0.f;
+        bool acc1 = false, acc2 = false, doSecond = false;
+        const bool mix = P.use_mixture != 0;
+
+        // Stage loop with ONE path-evaluation site: 0 = first stage, 1 = second stage,
+        // 2 = Green's reverse move. Lanes leave the loop as soon as their mutation is decided.
+#pragma nounroll
+        for (int stage = 0; stage < 3; ++stage) {
+            smp.mode = stage == 0 ? SM_STAGE1 : (stage == 1 ? SM_STAGE2 : SM_REVERSE);
+            uint32_t nr, nd;
+            DSplat res = eval_path(P, smp, nr, nd);
+            ct.rays += nr;
+            normalize_splat(res);
+            if (stage == 0) {
+                y = res; nd1 = nd;
+                if (!(mix ? lum_invalid_mix(y.lum) : lum_invalid(y.lum))) { // Eq. 5, drmlt_proc.cpp:544-550 / :285-293
+                    a1 = fminf(1.f, y.lum / cur.lum);
+                    acc1 = a1 >= 1.f || u32_to_unit(coins.y) < a1;
+                }
+                if (!mix) doSecond = !acc1 && (P.timid_after_large || !large);   // :553-558
+                else doSecond = !large && u32_to_unit(coins.w) < 0.5f;           // :296-299
+                if (!doSecond) break;
+            } else if (stage == 1) {
+                z = res; nd2 = nd;
+                if (mix) { // processMixture: the second-stage proposal replaces the first (:313-324)
+                    acc1 = false;
+                    a1 = 0.f;
+                    if (!lum_invalid_mix(z.lum)) {
+                        a2 = fminf(1.f, z.lum / cur.lum);
+                        acc2 = a2 >= 1.f || u32_to_unit(coins.z) < a2;
+                    }
+                    break;
+                }
+                if (lum_invalid(z.lum)) break;
+                if (P.type == 0) continue; // Green & Mira (2001): needs the reverse path y* = z - (y - x)
+                if (P.type == 1) { // Tierney & Mira (1999), drmlt_proc.cpp:625-650
+                    float aRev = fminf(1.f, y.lum / z.lum);
+                    if (!(aRev >= 1.f)) {
+                        float ratio = 1.f;
+                        if (!large) { // Q1(y|z) / Q1(y|x) over the used dimensions (drmlt_sampler.cpp:400-414)
+                            uint32_t dimStage = max(nd1, nd2) - 1u;
+                            float num = 0.f, den = 0.f;
+                            for (uint32_t i = 0; i < dimStage; ++i) {
+                                float yi = smp.y_raw(i);
+                                num += kelemen_logpdf(smp.z_raw(i) - yi);
+                                den += kelemen_logpdf(smp.x(i) - yi);
+                            }
+                            ratio = __expf(num - den);
+                        }
+                        if (!lum_invalid(ratio)) {
+                            a2 = fminf(1.f, (z.lum / cur.lum) * ratio * (1.f - aRev) / (1.f - a1));
+                            acc2 = a2 >= 1.f || u32_to_unit(coins.z) < a2;
+                        }
+                    }
+                } else { // pairwise orbital, DRMLT Eq. 11 (drmlt_proc.cpp:655-669)
+                    if (z.lum < y.lum) { a2 = 0.f; }
+                    else if (z.lum >= cur.lum) { a2 = 1.f; acc2 = true; }
+                    else {
+                        a2 = (z.lum - y.lum) / (cur.lum - y.lum);
+                        acc2 = a2 >= 1.f || u32_to_unit(coins.z) < a2;
+                    }
+                }
+                break;
+            } else { // Green's second-stage acceptance, Eq. 13-14 (drmlt_proc.cpp:599-615)
+                ct.acc2b_rev += 1u << 16;
+                float aRev = lum_invalid(res.lum) ? 0.f : fminf(1.f, res.lum / z.lum);
+                if (aRev != 1.f) {
+                    a2 = fminf(1.f, (z.lum / cur.lum) * (1.f - aRev) / (1.f - a1));
+                    acc2 = a2 >= 1.f || u32_to_unit(coins.z) < a2;
+                }
+            }
+        }
+
+        if (!mix) {
+            // expectation weights, drmlt_proc.cpp:677-688
+            float w1 = a1, w2 = (1.f - a1) * a2, w0 = 1.f - w1 - w2;
+            if (!amap) {
+                if (w0 > 0.f) film_put(P, cur.px, cur.py, mk3(cur.r * w0, cur.g * w0, cur.b * w0));
+                if (w1 > 0.f) film_put(P, y.px, y.py, mk3(y.r * w1, y.g * w1, y.b * w1));
+                if (doSecond && w2 > 0.f) film_put(P, z.px, z.py, mk3(z.r * w2, z.g * w2, z.b * w2));
+            }
+        } else {
+            // processMixture splats, drmlt_proc.cpp:327-333: a = acceptance of whichever proposal was tested
+            const float a = doSecond ? a2 : a1;
+            const DSplat &pr = doSecond ? z : y;
+            if (1.f - a > 0.f) film_put(P, cur.px, cur.py, mk3(cur.r * (1.f - a), cur.g * (1.f - a), cur.b * (1.f - a)));
+            if (a > 0.f) film_put(P, pr.px, pr.py, mk3(pr.r * a, pr.g * a, pr.b * a));
+        }
+
+        // bookkeeping (event counts; the 7 ratios are assembled on the host)
+        if (large) {
+            ct.large_acc1l += 1u + (acc1 ? 1u << 16 : 0u);
+            if (doSecond) ct.acc1b_secl += 1u << 16;
+            if (acc2) ct.secb_acc2l += 1u << 16;
+        } else {
+            if (acc1) ct.acc1b_secl += 1u;
+            if (doSecond) ct.secb_acc2l += 1u;
+            if (acc2) ct.acc2b_rev += 1u;
+        }
+
+        if (acc1 || acc2) {
+            // DRMLTSampler::accept: uCurrent = wrap(chosen proposal), every kept dimension
+            if (acc1) { for (int k = 0; k < D; ++k) lds_x[k * 64 + lane] = wrap01(smp.y_raw((uint32_t) k)); cur = y; }
+            else { for (int k = 0; k < D; ++k) lds_x[k * 64 + lane] = wrap01(smp.z_raw((uint32_t) k)); cur = z; }
+            if (amap) { // drmlt_proc.cpp:697-709
+                if (acc1) { if (!large && !P.use_mixture) film_put(P, cur.px, cur.py, mk3(1.f, 0.f, 0.f)); }
+                else if (!P.use_mixture) film_put(P, cur.px, cur.py, mk3(0.f, 1.f, 0.f));
+            }
+        }
+    }
+
+    if (live && !(P.debug & 4)) {
+        for (int k = 0; k < D; ++k) P.x[(size_t) k * P.n_chains + c] = lds_x[k * 64 + lane];
+        P.cur_lum[c] = cur.lum; P.cur_px[c] = cur.px; P.cur_py[c] = cur.py;
+        P.cur_r[c] = cur.r; P.cur_g[c] = cur.g; P.cur_b[c] = cur.b;
+    }
+    // wave-reduce the event counters, one atomic per counter per wave
+    unsigned long long v[9];
+    v[0] = wave_sum(ct.large_acc1l & 0xffffu); v[1] = wave_sum(ct.large_acc1l >> 16);
+    v[2] = wave_sum(ct.acc1b_secl & 0xffffu);  v[3] = wave_sum(ct.acc1b_secl >> 16);
+    v[4] = wave_sum(ct.secb_acc2l & 0xffffu);  v[5] = wave_sum(ct.secb_acc2l >> 16);
+    v[6] = wave_sum(ct.acc2b_rev & 0xffffu);   v[7] = wave_sum(ct.acc2b_rev >> 16);
+    v[8] = wave_sum(ct.rays);
+    if (lane == 0 && !(P.debug & 2))
+        for (int i = 0; i < 9; ++i) atomicAdd(P.stats + i, v[i]);
+}
+
+__global__ void __launch_bounds__(256) k_eval_paths(DParams P, const float *u, uint32_t n, uint32_t dim, float *out8) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Sampler smp;
+    smp.key0 = smp.key1 = smp.chain = smp.major = 0u;
+    smp.mode = SM_ARRAY; smp.type = P.type; smp.large = false; smp.sigma2 = P.sigma2; smp.lane = 0u;
+    smp.arr = u + (size_t) i * dim;
+    uint32_t nr, nd;
+    DSplat s = eval_path(P, smp, nr, nd);
+    float *o = out8 + (size_t) i * 8;
+    o[0] = s.lum; o[1] = s.px; o[2] = s.py; o[3] = s.r; o[4] = s.g; o[5] = s.b;
+    o[6] = __int_as_float((int) nd); o[7] = __int_as_float((int) nr);
+}
+
+__global__ void __launch_bounds__(256) k_render_pt(DParams P, uint64_t n_samples, uint32_t stream, float scale) {
+    uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t stride = (uint64_t) gridDim.x * blockDim.x;
+    for (; i < n_samples; i += stride) {
+        Sampler smp;
+        smp.key0 = P.key0; smp.key1 = P.key1; smp.chain = stream + (uint32_t) (i >> 32); smp.major = (uint32_t) i;
+        smp.mode = SM_PT; smp.type = P.type; smp.large = false; smp.sigma2 = P.sigma2; smp.lane = 0u; smp.arr = nullptr;
+        uint32_t nr, nd;
+        DSplat s = eval_path(P, smp, nr, nd);
+        if (s.lum > 0.f) film_put(P, s.px, s.py, mk3(s.r * scale, s.g * scale, s.b * scale));
+    }
+}
+
+// sum of pixel luminances in double (one atomic per block)
+__global__ void __launch_bounds__(256) k_lum_sum(const float *film, uint32_t n_pixels, double *sum) {
+    __shared__ double part[256];
+    double acc = 0.0;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_pixels; i += gridDim.x * blockDim.x)
+        acc += (double) film[3 * i] * 0.212671 + (double) film[3 * i + 1] * 0.715160 + (double) film[3 * i + 2] * 0.072169;
+    part[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int) threadIdx.x < s) part[threadIdx.x] += part[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) atomicAdd(sum, part[0]);
+}
+
+__global__ void __launch_bounds__(256) k_develop(const float *film, const float *direct, float factor, uint32_t n, float *out) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = film[i] * factor + (direct ? direct[i] : 0.f);
+}
+
+// ---- host-callable launchers (C++ linkage, used by drmlt_capi.cpp) --------------------------
+void launch_bootstrap(const DParams &P, uint32_t n, float *lum_out, hipStream_t st) {
+    hipLaunchKernelGGL(k_bootstrap, dim3((n + 255) / 256), dim3(256), 0, st, P, n, lum_out);
+}
+void launch_init_chains(const DParams &P, const uint32_t *seed_index, const float *seed_lum, hipStream_t st) {
+    hipLaunchKernelGGL(k_init_chains, dim3((P.n_chains + 255) / 256), dim3(256), 0, st, P, seed_index, seed_lum);
+}
+void launch_mutate(const DParams &P, uint32_t n_mut, uint32_t mut_base, hipStream_t st) {
+    size_t lds = (size_t) P.eff_dim * 64 * sizeof(float);
+    hipLaunchKernelGGL(k_mutate, dim3((P.n_chains + CHAIN_BLOCK - 1) / CHAIN_BLOCK), dim3(CHAIN_BLOCK), lds, st, P, n_mut, mut_base);
+}
+void launch_eval_paths(const DParams &P, const float *u, uint32_t n, uint32_t dim, float *out8, hipStream_t st) {
+    hipLaunchKernelGGL(k_eval_paths, dim3((n + 255) / 256), dim3(256), 0, st, P, u, n, dim, out8);
+}
+void launch_render_pt(const DParams &P, uint64_t n_samples, uint32_t stream, float scale, hipStream_t st) {
+    hipLaunchKernelGGL(k_render_pt, dim3(4096), dim3(256), 0, st, P, n_samples, stream, scale);
+}
+void launch_lum_sum(const float *film, uint32_t n_pixels, double *sum, hipStream_t st) {
+    hipLaunchKernelGGL(k_lum_sum, dim3(256), dim3(256), 0, st, film, n_pixels, sum);
+}
+void launch_develop(const float *film, const float *direct, float factor, uint32_t n, float *out, hipStream_t st) {
+    hipLaunchKernelGGL(k_develop, dim3((n + 255) / 256), dim3(256), 0, st, film, direct, factor, n, out);
+}

@@ -304,7 +304,10 @@ private:
         const TransitionKernel<F> &kern = currentKernel();
         for (size_t i = 0; i < m_maxDim; ++i) {
             if (m_largeStep) {
-                if (!first) throw std::runtime_error("large step in second stage");
+                // The reference has SAssert(isFirst) here (drmlt_sampler.cpp:320,346): with
+                // timidAfterLarge a rejected large step reaches this branch in its second stage and
+                // a build with assertions (MTS_DEBUG, the CMake default) aborts. Restated is what
+                // the code does with assertions compiled out: another uniform proposal.
                 uProposed.push_back((F) m_random->nextFloat());
             } else if (kern.isIdentity()) {
                 uProposed.push_back(uCurrent.at(i));

@@ -182,6 +182,15 @@ public:
             emitterCdf.push_back(emitterCdf.back() + (F) e.sampling_weight);
         }
         if (emitters.empty()) return "scene has no emitters";
+        // the kd-tree's box is slightly enlarged after construction (gkdtree.h:1213-1220,
+        // MTS_KD_AABB_EPSILON = 1e-3): needed when geometry lies ON the tight box, as walls do
+        {
+            const F eps = F(1e-3);
+            V3<F> ext = aabbMax - aabbMin;
+            aabbMin = aabbMin - (ext * eps + V3<F>(eps));
+            ext = aabbMax - aabbMin;
+            aabbMax = aabbMax + (ext * eps + V3<F>(eps));
+        }
         F sum = emitterCdf.back();
         for (size_t i = 1; i < emitterCdf.size(); ++i) emitterCdf[i] *= F(1) / sum; // pmf.h:109-121
         emitterCdf.back() = 1;

@@ -1,0 +1,244 @@
+"""GPU parity tests: every call goes through the C-ABI (libdrmlt_amd.so) and is compared with the CPU oracle
+on identical inputs. Floating-point path => tolerances are stated per test:
+  * f(u) on identical PSS points: same path topology for >= 99.5 % of points, luminance within 1e-3 relative
+    at the 99th percentile (fp32 device vs fp64 oracle; discontinuities of f account for the rest);
+  * chains: the addressed RNG makes device and oracle chains comparable mutation by mutation;
+  * images: relative MSE with BASELINE.md's epsilon."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+LUMW = np.array([0.212671, 0.715160, 0.072169])
+
+
+def lum(img):
+    return img @ LUMW
+
+
+def rel_mse(img, ref):
+    li, lr = lum(img), lum(ref)
+    return float(np.mean((li - lr) ** 2 / (lr ** 2 + 1e-2 * lr.mean() ** 2)))
+
+
+def make(pkg, ob, sd, precision=64, **kw):
+    abi = pkg.abi
+    base = dict(max_depth=8, rr_depth=5, direct_samples=-1, luminance_samples=20000)
+    base.update(kw)
+    cfg = abi.make_config(**base)
+    return cfg, pkg.Context(cfg, sd), ob.Oracle(abi, cfg, sd, precision)
+
+
+SCENES = ["cornell_c1", "cornell_c2", "glass_sphere", "triangle_soup"]
+
+
+@pytest.mark.parametrize("name", SCENES)
+def test_eval_paths_matches_oracle(pkg, ob, name, native_lib):
+    sd = pkg.scenes.SCENES[name](res=64) if name != "triangle_soup" else pkg.scenes.triangle_soup(600, 64)
+    cfg, ctx, orc = make(pkg, ob, sd, type="orbital", work_units=64)
+    u = np.random.default_rng(1).random((8192, 50), dtype=np.float32)
+    g, o = ctx.eval_paths(u), orc.eval_paths(u)
+    same = g["n_dims"] == o["n_dims"]
+    assert same.mean() >= 0.995, same.mean()
+    # the device skips the shadow ray when the BSDF value is already zero (back-face hits), the reference
+    # tests visibility first (scene.cpp:890-895): never more rays, identical counts on one-sided scenes
+    assert np.all(g["n_rays"][same] <= o["n_rays"][same])
+    if name != "triangle_soup":
+        assert (g["n_rays"] == o["n_rays"])[same].mean() > 0.995
+    assert np.allclose(g["x"], o["x"], atol=1e-3) and np.allclose(g["y"], o["y"], atol=1e-3)
+    rel = np.abs(g["luminance"] - o["luminance"])[same] / np.maximum(o["luminance"][same], 1e-3)
+    assert np.quantile(rel, 0.99) < 1e-3, np.quantile(rel, 0.99)
+    assert g["luminance"].mean() == pytest.approx(o["luminance"].mean(), rel=5e-3)
+    assert np.allclose(g["rgb"][same], o["rgb"][same], rtol=5e-2, atol=1e-3)
+
+
+def test_bvh_and_brute_force_agree_on_device(pkg, ob, native_lib):
+    sd = pkg.scenes.cornell_c2(64)
+    u = np.random.default_rng(3).random((8192, 50), dtype=np.float32)
+    cfg = pkg.abi.make_config(type="orbital", max_depth=8, direct_samples=-1, work_units=64)
+    os.environ["DRMLT_BVH_THRESHOLD"] = "1000000"
+    a = pkg.Context(cfg, sd).eval_paths(u)
+    os.environ["DRMLT_BVH_THRESHOLD"] = "0"
+    try:
+        b = pkg.Context(cfg, sd).eval_paths(u)
+    finally:
+        del os.environ["DRMLT_BVH_THRESHOLD"]
+    same = a["n_dims"] == b["n_dims"]
+    assert same.mean() > 0.999
+    assert np.allclose(a["luminance"][same], b["luminance"][same], rtol=1e-4, atol=1e-6)
+
+
+def test_bootstrap_and_seed_replay(pkg, ob, native_lib):
+    sd = pkg.scenes.cornell_c2(64)
+    cfg, ctx, orc = make(pkg, ob, sd, type="orbital", work_units=4096, sample_count=1)
+    bg, bo = ctx.seed(0x5EED), orc.seed(0x5EED)       # seed() raises DRMLT_E_REPLAY on a luminance mismatch
+    assert bg == pytest.approx(bo, rel=2e-4)
+    (cg, ug), (co, uo) = ctx.chain_state(34), orc.chain_state(34)
+    # chain state = the raw uniforms of its bootstrap sample. fp32-vs-fp64 differences in ~0.1 % of the
+    # bootstrap luminances shift the resampling CDF, so compare the two seed SETS, not positions
+    keys_g = {r.tobytes() for r in ug}
+    keys_o = {r.tobytes() for r in uo}
+    assert len(keys_g & keys_o) / len(keys_o) > 0.5   # most picks coincide even though the CDF is perturbed
+    # replay: the stored current state is f(u) of the stored vector (drmlt_proc.cpp:481,509-512)
+    chk = orc.eval_paths(np.pad(ug, ((0, 0), (0, 16))))
+    ok = np.abs(chk["luminance"] - cg["luminance"]) <= 1e-3 * cg["luminance"]
+    assert ok.mean() > 0.995
+    assert np.allclose(chk["x"][ok], cg["x"][ok], atol=1e-3)
+    # luminance-proportional resampling (pathsampler.cpp:946-954): E[lum of a seed] = sum(l^2) / sum(l)
+    lum_all = orc.bootstrap_lum(0x5EED, 0, 40960)
+    assert cg["luminance"].mean() == pytest.approx((lum_all ** 2).sum() / lum_all.sum(), rel=0.06)
+    st = ctx.stats()
+    assert st.n_chains == 4096 and st.max_dim == 50
+
+
+VARIANTS = [
+    dict(type="orbital"), dict(type="green"), dict(type="mira"),
+    dict(type="orbital", use_mixture=1), dict(type="green", use_mixture=1),
+    dict(type="orbital", timid_after_large=1), dict(type="mira", timid_after_large=1),
+    dict(type="orbital", p_large=0.05), dict(type="orbital", direct_samples=16),
+]
+
+
+@pytest.mark.parametrize("kw", VARIANTS, ids=lambda k: "-".join("%s=%s" % i for i in k.items()))
+def test_chains_track_the_oracle(pkg, ob, kw, native_lib):
+    sd = pkg.scenes.cornell_c2(32)
+    n_chains, n_mut = 2048, 48
+    cfg, ctx, orc = make(pkg, ob, sd, work_units=n_chains, sample_count=1, **kw)
+    ctx.seed(0xABCD), orc.seed(0xABCD)
+    (c0g, u0g), (c0o, u0o) = ctx.chain_state(34), orc.chain_state(34)
+    same0 = np.all(u0g == u0o, axis=1)
+    ctx.run(n_chains * n_mut)
+    orc.run(n_chains * n_mut, 8)
+    (cg, ug), (co, uo) = ctx.chain_state(34), orc.chain_state(34)
+    tracked = np.all(np.abs(ug - uo) < 2e-3, axis=1) & same0
+    # a chain leaves the oracle's trajectory only when an acceptance test is decided differently in fp32
+    assert tracked.sum() / same0.sum() > 0.97, tracked.sum() / same0.sum()
+    sg, so = ctx.stats(), orc.stats()
+    assert sg.mutations == so.mutations == n_chains * n_mut
+    for k in ("first", "large", "bold", "second", "second_large", "second_bold", "overall"):
+        bg, bo = getattr(sg, k + "_base"), getattr(so, k + "_base")
+        assert abs(bg - bo) <= 0.01 * max(bo, 1) + 20, (k, bg, bo)
+        if bo > 200:
+            pg, po = getattr(sg, k + "_acc") / bg, getattr(so, k + "_acc") / bo
+            assert abs(pg - po) < 4 * np.sqrt(po * (1 - po) / bo) + 0.01, (k, pg, po)
+    assert abs(sg.path_evals - so.path_evals) <= 0.01 * so.path_evals
+    assert abs(sg.rays - so.rays) <= 0.02 * so.rays
+    fg, fo = ctx.film(), orc.film()
+    assert lum(fg).sum() == pytest.approx(lum(fo).sum(), rel=2e-3)
+    # same chains splat the same pixels: block-averaged films agree
+    bgk, bok = (lum(f).reshape(8, 4, 8, 4).sum(axis=(1, 3)) for f in (fg, fo))
+    assert np.abs(bgk - bok).sum() / bok.sum() < 0.06
+    ig, io = ctx.develop(), orc.develop()
+    assert lum(ig).mean() == pytest.approx(lum(io).mean(), rel=2e-3)
+
+
+def test_acceptance_map(pkg, ob, native_lib):
+    sd = pkg.scenes.cornell_c2(32)
+    n_chains, n_mut = 2048, 32
+    cfg, ctx, orc = make(pkg, ob, sd, type="orbital", work_units=n_chains, sample_count=1, acceptance_map=1)
+    assert ctx.seed(1) == 1.0 and orc.seed(1) == 1.0       # luminance forced to 1 (drmlt.cpp:550-552)
+    ctx.run(n_chains * n_mut), orc.run(n_chains * n_mut, 8)
+    fg, fo = ctx.develop(), orc.develop()                  # factor 1: raw bins
+    sg = ctx.stats()
+    w = 0.99998 ** 2                                       # box-filter table weight
+    assert fg[..., 2].max() == 0
+    assert fg[..., 0].sum() == pytest.approx(sg.bold_acc * w, rel=1e-3)      # red: accepted bold first stages
+    assert fg[..., 1].sum() == pytest.approx(sg.second_acc * w, rel=1e-3)    # green: accepted second stages
+    assert fg[..., 0].sum() == pytest.approx(fo[..., 0].sum(), rel=0.02)
+    assert fg[..., 1].sum() == pytest.approx(fo[..., 1].sum(), rel=0.05)
+
+
+def test_gaussian_filter_film(pkg, ob, native_lib):
+    sd = pkg.scenes.cornell_c2(32, filt=pkg.abi.FILTER_GAUSSIAN)
+    n_chains, n_mut = 1024, 32
+    cfg, ctx, orc = make(pkg, ob, sd, type="orbital", work_units=n_chains, sample_count=1)
+    ctx.seed(3), orc.seed(3)
+    ctx.run(n_chains * n_mut), orc.run(n_chains * n_mut, 8)
+    fg, fo = ctx.film(), orc.film()
+    assert lum(fg).sum() == pytest.approx(lum(fo).sum(), rel=5e-3)
+    assert np.abs(lum(fg) - lum(fo)).sum() / lum(fo).sum() < 0.08
+
+
+def test_mlt_image_is_unbiased_against_device_path_tracing(pkg, ob, native_lib):
+    sd = pkg.scenes.cornell_c2(32)
+    spp = 2048
+    cfg, ctx, orc = make(pkg, ob, sd, type="orbital", work_units=4096, sample_count=spp, luminance_samples=200000)
+    ref = ctx.render_pt(8192, seed=5)
+    ref_cpu = orc.render_pt(256, seed=5, nthreads=8)
+    assert lum(ref).mean() == pytest.approx(lum(ref_cpu).mean(), rel=0.02)   # same integrand on both sides
+    b = ctx.seed(9)
+    assert b == pytest.approx(lum(ref).mean(), rel=0.02)
+    ctx.run(32 * 32 * spp)
+    img = ctx.develop()
+    assert lum(img).mean() == pytest.approx(b, rel=1e-3)
+    # equal-budget protocol: the device image is as close to the reference as the oracle's
+    orc.seed(9)
+    orc.run(32 * 32 * spp, 16)
+    e_gpu, e_cpu = rel_mse(img, ref), rel_mse(orc.develop(), ref)
+    assert e_gpu < 1.25 * e_cpu + 2e-4, (e_gpu, e_cpu)
+    assert e_gpu < 1e-2
+
+
+def test_config2_full_size_invariants(pkg, ob, native_lib):
+    """BASELINE config 2 at full size: size-independent properties only."""
+    sd = pkg.scenes.cornell_c2(512)
+    n_chains = 65536
+    cfg = pkg.abi.make_config(type="orbital", max_depth=8, rr_depth=5, direct_samples=-1, work_units=n_chains,
+                              luminance_samples=655360, sample_count=256)
+    ctx = pkg.Context(cfg, sd)
+    b = ctx.seed(0x5EED)
+    total = 512 * 512 * 64
+    ctx.run(total)
+    st = ctx.stats()
+    M = st.mutations
+    assert M == total
+    assert st.first_base == M and st.large_base + st.bold_base == M
+    assert st.second_base == st.bold_base - st.bold_acc and st.second_large_base == 0
+    assert st.overall_base == M + st.second_base and st.overall_acc == st.first_acc + st.second_acc == st.accepted
+    assert st.path_evals == M + st.second_base
+    assert abs(st.large_base / M - 0.3) < 2e-3
+    film = ctx.film()
+    assert np.all(np.isfinite(film)) and film.min() >= 0
+    # every mutation deposits unit luminance (three expectation weights sum to one)
+    assert lum(film).sum() == pytest.approx(M * 0.99998 ** 2, rel=2e-3)
+    cur, u = ctx.chain_state(34)
+    assert np.all((u >= 0) & (u <= 1)) and np.all(cur["luminance"] > 0)
+    img = ctx.develop()
+    assert lum(img).mean() == pytest.approx(b, rel=1e-3)
+    direct = np.full_like(img, 0.25)
+    assert np.allclose(ctx.develop(direct), img + 0.25, atol=1e-5)          # develop adds the direct image
+
+
+def test_call_order_and_cancellation(pkg, ob, native_lib):
+    abi = pkg.abi
+    sd = pkg.scenes.cornell_c1(16)
+    cfg = abi.make_config(type="orbital", max_depth=8, direct_samples=-1, work_units=256, sample_count=64)
+    ctx = pkg.Context(cfg, sd)
+    with pytest.raises(pkg.DrmltError) as e:
+        ctx.run(1000)
+    assert e.value.code == abi.E_STATE
+    ctx.seed(1)
+    seen = []
+    ctx.run(256 * 600, progress=lambda d, t: seen.append((d, t)))
+    assert seen and seen[-1][0] == seen[-1][1] == 256 * 600 and all(a[0] < b[0] for a, b in zip(seen, seen[1:]))
+    stop = C.c_int(1)
+    with pytest.raises(pkg.DrmltError) as e:
+        ctx.run(256 * 600, stop=stop)
+    assert e.value.code == abi.E_CANCELLED
+    assert ctx.stats().mutations == 256 * 600
+
+
+def test_black_scene_reports_zero_luminance(pkg, ob, native_lib):
+    sc = pkg.scenes
+    sd = sc.SceneData("dark")
+    grey, black = sd.diffuse(0.5), sd.diffuse(0.0)
+    sd.rectangle(sc.translate(0, -1, 0) @ sc.rotate("x", -90), grey)
+    sd.rectangle(sc.translate(0, 1.5, 0) @ sc.rotate("x", -90) @ sc.scale(0.25), black, radiance=10.0)  # faces away
+    sd.set_camera(sc.lookat((0, 0, 3.9), (0, 0, 0), (0, 1, 0)), 39.0, 16, 16)
+    ctx = pkg.Context(pkg.abi.make_config(type="orbital", max_depth=4, direct_samples=-1, work_units=64), sd)
+    with pytest.raises(pkg.DrmltError) as e:
+        ctx.seed(1)
+    assert e.value.code == pkg.abi.E_ZERO_LUM and "luminance appears to be zero" in str(e.value)
