@@ -1,0 +1,261 @@
+// Mitsuba 0.6 plugin `drmlt.so` backed by libdrmlt_amd.so: the thin adaptor of SURVEY.md 8(b).
+//
+// Build ONLY inside a Mitsuba build tree of the fork (needs its headers + Boost/Xerces/OpenEXR,
+// none of which exist in the development image, so this file is not compiled by build()):
+//   add to src/integrators/CMakeLists.txt
+//     add_integrator(drmlt <path>/mitsuba_adaptor.cpp)      # replaces the four drmlt/*.cpp files
+//     target_link_libraries(drmlt drmlt_amd)                # libdrmlt_amd.so + include/drmlt_abi.h
+// It keeps the reference's plugin surface (class name, parameters, RTTI, CreateInstance symbol:
+// include/mitsuba/core/cobject.h:99-107, src/integrators/drmlt/drmlt.cpp:176-621), so
+//   mitsuba scene.xml -D integrator=drmlt -D technique=path -D type=orbital
+// runs against unmodified scene XML. Everything inside render() that the reference does on CPU
+// threads (seeding, chain loop, film merge, develop) happens behind the C-ABI on the GPU.
+#include <mitsuba/bidir/util.h>
+#include <mitsuba/core/plugin.h>
+#include <mitsuba/render/renderjob.h>
+#include <mitsuba/render/scene.h>
+#include <mitsuba/render/trimesh.h>
+
+#include <vector>
+
+#include "drmlt_abi.h"
+
+MTS_NAMESPACE_BEGIN
+
+class DRMLT : public Integrator {
+public:
+    DRMLT(const Properties &props) : Integrator(props), m_stop(0) {
+        memset(&m_cfg, 0, sizeof m_cfg);
+        m_cfg.struct_size = sizeof m_cfg;
+        m_cfg.algo = DRMLT_ALGO_DRMLT;
+        // parameter names and defaults: drmlt.cpp:193-349
+        std::string technique = props.getString("technique");
+        if (technique == "path") m_cfg.technique = DRMLT_TECH_PATH;
+        else if (technique == "bdpt") m_cfg.technique = DRMLT_TECH_BDPT;
+        else if (technique == "mmlt") m_cfg.technique = DRMLT_TECH_MMLT;
+        else Log(EError, "Unknown technique type");
+        std::string type = props.getString("type");
+        if (type == "green") m_cfg.type = DRMLT_TYPE_GREEN;
+        else if (type == "mira") m_cfg.type = DRMLT_TYPE_MIRA;
+        else if (type == "mirasym" || type == "orbital") m_cfg.type = DRMLT_TYPE_ORBITAL;
+        else Log(EError, "Unknown implementation type");
+        m_cfg.max_depth = props.getInteger("maxDepth", -1);
+        m_cfg.rr_depth = props.getInteger("rrDepth", 5);
+        m_cfg.direct_samples = props.getInteger("directSamples", 16);
+        m_cfg.luminance_samples = props.getInteger("luminanceSamples", 100000);
+        m_cfg.p_large = (float) props.getFloat("pLarge", 0.3f);
+        m_cfg.work_units = props.getInteger("workUnits", -1);
+        m_cfg.average_luminance = (float) props.getFloat("averageLuminance", -1.0f);
+        m_cfg.acceptance_map = props.getBoolean("acceptanceMap", false);
+        m_cfg.timid_after_large = props.getBoolean("timidAfterLarge", false);
+        m_cfg.fix_emitter_path = props.getBoolean("fixEmitterPath", false);
+        m_cfg.use_mixture = props.getBoolean("useMixture", false);
+        m_cfg.sigma = (float) props.getFloat("sigma", 1.0f / 64.0f);
+        m_cfg.scale_second = (float) props.getFloat("scaleSecond", 0.1);
+        m_cfg.kelemen_style_weights = props.getBoolean("kelemenStyleWeights", true);
+        m_cfg.kelemen_style_mutation = 1;
+        m_device = props.getInteger("device", 0);
+        if (props.getBoolean("twoStage", false))
+            Log(EError, "twoStage is not supported by the MI355X backend yet");
+    }
+
+    DRMLT(Stream *stream, InstanceManager *manager) : Integrator(stream, manager), m_stop(0) {
+        stream->read(&m_cfg, sizeof m_cfg);
+        m_device = stream->readInt();
+    }
+
+    void serialize(Stream *stream, InstanceManager *manager) const {
+        Integrator::serialize(stream, manager);
+        stream->write(&m_cfg, sizeof m_cfg);
+        stream->writeInt(m_device);
+    }
+
+    bool preprocess(const Scene *scene, RenderQueue *queue, const RenderJob *job, int sceneResID, int sensorResID,
+                    int samplerResID) {
+        Integrator::preprocess(scene, queue, job, sceneResID, sensorResID, samplerResID);
+        if (scene->getSubsurfaceIntegrators().size() > 0)
+            Log(EError, "Subsurface integrators are not supported by MLT!");
+        if (scene->getSensor()->getSampler()->getClass()->getName() != "IndependentSampler")
+            Log(EError, "Metropolis light transport requires the independent sampler");
+        return true;
+    }
+
+    void cancel() { m_stop = 1; } // polled between kernel launches by drmlt_run
+
+    bool render(Scene *scene, RenderQueue *queue, const RenderJob *job, int sceneResID, int sensorResID,
+                int samplerResID) {
+        ref<Sensor> sensor = scene->getSensor();
+        Film *film = sensor->getFilm();
+        const Vector2i crop = film->getCropSize();
+        m_cfg.sample_count = (int32_t) sensor->getSampler()->getSampleCount(); // mutations per pixel, drmlt.cpp:400
+        m_stop = 0;
+
+        // ---- flatten the scene through public accessors only
+        std::vector<drmlt_shape> shapes;
+        std::vector<drmlt_bsdf> bsdfs;
+        std::vector<drmlt_emitter> emitters;
+        const ref_vector<Shape> &mtsShapes = scene->getShapes();
+        for (size_t i = 0; i < mtsShapes.size(); ++i)
+            appendShape(mtsShapes[i].get(), shapes, bsdfs, emitters);
+
+        drmlt_scene sc;
+        memset(&sc, 0, sizeof sc);
+        sc.struct_size = sizeof sc;
+        sc.n_shapes = (int32_t) shapes.size(); sc.shapes = shapes.data();
+        sc.n_bsdfs = (int32_t) bsdfs.size(); sc.bsdfs = bsdfs.data();
+        sc.n_emitters = (int32_t) emitters.size(); sc.emitters = emitters.data();
+        const PerspectiveCamera *cam = dynamic_cast<const PerspectiveCamera *>(sensor.get());
+        if (!cam || cam->needsApertureSample())
+            Log(EError, "The MI355X drmlt backend supports the `perspective` sensor only");
+        const Matrix4x4 &m = cam->getWorldTransform(0).getMatrix();
+        for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) sc.camera.to_world[r * 4 + c] = (float) m(r, c);
+        sc.camera.fov_x_deg = (float) cam->getXFov();
+        sc.camera.near_clip = (float) cam->getNearClip();
+        sc.camera.far_clip = (float) cam->getFarClip();
+        sc.camera.width = crop.x; sc.camera.height = crop.y;
+        const ReconstructionFilter *rf = film->getReconstructionFilter();
+        std::string rfName = rf->getClass()->getName();
+        if (rfName == "BoxFilter") { sc.camera.filter = DRMLT_FILTER_BOX; sc.camera.filter_param = (float) rf->getRadius() - 1e-5f; }
+        else if (rfName == "GaussianFilter") { sc.camera.filter = DRMLT_FILTER_GAUSSIAN; sc.camera.filter_param = (float) rf->getRadius() / 4; }
+        else Log(EError, "Unsupported reconstruction filter for the MI355X drmlt backend: %s", rfName.c_str());
+
+        char err[512];
+        drmlt_ctx *ctx = drmlt_create(&m_cfg, &sc, m_device, err, sizeof err);
+        if (!ctx) Log(EError, "%s", err); // throws, as the reference's parameter checks do
+
+        // separate direct pass stays on the host integrator (util.cpp:30-92), exactly as in the reference
+        ref<Bitmap> directImage;
+        if (m_cfg.direct_samples > 0) {
+            directImage = BidirectionalUtils::renderDirectComponent(scene, sceneResID, sensorResID, queue, job,
+                                                                    m_cfg.direct_samples);
+            if (directImage == NULL) { drmlt_destroy(ctx); return false; }
+        }
+
+        double b = 0;
+        uint64_t seed = ((uint64_t) (uintptr_t) this << 16) ^ (uint64_t) job->getID(); // any distinct value works
+        int rc = drmlt_seed(ctx, seed, 0, &b);
+        if (rc == DRMLT_OK) {
+            Log(EInfo, "Normalization factor computed: %lf", b);
+            uint64_t total = (uint64_t) crop.x * crop.y * (uint64_t) m_cfg.sample_count;
+            rc = drmlt_run(ctx, total, &m_stop, NULL, NULL);
+        }
+        bool ok = rc == DRMLT_OK;
+        if (ok) {
+            ref<Bitmap> out = new Bitmap(Bitmap::ESpectrum, Bitmap::EFloat32, crop);
+            std::vector<float> direct;
+            if (directImage) {
+                ref<Bitmap> d32 = directImage->convert(Bitmap::ESpectrum, Bitmap::EFloat32);
+                direct.assign(d32->getFloat32Data(), d32->getFloat32Data() + (size_t) crop.x * crop.y * 3);
+            }
+            rc = drmlt_develop(ctx, direct.empty() ? NULL : direct.data(), out->getFloat32Data());
+            ok = rc == DRMLT_OK;
+            if (ok) { film->setBitmap(out); queue->signalRefresh(job); } // drmlt_proc.cpp:850-853
+            drmlt_stats st;
+            if (drmlt_stats_get(ctx, &st) == DRMLT_OK) logStats(st);
+        }
+        std::string msg = ok || rc == DRMLT_E_CANCELLED ? "" : drmlt_last_error(ctx);
+        drmlt_destroy(ctx);
+        if (!msg.empty()) Log(EError, "%s", msg.c_str());
+        return ok;
+    }
+
+    MTS_DECLARE_CLASS()
+private:
+    static void logStats(const drmlt_stats &s) { // the StatsCounter block of drmlt_proc.cpp:34-49
+        #define PCT(a, b) ((b) ? 100.0 * (double) (a) / (double) (b) : 0.0)
+        SLog(EInfo, "Accepted 1st-stage mutations : %.2f %%", PCT(s.first_acc, s.first_base));
+        SLog(EInfo, "Accepted large mutations     : %.2f %%", PCT(s.large_acc, s.large_base));
+        SLog(EInfo, "Accepted bold mutations      : %.2f %%", PCT(s.bold_acc, s.bold_base));
+        SLog(EInfo, "Accepted 2nd-stage mutations : %.2f %%", PCT(s.second_acc, s.second_base));
+        SLog(EInfo, "Overall acceptance rate      : %.2f %%", PCT(s.overall_acc, s.overall_base));
+        SLog(EInfo, "%.3e mutations/s on the device", 1e3 * (double) s.mutations / s.kernel_ms);
+        #undef PCT
+    }
+
+    int bsdfIndex(const BSDF *bsdf, std::vector<drmlt_bsdf> &bsdfs) {
+        const Properties &p = bsdf->getProperties();
+        std::string name = bsdf->getClass()->getName();
+        drmlt_bsdf b;
+        memset(&b, 0, sizeof b);
+        Float r, g, bl;
+        if (name == "SmoothDiffuse") {
+            b.type = DRMLT_BSDF_DIFFUSE;
+            Intersection its;
+            bsdf->getDiffuseReflectance(its).toLinearRGB(r, g, bl); // constant textures only
+            b.rgb[0] = (float) r; b.rgb[1] = (float) g; b.rgb[2] = (float) bl;
+        } else if (name == "SmoothDielectric") {
+            b.type = DRMLT_BSDF_DIELECTRIC;
+            b.p[0] = (float) lookupIOR(p, "intIOR", "bk7");
+            b.p[1] = (float) lookupIOR(p, "extIOR", "air");
+        } else {
+            Log(EError, "BSDF type %s has no MI355X drmlt implementation (refusing rather than approximating)", name.c_str());
+        }
+        bsdfs.push_back(b);
+        return (int) bsdfs.size() - 1;
+    }
+
+    void appendShape(const Shape *shape, std::vector<drmlt_shape> &shapes, std::vector<drmlt_bsdf> &bsdfs,
+                     std::vector<drmlt_emitter> &emitters) {
+        std::string name = shape->getClass()->getName();
+        int bsdf = bsdfIndex(shape->getBSDF(), bsdfs);
+        size_t first = shapes.size();
+        drmlt_shape s;
+        memset(&s, 0, sizeof s);
+        s.bsdf = bsdf; s.emitter = -1;
+        if (name == "Rectangle") {
+            s.type = DRMLT_SHAPE_RECTANGLE;
+            Transform t = shape->getProperties().getTransform("toWorld", Transform());
+            if (shape->getProperties().getBoolean("flipNormals", false)) t = t * Transform::scale(Vector(1, 1, -1));
+            const Matrix4x4 &m = t.getMatrix();
+            for (int r = 0; r < 3; ++r) for (int c = 0; c < 4; ++c) s.data[r * 4 + c] = (float) m(r, c);
+            shapes.push_back(s);
+        } else if (name == "Sphere") {
+            s.type = DRMLT_SHAPE_SPHERE;
+            AABB box = shape->getAABB();
+            Point c = box.getCenter();
+            s.data[0] = (float) c.x; s.data[1] = (float) c.y; s.data[2] = (float) c.z;
+            s.data[3] = (float) (0.5f * (box.max.x - box.min.x));
+            shapes.push_back(s);
+        } else if (shape->getClass()->derivesFrom(MTS_CLASS(TriMesh))) {
+            const TriMesh *mesh = static_cast<const TriMesh *>(shape);
+            if (mesh->getVertexNormals() != NULL && !shape->getProperties().getBoolean("faceNormals", false))
+                Log(EWarn, "Mesh \"%s\": smooth vertex normals are ignored (face normals are used)", mesh->getName().c_str());
+            const Triangle *tri = mesh->getTriangles();
+            const Point *pos = mesh->getVertexPositions();
+            s.type = DRMLT_SHAPE_TRIANGLE;
+            for (size_t i = 0; i < mesh->getTriangleCount(); ++i) {
+                for (int v = 0; v < 3; ++v) {
+                    const Point &p = pos[tri[i].idx[v]];
+                    s.data[3 * v] = (float) p.x; s.data[3 * v + 1] = (float) p.y; s.data[3 * v + 2] = (float) p.z;
+                }
+                shapes.push_back(s);
+            }
+        } else {
+            Log(EError, "Shape type %s has no MI355X drmlt implementation", name.c_str());
+        }
+        if (shape->isEmitter()) {
+            if (shapes.size() - first != 1)
+                Log(EError, "Area emitters on multi-triangle meshes are not supported yet");
+            const Emitter *em = shape->getEmitter();
+            if (em->getClass()->getName() != "AreaLight") Log(EError, "Only area emitters are supported");
+            drmlt_emitter e;
+            memset(&e, 0, sizeof e);
+            e.type = DRMLT_EMITTER_AREA;
+            e.shape = (int32_t) first;
+            Float r, g, b;
+            em->getProperties().getSpectrum("radiance").toLinearRGB(r, g, b);
+            e.radiance[0] = (float) r; e.radiance[1] = (float) g; e.radiance[2] = (float) b;
+            e.sampling_weight = (float) em->getSamplingWeight();
+            shapes[first].emitter = (int32_t) emitters.size();
+            emitters.push_back(e);
+        }
+    }
+
+    drmlt_config m_cfg;
+    int m_device;
+    volatile int m_stop;
+};
+
+MTS_IMPLEMENT_CLASS_S(DRMLT, false, Integrator)
+MTS_EXPORT_PLUGIN(DRMLT, "Delayed Rejection MLT (MI355X backend)");
+MTS_NAMESPACE_END

@@ -144,6 +144,17 @@ class SceneData:
         c.fov_x_deg, c.near_clip, c.far_clip = fov_x_deg, near, far
         c.width, c.height, c.filter, c.filter_param = width, height, filt, filter_param
 
+    def save(self, path):
+        """Flat binary scene file read by the C++ host (host/drmlt_integrator.hpp: SceneFile::load)."""
+        import struct as _st
+        with open(path, "wb") as f:
+            f.write(_st.pack("<8I", 0x4C4D5244, 1, len(self.shapes), len(self.bsdfs), len(self.emitters),
+                             C.sizeof(abi.Shape), C.sizeof(abi.Bsdf), C.sizeof(abi.Emitter)))
+            for group in (self.shapes, self.bsdfs, self.emitters):
+                for item in group:
+                    f.write(bytes(item))
+            f.write(bytes(self.camera))
+
     def struct(self):
         sh = (abi.Shape * len(self.shapes))(*self.shapes)
         bs = (abi.Bsdf * len(self.bsdfs))(*self.bsdfs)
