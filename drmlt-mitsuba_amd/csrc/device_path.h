@@ -158,18 +158,24 @@ struct Hit {
 };
 
 // One primitive against one ray. `P` is wave-uniform in the brute-force loop (SGPR operands).
+// Flat primitives are branch-free (selects only): no exec-mask traffic in the hot loop.
 DEV void intersect_prim(const DPrim &P, int idx, f3 o, f3 d, float tmin, Hit &h) {
     f3 lo = mk3(fmaf(P.m[0], o.x, fmaf(P.m[1], o.y, fmaf(P.m[2], o.z, P.m[3]))),
                 fmaf(P.m[4], o.x, fmaf(P.m[5], o.y, fmaf(P.m[6], o.z, P.m[7]))),
                 fmaf(P.m[8], o.x, fmaf(P.m[9], o.y, fmaf(P.m[10], o.z, P.m[11]))));
     f3 ld = mk3(fmaf(P.m[0], d.x, fmaf(P.m[1], d.y, P.m[2] * d.z)), fmaf(P.m[4], d.x, fmaf(P.m[5], d.y, P.m[6] * d.z)),
                 fmaf(P.m[8], d.x, fmaf(P.m[9], d.y, P.m[10] * d.z)));
-    if (P.type != PRIM_SPHERE) {
+    if (P.type != PRIM_SPHERE) { // wave-uniform branch
         float t = -lo.z * fast_rcp(ld.z);
         float u = fmaf(t, ld.x, lo.x), v = fmaf(t, ld.y, lo.y);
-        bool inside = (P.type == PRIM_TRIANGLE) ? (u >= 0.f && v >= 0.f && u + v <= 1.f)
-                                                : (fabsf(u) <= 1.f && fabsf(v) <= 1.f);
-        if (inside && t >= tmin && t <= h.t) { h.prim = idx; h.t = t; h.u = u; h.v = v; }
+        // triangle: u >= 0, v >= 0, u + v <= 1   rectangle: |u| <= 1, |v| <= 1
+        bool tri = P.type == PRIM_TRIANGLE;
+        float a = tri ? u : 1.f - fabsf(u), b = tri ? v : 1.f - fabsf(v), c = tri ? 1.f - (u + v) : 0.f;
+        bool hit = fminf(fminf(a, b), c) >= 0.f && t >= tmin && t <= h.t;
+        h.prim = hit ? idx : h.prim;
+        h.t = hit ? t : h.t;
+        h.u = hit ? u : h.u;
+        h.v = hit ? v : h.v;
     } else {
         // unit sphere; discriminant from the closest-approach vector (stable in fp32)
         float A = dot3(ld, ld), invA = fast_rcp(A);
@@ -193,12 +199,34 @@ DEV void intersect_prim(const DPrim &P, int idx, f3 o, f3 d, float tmin, Hit &h)
     }
 }
 
-// closest hit in [tmin, tmax] over all primitives (the loop index is wave-uniform, so the
-// 64 B primitive record arrives through the scalar cache and feeds VALU ops as SGPRs)
+// closest hit in [tmin, tmax] over all primitives. The loop index is wave-uniform, so the 64 B
+// primitive record is fetched through the SCALAR cache (constant address space => s_load_dwordx16)
+// and feeds the VALU ops as SGPR operands: no VGPRs, no vector-memory latency in the loop.
+typedef const DPrim __attribute__((address_space(4))) *ScalarPrimPtr;
+
 DEV Hit trace_brute(const DParams &P, f3 o, f3 d, float tmin, float tmax) {
     Hit h{-1, tmax, 0.f, 0.f};
     const int n = P.n_prims;
-    for (int i = 0; i < n; ++i) intersect_prim(P.prims[i], i, o, d, tmin, h);
+    if (P.debug & 64) { // A/B: vector-memory path
+        for (int i = 0; i < n; ++i) intersect_prim(P.prims[i], i, o, d, tmin, h);
+        return h;
+    }
+    ScalarPrimPtr sp = (ScalarPrimPtr) (uintptr_t) P.prims;
+    // ping-pong software pipeline: while primitive i is tested (~35 VALU ops) the record of
+    // primitive i+1 is already in flight through the scalar cache, and vice versa
+    auto load = [&](int i, DPrim &G) {
+#pragma unroll
+        for (int k = 0; k < 12; ++k) G.m[k] = sp[i].m[k];
+        G.type = sp[i].type;
+    };
+    DPrim A, B;
+    load(0, A);
+    for (int i = 0; i < n; i += 2) {
+        load(i + 1 < n ? i + 1 : i, B);
+        intersect_prim(A, i, o, d, tmin, h);
+        load(i + 2 < n ? i + 2 : i, A);
+        if (i + 1 < n) intersect_prim(B, i + 1, o, d, tmin, h);
+    }
     return h;
 }
 
