@@ -151,6 +151,87 @@ struct Sampler {
     }
 };
 
+// ------------------------------------------------------------------ PSS sampler of k_mutate_v2
+// Same proposals as `Sampler`, but the Philox draws of a mutation are produced up front, by all
+// lanes that start an evaluation together (convergent code in the bookkeeping branch), and parked
+// in LDS next to the chain state:
+//   lds_x  [0 .. D)          current state x
+//   lds_u1 = lds_x + D*64    first-stage uniforms, draw k of the TAG_S1 stream (row k, D rounded to 4)
+//   lds_s2 = lds_u1 + D4*64  second-stage values: orbital: theta uniform of pair q in row q;
+//                            iid: the Gaussian perturbation of dim k in row k; large: uniform k
+// The per-dimension code below is then pure arithmetic on LDS operands -- no RNG, no caches, no
+// divergent Philox in the ray loop (measured: the on-demand sampler was ~2/3 of the VALU work).
+struct LdsSampler {
+    uint32_t key0, key1, chain, major;
+    int mode, type;
+    bool large;
+    float sigma2;
+    uint32_t lane;
+    uint32_t u1_off, s2_off; // row offsets (in floats) of lds_u1 / lds_s2
+
+    DEV void reset_caches() {}
+    DEV float x(uint32_t k) const { return lds_x[k * 64u + lane]; }
+    DEV float u1(uint32_t k) const { return lds_x[u1_off + k * 64u + lane]; }
+    DEV float s2(uint32_t k) const { return lds_x[s2_off + k * 64u + lane]; }
+
+    // all first-stage draws of this mutation: rows [0, D4) of lds_u1
+    DEV void fill_stage1(uint32_t D4) {
+        for (uint32_t b = 0; b < D4 / 4u; ++b) {
+            u4 r = philox4x32_10(key0, key1, b, major, chain, TAG_S1);
+            float *dst = &lds_x[u1_off + b * 256u + lane];
+            dst[0] = u32_to_unit(r.x); dst[64] = u32_to_unit(r.y); dst[128] = u32_to_unit(r.z); dst[192] = u32_to_unit(r.w);
+        }
+    }
+    // second-stage values (see layout above)
+    DEV void fill_stage2(uint32_t D4) {
+        if (large || type == 2) {
+            const uint32_t rows = large ? D4 : (D4 / 2u + 3u) & ~3u; // uniforms: one per dim, or one per pair
+            for (uint32_t b = 0; b < rows / 4u; ++b) {
+                u4 r = philox4x32_10(key0, key1, b, major, chain, TAG_S2);
+                float *dst = &lds_x[s2_off + b * 256u + lane];
+                dst[0] = u32_to_unit(r.x); dst[64] = u32_to_unit(r.y); dst[128] = u32_to_unit(r.z); dst[192] = u32_to_unit(r.w);
+            }
+        } else {
+            for (uint32_t b = 0; b < D4 / 2u; ++b) { // draws (2k, 2k+1) -> Gaussian sample of dim k
+                u4 r = philox4x32_10(key0, key1, b, major, chain, TAG_S2);
+                float *dst = &lds_x[s2_off + b * 128u + lane];
+                dst[0] = gaussian_sample(u32_to_unit(r.x), u32_to_unit(r.y), sigma2);
+                dst[64] = gaussian_sample(u32_to_unit(r.z), u32_to_unit(r.w), sigma2);
+            }
+        }
+    }
+
+    DEV float y_raw(uint32_t k) const {
+        if (large) return u1(k);
+        if (type != 2) return x(k) + kelemen_sample(u1(k), KELEMEN_S2);
+        const uint32_t k0 = k & ~1u;
+        float d = kelemen_sample(u1(k0), KELEMEN_S2 * ORBITAL_SCALE), a = u1(k0 + 1u);
+        return fmaf(d, (k & 1u) ? sin_rev(a) : cos_rev(a), x(k));
+    }
+    DEV float z_raw(uint32_t k) const {
+        if (large) return s2(k);
+        if (type != 2) return x(k) + s2(k);
+        const uint32_t k0 = k & ~1u;
+        float x0 = x(k0), x1 = x(k0 + 1u);
+        float d = kelemen_sample(u1(k0), KELEMEN_S2 * ORBITAL_SCALE), a = u1(k0 + 1u);
+        float y0 = fmaf(d, cos_rev(a), x0), y1 = fmaf(d, sin_rev(a), x1);
+        float xi = s2(k0 >> 1);
+        float sign = 1.f;
+        if (xi < 0.5f) { xi *= 2.f; } else { sign = -1.f; xi = 2.f * (xi - 0.5f); }
+        float V = cos_rev(xi);
+        float A = fminf(1.f, fmaxf(-1.f, (V + WC_DISPERSION) / (1.f + WC_DISPERSION * V)));
+        float ct = A, st = sign * sqrtf(fmaxf(0.f, 1.f - A * A));
+        float dx0 = x0 - y0, dx1 = x1 - y1;
+        return (k & 1u) ? y1 + (st * dx0 + ct * dx1) : y0 + (ct * dx0 - st * dx1);
+    }
+    DEV float next(uint32_t k) const {
+        if (mode == SM_STAGE1) return wrap01(y_raw(k));
+        if (mode == SM_STAGE2) return wrap01(z_raw(k));
+        float du = y_raw(k) - x(k); // Green reverse: y* = z - (y - x)
+        return wrap01(z_raw(k) - du);
+    }
+};
+
 // ------------------------------------------------------------------ ray queries
 struct Hit {
     int prim;
@@ -294,7 +375,7 @@ DEV Hit trace(const DParams &P, f3 o, f3 d, float tmin, float tmax, bool any_hit
 // All PSS components a step needs are drawn at ONE site (the `next` loop below): the sampler
 // code (Philox + transition kernels) is the bulk of the instruction footprint, so it is
 // instantiated once per kernel instead of once per consumer.
-enum { PH_DONE = 0, PH_BEGIN = 1, PH_CLOSEST = 2, PH_SHADOW = 3 };
+enum { PH_DONE = 0, PH_BEGIN = 1, PH_CLOSEST = 2, PH_SHADOW = 3, PH_IDLE = 4 };
 
 struct PathState {
     f3 o, d;          // ray to trace next (o doubles as the current surface point)
@@ -362,7 +443,7 @@ DEV void path_init(const DParams &P, PathState &ps) {
 
 // Consume the result of the ray query issued for `ps` (none in PH_BEGIN) and either issue the
 // next ray (PH_CLOSEST / PH_SHADOW) or finish the path (PH_DONE, radiance in ps.Li).
-DEV void path_step(const DParams &P, PathState &ps, Sampler &smp, const Hit &hit) {
+template <class SamplerT> DEV void path_step(const DParams &P, PathState &ps, SamplerT &smp, const Hit &hit) {
     // ---------------- part 1: digest the ray query, decide which PSS components are needed
     bool want_rr = false, want_nee = false;
     int need = 0;

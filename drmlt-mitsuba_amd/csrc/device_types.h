@@ -82,7 +82,9 @@ struct DParams {
     float *cur_lum, *cur_px, *cur_py, *cur_r, *cur_g, *cur_b;
     unsigned long long *stats; // 18 counters, layout of drmlt_stats
     int32_t *error_flag;
-    int32_t debug; // DRMLT_DEBUG bit mask (diagnostics only)
+    int32_t debug;          // DRMLT_DEBUG bit mask (diagnostics only)
+    int32_t kernel_variant; // 1: k_mutate (nested loops), 2: k_mutate_v2 (per-lane state machines)
+    int32_t mh_batch;       // k_mutate_v2: parked lanes needed before the bookkeeping branch is taken
 };
 
 // result of one PSS evaluation, SoA-friendly

@@ -241,6 +241,215 @@ __global__ void __launch_bounds__(CHAIN_BLOCK) k_mutate(DParams P, uint32_t n_mu
         for (int i = 0; i < 9; ++i) atomicAdd(P.stats + i, v[i]);
 }
 
+// ------------------------------------------------------------------------------------------
+// k_mutate_v2: the same chain loop as k_mutate, restructured for the wave.
+//
+// k_mutate nests "for every stage: run the path to completion": a wave then runs as long as its
+// longest path, and the second stage (needed by a few lanes only) costs the whole wave a second
+// full evaluation -- measured VALU lane utilisation 22 %. Here every lane is an independent
+// state machine and one loop iteration is ONE ray step for all lanes, whatever path, stage or
+// mutation each of them is in. Lanes whose path has finished park until at least
+// `P.mh_batch` of them can take the Metropolis-Hastings bookkeeping branch together (the branch
+// is divergent, so its cost is amortised over the lanes that share it). Per lane the arithmetic
+// is identical to k_mutate: both kernels produce the same chains.
+struct ChainState {
+    DSplat cur, y, z;
+    float a1, coin_acc1, coin_acc2, coin_mix;
+    uint32_t it, nd1, nd2;
+    int stage;       // -1: no mutation in flight, 0/1/2: evaluating first / second / reverse
+    bool large, do_second;
+};
+
+DEV void start_path(const DParams &P, LdsSampler &smp, PathState &ps, int stage) {
+    smp.mode = stage == 0 ? SM_STAGE1 : (stage == 1 ? SM_STAGE2 : SM_REVERSE);
+    const uint32_t D4 = ((uint32_t) P.eff_dim + 3u) & ~3u;
+    if (stage == 0) smp.fill_stage1(D4);       // every draw this mutation's proposals can use,
+    else if (stage == 1) smp.fill_stage2(D4);  // produced by all lanes that start an evaluation now
+    path_init(P, ps);
+}
+
+// Digest a finished path evaluation of this lane: advance the mutation's stage machine, finish
+// the mutation (splats, counters, commit) when decided, and start the next evaluation.
+// Returns false when the lane has completed all its mutations.
+DEV bool mh_advance(const DParams &P, ChainState &cs, LdsSampler &smp, PathState &ps, Counters &ct, uint32_t n_mut,
+                    uint32_t mut_base, uint32_t lane) {
+    const bool mix = P.use_mixture != 0;
+    const bool amap = P.acceptance_map != 0;
+    const int D = P.eff_dim;
+    bool decided = false;
+    float a2 = 0.f;
+    bool acc1 = false, acc2 = false;
+    if (cs.stage >= 0) {
+        DSplat res;
+        res.px = ps.px; res.py = ps.py; res.r = ps.Li.x; res.g = ps.Li.y; res.b = ps.Li.z;
+        res.lum = luminance3(ps.Li);
+        normalize_splat(res);
+        ct.rays += ps.nrays;
+        if (cs.stage == 0) {
+            cs.y = res; cs.nd1 = ps.k;
+            cs.a1 = 0.f;
+            if (!(mix ? lum_invalid_mix(res.lum) : lum_invalid(res.lum))) cs.a1 = fminf(1.f, res.lum / cs.cur.lum);
+            acc1 = cs.a1 >= 1.f || (cs.a1 > 0.f && cs.coin_acc1 < cs.a1);
+            if (!mix) cs.do_second = !acc1 && (P.timid_after_large || !cs.large);
+            else cs.do_second = !cs.large && cs.coin_mix < 0.5f;
+            if (cs.do_second) { cs.stage = 1; start_path(P, smp, ps, 1); return true; }
+            decided = true;
+        } else if (cs.stage == 1) {
+            cs.z = res; cs.nd2 = ps.k;
+            acc1 = false;
+            if (mix) {
+                cs.a1 = 0.f;
+                if (!lum_invalid_mix(res.lum)) {
+                    a2 = fminf(1.f, res.lum / cs.cur.lum);
+                    acc2 = a2 >= 1.f || cs.coin_acc2 < a2;
+                }
+            } else if (!lum_invalid(res.lum)) {
+                if (P.type == 0) { cs.stage = 2; start_path(P, smp, ps, 2); return true; }
+                if (P.type == 1) {
+                    float aRev = fminf(1.f, cs.y.lum / res.lum);
+                    if (!(aRev >= 1.f)) {
+                        float ratio = 1.f;
+                        if (!cs.large) {
+                            uint32_t dimStage = max(cs.nd1, cs.nd2) - 1u;
+                            float num = 0.f, den = 0.f;
+                            for (uint32_t i = 0; i < dimStage; ++i) {
+                                float yi = smp.y_raw(i);
+                                num += kelemen_logpdf(smp.z_raw(i) - yi);
+                                den += kelemen_logpdf(smp.x(i) - yi);
+                            }
+                            ratio = __expf(num - den);
+                        }
+                        if (!lum_invalid(ratio)) {
+                            a2 = fminf(1.f, (res.lum / cs.cur.lum) * ratio * (1.f - aRev) / (1.f - cs.a1));
+                            acc2 = a2 >= 1.f || cs.coin_acc2 < a2;
+                        }
+                    }
+                } else {
+                    if (res.lum < cs.y.lum) { a2 = 0.f; }
+                    else if (res.lum >= cs.cur.lum) { a2 = 1.f; acc2 = true; }
+                    else {
+                        a2 = (res.lum - cs.y.lum) / (cs.cur.lum - cs.y.lum);
+                        acc2 = a2 >= 1.f || cs.coin_acc2 < a2;
+                    }
+                }
+            }
+            decided = true;
+        } else {
+            ct.acc2b_rev += 1u << 16;
+            float aRev = lum_invalid(res.lum) ? 0.f : fminf(1.f, res.lum / cs.z.lum);
+            if (aRev != 1.f) {
+                a2 = fminf(1.f, (cs.z.lum / cs.cur.lum) * (1.f - aRev) / (1.f - cs.a1));
+                acc2 = a2 >= 1.f || cs.coin_acc2 < a2;
+            }
+            decided = true;
+        }
+    }
+    if (decided) {
+        const DSplat &cur = cs.cur, &y = cs.y, &z = cs.z;
+        if (!mix) {
+            float w1 = cs.a1, w2 = (1.f - cs.a1) * a2, w0 = 1.f - w1 - w2;
+            if (!amap) {
+                if (w0 > 0.f) film_put(P, cur.px, cur.py, mk3(cur.r * w0, cur.g * w0, cur.b * w0));
+                if (w1 > 0.f) film_put(P, y.px, y.py, mk3(y.r * w1, y.g * w1, y.b * w1));
+                if (cs.do_second && w2 > 0.f) film_put(P, z.px, z.py, mk3(z.r * w2, z.g * w2, z.b * w2));
+            }
+        } else {
+            const float a = cs.do_second ? a2 : cs.a1;
+            const DSplat &pr = cs.do_second ? z : y;
+            if (1.f - a > 0.f) film_put(P, cur.px, cur.py, mk3(cur.r * (1.f - a), cur.g * (1.f - a), cur.b * (1.f - a)));
+            if (a > 0.f) film_put(P, pr.px, pr.py, mk3(pr.r * a, pr.g * a, pr.b * a));
+        }
+        if (cs.large) {
+            ct.large_acc1l += 1u + (acc1 ? 1u << 16 : 0u);
+            if (cs.do_second) ct.acc1b_secl += 1u << 16;
+            if (acc2) ct.secb_acc2l += 1u << 16;
+        } else {
+            if (acc1) ct.acc1b_secl += 1u;
+            if (cs.do_second) ct.secb_acc2l += 1u;
+            if (acc2) ct.acc2b_rev += 1u;
+        }
+        if (acc1 || acc2) {
+            smp.mode = acc1 ? SM_STAGE1 : SM_STAGE2;
+            for (int k = 0; k < D; ++k) lds_x[k * 64 + lane] = smp.next((uint32_t) k);
+            cs.cur = acc1 ? cs.y : cs.z;
+            if (amap && !mix) {
+                if (acc1) { if (!cs.large) film_put(P, cs.cur.px, cs.cur.py, mk3(1.f, 0.f, 0.f)); }
+                else film_put(P, cs.cur.px, cs.cur.py, mk3(0.f, 1.f, 0.f));
+            }
+        }
+        cs.it++;
+        cs.stage = -1;
+    }
+    // start the next mutation
+    if (cs.it >= n_mut) { ps.phase = PH_IDLE; return false; }
+    const uint32_t m = mut_base + cs.it;
+    const u4 coins = philox4x32_10(P.key0, P.key1, 0u, m, smp.chain, TAG_COIN);
+    cs.large = u32_to_unit(coins.x) < P.p_large;
+    cs.coin_acc1 = u32_to_unit(coins.y); cs.coin_acc2 = u32_to_unit(coins.z); cs.coin_mix = u32_to_unit(coins.w);
+    smp.major = m;
+    smp.large = cs.large;
+    cs.stage = 0;
+    cs.do_second = false;
+    cs.nd1 = cs.nd2 = 0u;
+    start_path(P, smp, ps, 0);
+    return true;
+}
+
+__global__ void __launch_bounds__(CHAIN_BLOCK) k_mutate_v2(DParams P, uint32_t n_mut, uint32_t mut_base) {
+    const uint32_t lane = threadIdx.x;
+    const uint32_t c = blockIdx.x * CHAIN_BLOCK + lane;
+    const bool live = c < P.n_chains;
+    const uint32_t cc = live ? c : P.n_chains - 1;
+    const int D = P.eff_dim;
+    for (int k = 0; k < D; ++k) lds_x[k * 64 + lane] = P.x[(size_t) k * P.n_chains + cc];
+
+    ChainState cs;
+    cs.cur.lum = P.cur_lum[cc]; cs.cur.px = P.cur_px[cc]; cs.cur.py = P.cur_py[cc];
+    cs.cur.r = P.cur_r[cc]; cs.cur.g = P.cur_g[cc]; cs.cur.b = P.cur_b[cc];
+    cs.y = cs.cur; cs.z = cs.cur;
+    cs.a1 = 0.f; cs.coin_acc1 = cs.coin_acc2 = cs.coin_mix = 0.f;
+    cs.it = 0u; cs.nd1 = cs.nd2 = 0u; cs.stage = -1; cs.large = false; cs.do_second = false;
+
+    LdsSampler smp;
+    smp.key0 = P.key0; smp.key1 = P.key1; smp.chain = P.chain_offset + cc; smp.major = 0u;
+    smp.mode = SM_STAGE1; smp.type = P.type; smp.large = false; smp.sigma2 = P.sigma2; smp.lane = lane;
+    const uint32_t D4 = ((uint32_t) D + 3u) & ~3u;
+    smp.u1_off = (uint32_t) D * 64u;
+    smp.s2_off = smp.u1_off + D4 * 64u;
+    Counters ct = {0u, 0u, 0u, 0u, 0u};
+    PathState ps;
+    path_init(P, ps);
+    ps.phase = (live && n_mut > 0u) ? PH_DONE : PH_IDLE; // PH_DONE with stage -1: "start the first mutation"
+    Hit h{-1, 0.f, 0.f, 0.f};
+    const int batch = P.mh_batch;
+
+    for (;;) {
+        const bool parked = ps.phase == PH_DONE;
+        const unsigned long long pmask = __ballot(parked);
+        const unsigned long long rmask = __ballot(ps.phase != PH_DONE && ps.phase != PH_IDLE);
+        if (!pmask && !rmask) break;
+        if (pmask && (__popcll(pmask) >= batch || !rmask)) {
+            if (parked) mh_advance(P, cs, smp, ps, ct, n_mut, mut_base, lane);
+        }
+        if (ps.phase == PH_CLOSEST || ps.phase == PH_SHADOW) h = trace(P, ps.o, ps.d, ps.tmin, ps.tmax, ps.phase == PH_SHADOW);
+        if (ps.phase != PH_DONE && ps.phase != PH_IDLE) path_step(P, ps, smp, h);
+    }
+
+    if (live) {
+        for (int k = 0; k < D; ++k) P.x[(size_t) k * P.n_chains + c] = lds_x[k * 64 + lane];
+        P.cur_lum[c] = cs.cur.lum; P.cur_px[c] = cs.cur.px; P.cur_py[c] = cs.cur.py;
+        P.cur_r[c] = cs.cur.r; P.cur_g[c] = cs.cur.g; P.cur_b[c] = cs.cur.b;
+    }
+    unsigned long long v[9];
+    v[0] = wave_sum(ct.large_acc1l & 0xffffu); v[1] = wave_sum(ct.large_acc1l >> 16);
+    v[2] = wave_sum(ct.acc1b_secl & 0xffffu);  v[3] = wave_sum(ct.acc1b_secl >> 16);
+    v[4] = wave_sum(ct.secb_acc2l & 0xffffu);  v[5] = wave_sum(ct.secb_acc2l >> 16);
+    v[6] = wave_sum(ct.acc2b_rev & 0xffffu);   v[7] = wave_sum(ct.acc2b_rev >> 16);
+    v[8] = wave_sum(ct.rays);
+    if (lane == 0)
+        for (int i = 0; i < 9; ++i) atomicAdd(P.stats + i, v[i]);
+}
+
 __global__ void __launch_bounds__(256) k_eval_paths(DParams P, const float *u, uint32_t n, uint32_t dim, float *out8) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -296,8 +505,13 @@ void launch_init_chains(const DParams &P, const uint32_t *seed_index, const floa
     hipLaunchKernelGGL(k_init_chains, dim3((P.n_chains + 255) / 256), dim3(256), 0, st, P, seed_index, seed_lum);
 }
 void launch_mutate(const DParams &P, uint32_t n_mut, uint32_t mut_base, hipStream_t st) {
-    size_t lds = (size_t) P.eff_dim * 64 * sizeof(float);
-    hipLaunchKernelGGL(k_mutate, dim3((P.n_chains + CHAIN_BLOCK - 1) / CHAIN_BLOCK), dim3(CHAIN_BLOCK), lds, st, P, n_mut, mut_base);
+    const size_t D = (size_t) P.eff_dim, D4 = (D + 3) & ~(size_t) 3;
+    dim3 grid((P.n_chains + CHAIN_BLOCK - 1) / CHAIN_BLOCK), block(CHAIN_BLOCK);
+    if (P.kernel_variant == 1) {
+        hipLaunchKernelGGL(k_mutate, grid, block, D * 64 * sizeof(float), st, P, n_mut, mut_base);
+    } else { // x + first-stage uniforms + second-stage values, one 256 B row per dimension
+        hipLaunchKernelGGL(k_mutate_v2, grid, block, (D + 2 * D4) * 64 * sizeof(float), st, P, n_mut, mut_base);
+    }
 }
 void launch_eval_paths(const DParams &P, const float *u, uint32_t n, uint32_t dim, float *out8, hipStream_t st) {
     hipLaunchKernelGGL(k_eval_paths, dim3((n + 255) / 256), dim3(256), 0, st, P, u, n, dim, out8);
