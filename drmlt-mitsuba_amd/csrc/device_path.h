@@ -18,7 +18,7 @@
 // Current PSS states of the 64 chains of this wave, [dim][lane]: lane-contiguous rows, so any
 // per-lane dimension pattern is bank-conflict free (64 == 0 mod 32 banks). Addressed directly
 // (ds_read), never through a generic pointer: LDS offset 0 casts to the flat null pointer.
-extern __shared__ float lds_x[];
+extern __shared__ __attribute__((aligned(16))) float lds_x[];
 
 // ------------------------------------------------------------------ PSS sampler
 enum { SM_BOOT = 0, SM_ARRAY = 1, SM_STAGE1 = 2, SM_STAGE2 = 3, SM_REVERSE = 4, SM_PT = 5 };
@@ -168,18 +168,21 @@ struct LdsSampler {
     float sigma2;
     uint32_t lane;
     uint32_t u1_off, s2_off; // row offsets (in floats) of lds_u1 / lds_s2
+    uint32_t stride;         // floats per row (64; 32 in the half-wave experiment)
+    bool timing_probe;       // DRMLT_DEBUG bit 256: replace stage-1 Philox by a trivial hash (timing experiments only)
 
     DEV void reset_caches() {}
-    DEV float x(uint32_t k) const { return lds_x[k * 64u + lane]; }
-    DEV float u1(uint32_t k) const { return lds_x[u1_off + k * 64u + lane]; }
-    DEV float s2(uint32_t k) const { return lds_x[s2_off + k * 64u + lane]; }
+    DEV float x(uint32_t k) const { return lds_x[k * stride + lane]; }
+    DEV float u1(uint32_t k) const { return lds_x[u1_off + k * stride + lane]; }
+    DEV float s2(uint32_t k) const { return lds_x[s2_off + k * stride + lane]; }
 
     // all first-stage draws of this mutation: rows [0, D4) of lds_u1
     DEV void fill_stage1(uint32_t D4) {
         for (uint32_t b = 0; b < D4 / 4u; ++b) {
-            u4 r = philox4x32_10(key0, key1, b, major, chain, TAG_S1);
-            float *dst = &lds_x[u1_off + b * 256u + lane];
-            dst[0] = u32_to_unit(r.x); dst[64] = u32_to_unit(r.y); dst[128] = u32_to_unit(r.z); dst[192] = u32_to_unit(r.w);
+            u4 r = timing_probe ? u4{b * 2654435761u ^ major, chain * 40503u + b, major * 2246822519u, b + chain}
+                                : philox4x32_10(key0, key1, b, major, chain, TAG_S1);
+            float *dst = &lds_x[u1_off + b * 4u * stride + lane];
+            dst[0] = u32_to_unit(r.x); dst[stride] = u32_to_unit(r.y); dst[2u * stride] = u32_to_unit(r.z); dst[3u * stride] = u32_to_unit(r.w);
         }
     }
     // second-stage values (see layout above)
@@ -188,15 +191,15 @@ struct LdsSampler {
             const uint32_t rows = large ? D4 : (D4 / 2u + 3u) & ~3u; // uniforms: one per dim, or one per pair
             for (uint32_t b = 0; b < rows / 4u; ++b) {
                 u4 r = philox4x32_10(key0, key1, b, major, chain, TAG_S2);
-                float *dst = &lds_x[s2_off + b * 256u + lane];
-                dst[0] = u32_to_unit(r.x); dst[64] = u32_to_unit(r.y); dst[128] = u32_to_unit(r.z); dst[192] = u32_to_unit(r.w);
+                float *dst = &lds_x[s2_off + b * 4u * stride + lane];
+                dst[0] = u32_to_unit(r.x); dst[stride] = u32_to_unit(r.y); dst[2u * stride] = u32_to_unit(r.z); dst[3u * stride] = u32_to_unit(r.w);
             }
         } else {
             for (uint32_t b = 0; b < D4 / 2u; ++b) { // draws (2k, 2k+1) -> Gaussian sample of dim k
                 u4 r = philox4x32_10(key0, key1, b, major, chain, TAG_S2);
-                float *dst = &lds_x[s2_off + b * 128u + lane];
+                float *dst = &lds_x[s2_off + b * 2u * stride + lane];
                 dst[0] = gaussian_sample(u32_to_unit(r.x), u32_to_unit(r.y), sigma2);
-                dst[64] = gaussian_sample(u32_to_unit(r.z), u32_to_unit(r.w), sigma2);
+                dst[stride] = gaussian_sample(u32_to_unit(r.z), u32_to_unit(r.w), sigma2);
             }
         }
     }
@@ -300,14 +303,22 @@ DEV Hit trace_brute(const DParams &P, f3 o, f3 d, float tmin, float tmax) {
         for (int k = 0; k < 12; ++k) G.m[k] = sp[i].m[k];
         G.type = sp[i].type;
     };
+    // SMEM returns out of order, so the only wait is lgkmcnt(0) = "everything outstanding". The
+    // empty asm pins that wait on record X BEFORE the request for the other record is issued;
+    // otherwise the compiler's wait for X (placed at X's first use) would also wait for the
+    // record just requested and the pipeline would collapse to one load at a time.
+#define PIN(G) asm volatile("" ::"s"(G.m[0]), "s"(G.m[4]), "s"(G.m[8]), "s"(G.type))
     DPrim A, B;
     load(0, A);
     for (int i = 0; i < n; i += 2) {
+        PIN(A);
         load(i + 1 < n ? i + 1 : i, B);
         intersect_prim(A, i, o, d, tmin, h);
+        PIN(B);
         load(i + 2 < n ? i + 2 : i, A);
         if (i + 1 < n) intersect_prim(B, i + 1, o, d, tmin, h);
     }
+#undef PIN
     return h;
 }
 
@@ -367,6 +378,55 @@ DEV Hit trace_bvh(const DParams &P, f3 o, f3 d, float tmin, float tmax, bool any
 DEV Hit trace(const DParams &P, f3 o, f3 d, float tmin, float tmax, bool any_hit) {
     if (P.use_bvh) return trace_bvh(P, o, d, tmin, tmax, any_hit);
     return trace_brute(P, o, d, tmin, tmax);
+}
+
+// ------------------------------------------------------------------ scene tables
+// Shading / BSDF / emitter records are read per lane after a hit. Small scenes stage them in LDS
+// once per launch (a dependent chain of 3-4 global gathers per step was ~1/3 of the wave's time
+// at one wave per SIMD); large scenes read them from HBM/L2.
+struct GlobalTables {
+    const DShade *sh; const DBsdf *bs; const DEmitter *em;
+    DEV DShade shade(int i) const { return sh[i]; }
+    DEV DBsdf bsdf(int i) const { return bs[i]; }
+    DEV DEmitter emitter(int i) const { return em[i]; }
+    DEV float emitter_cdf_lo(int i) const { return em[i].cdf_lo; }
+};
+struct LdsTables {
+    uint32_t shade_off, bsdf_off, emit_off; // float offsets into lds_x, multiples of 4
+    DEV DShade shade(int i) const {
+        DShade s;
+        float *d = reinterpret_cast<float *>(&s);
+        const uint32_t o = shade_off + (uint32_t) i * 16u;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) d[k] = lds_x[o + k];
+        return s;
+    }
+    DEV DBsdf bsdf(int i) const {
+        DBsdf b;
+        float *d = reinterpret_cast<float *>(&b);
+        const uint32_t o = bsdf_off + (uint32_t) i * 12u;
+#pragma unroll
+        for (int k = 0; k < 12; ++k) d[k] = lds_x[o + k];
+        return b;
+    }
+    DEV DEmitter emitter(int i) const {
+        DEmitter e;
+        float *d = reinterpret_cast<float *>(&e);
+        const uint32_t o = emit_off + (uint32_t) i * 8u;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) d[k] = lds_x[o + k];
+        return e;
+    }
+    DEV float emitter_cdf_lo(int i) const { return lds_x[emit_off + (uint32_t) i * 8u + 4u]; }
+};
+// cooperative copy of the three tables into LDS by one wave
+DEV void stage_tables(const DParams &P, const LdsTables &T, uint32_t lane) {
+    const float *src = reinterpret_cast<const float *>(P.shade);
+    for (uint32_t i = lane; i < (uint32_t) P.n_prims * 16u; i += 64u) lds_x[T.shade_off + i] = src[i];
+    src = reinterpret_cast<const float *>(P.bsdfs);
+    for (uint32_t i = lane; i < (uint32_t) P.n_bsdfs * 12u; i += 64u) lds_x[T.bsdf_off + i] = src[i];
+    src = reinterpret_cast<const float *>(P.emitters);
+    for (uint32_t i = lane; i < (uint32_t) P.n_emitters * 8u; i += 64u) lds_x[T.emit_off + i] = src[i];
 }
 
 // ------------------------------------------------------------------ estimator state machine
@@ -443,7 +503,8 @@ DEV void path_init(const DParams &P, PathState &ps) {
 
 // Consume the result of the ray query issued for `ps` (none in PH_BEGIN) and either issue the
 // next ray (PH_CLOSEST / PH_SHADOW) or finish the path (PH_DONE, radiance in ps.Li).
-template <class SamplerT> DEV void path_step(const DParams &P, PathState &ps, SamplerT &smp, const Hit &hit) {
+template <class SamplerT, class TablesT>
+DEV void path_step(const DParams &P, const TablesT &T, PathState &ps, SamplerT &smp, const Hit &hit) {
     // ---------------- part 1: digest the ray query, decide which PSS components are needed
     bool want_rr = false, want_nee = false;
     int need = 0;
@@ -454,11 +515,11 @@ template <class SamplerT> DEV void path_step(const DParams &P, PathState &ps, Sa
         need = 2; // film position, pathsampler.cpp:538-543
     } else if (ps.phase == PH_SHADOW) {
         if (hit.prim < 0) ps.Li = ps.Li + ps.nee; // unoccluded
-        B = P.bsdfs[ps.bsdf];
+        B = T.bsdf(ps.bsdf);
     } else {
         if (hit.prim < 0) { ps.phase = PH_DONE; return; } // no environment emitter
-        const DShade S = P.shade[hit.prim];
-        const int ptype = P.prims[hit.prim].type;
+        const DShade S = T.shade(hit.prim);
+        const int ptype = S.bsdf >> 24; // primitive kind rides in the top byte
         // surface point + shading frame (skdtree.h:340-429, rectangle.cpp:155-168, sphere.cpp:207-255)
         if (ptype != PRIM_SPHERE) {
             p = fma3(ld3(S.eu), hit.u, fma3(ld3(S.ev), hit.v, ld3(S.origin)));
@@ -478,7 +539,7 @@ template <class SamplerT> DEV void path_step(const DParams &P, PathState &ps, Sa
             ps.eta *= ps.beta_eta;
             // emitter hit by the BSDF-sampled ray: MIS against direct sampling (path.cpp:269-285)
             if (S.emitter >= 0 && ps.direct_on && ps.non_specular) {
-                const DEmitter E = P.emitters[S.emitter];
+                const DEmitter E = T.emitter(S.emitter);
                 float dn = dot3(ps.d, n);
                 if (dn < 0.f) { // AreaLight::eval: dot(n, -d) > 0
                     float lumPdf = 0.f;
@@ -505,8 +566,8 @@ template <class SamplerT> DEV void path_step(const DParams &P, PathState &ps, Sa
         f3 md = -ps.d;
         ps.wi = mk3(dot3(md, s), dot3(md, t), dot3(md, n));
         ps.o = p; ps.n = n; ps.s = s;
-        ps.bsdf = S.bsdf;
-        B = P.bsdfs[S.bsdf];
+        ps.bsdf = S.bsdf & 0xffffff;
+        B = T.bsdf(ps.bsdf);
         ps.refn_zero = B.type == 1; // transmissive / two-sided: DirectSamplingRecord(its) zeroes refN
         want_nee = ps.direct_on && (B.type == 0 || B.type == 2);
         need = (want_rr ? 1 : 0) + (want_nee ? 2 : 0) + 2;
@@ -555,13 +616,13 @@ template <class SamplerT> DEV void path_step(const DParams &P, PathState &ps, Sa
             f3 t = cross3(n, s);
             int ei = 0; // DiscreteDistribution::sample (lower_bound semantics)
             for (int i = 1; i < P.n_emitters; ++i)
-                if (P.emitters[i].cdf_lo < sx) ei = i;
-            const DEmitter E = P.emitters[ei];
+                if (T.emitter_cdf_lo(i) < sx) ei = i;
+            const DEmitter E = T.emitter(ei);
             float emPdf = E.cdf_hi - E.cdf_lo;
             sx = (sx - E.cdf_lo) / emPdf; // sampleReuse
-            const DShade L = P.shade[E.prim];
+            const DShade L = T.shade(E.prim);
             f3 lp;
-            if (P.prims[E.prim].type == PRIM_RECTANGLE) { // rectangle.cpp:210-216
+            if ((L.bsdf >> 24) == PRIM_RECTANGLE) { // rectangle.cpp:210-216
                 lp = fma3(ld3(L.eu), sx * 2.f - 1.f, fma3(ld3(L.ev), sy * 2.f - 1.f, ld3(L.origin)));
             } else { // single triangle: squareToUniformTriangle
                 float a = sqrtf(fmaxf(0.f, 1.f - sx));
@@ -646,9 +707,10 @@ DEV DSplat eval_path(const DParams &P, Sampler &smp, uint32_t &nrays, uint32_t &
     smp.reset_caches();
     path_init(P, ps);
     Hit h{-1, 0.f, 0.f, 0.f};
+    const GlobalTables T{P.shade, P.bsdfs, P.emitters};
     for (;;) {
         if (ps.phase != PH_BEGIN) h = trace(P, ps.o, ps.d, ps.tmin, ps.tmax, ps.phase == PH_SHADOW);
-        path_step(P, ps, smp, h);
+        path_step(P, T, ps, smp, h);
         if (ps.phase == PH_DONE) break;
     }
     DSplat out;

@@ -63,12 +63,12 @@ struct DParams {
     const DEmitter *emitters;
     const DBvhNode *bvh;
     const float *filter_lut; // 32 entries (MTS_FILTER_RESOLUTION + 1)
-    int32_t n_prims, n_emitters, n_bvh_nodes, use_bvh;
+    int32_t n_prims, n_emitters, n_bvh_nodes, use_bvh, n_bsdfs, tables_in_lds;
     // sensor + film
     float cam[12]; // camera-to-world rows (3x4)
     float tan_half_fov, inv_aspect, near_clip, far_clip;
     int32_t width, height;
-    float filter_radius, filter_scale;
+    float filter_radius, filter_scale, box_weight; // box_weight: the (constant) table value of the box filter
     float *film;
     // configuration
     int32_t type, max_depth, rr_depth, exclude_direct;

@@ -138,7 +138,7 @@ std::string build_scene(drmlt_ctx *ctx, const drmlt_scene &s, std::vector<DBsdf>
         DPrim g{};
         DShade sh{};
         PrimBounds pb;
-        sh.bsdf = in.bsdf;
+        sh.bsdf = in.bsdf; // | kind << 24, set below
         sh.emitter = in.emitter < 0 ? -1 : in.emitter;
         double m[12], inv[12];
         if (in.type == DRMLT_SHAPE_TRIANGLE) {
@@ -192,6 +192,7 @@ std::string build_scene(drmlt_ctx *ctx, const drmlt_scene &s, std::vector<DBsdf>
             return "unknown shape type " + std::to_string(in.type);
         }
         for (int k = 0; k < 12; ++k) g.m[k] = (float) inv[k];
+        sh.bsdf |= g.type << 24;
         ctx->prims.push_back(g);
         ctx->shade.push_back(sh);
         bounds.push_back(pb);
@@ -354,6 +355,11 @@ drmlt_ctx *drmlt_create(const drmlt_config *cfg, const drmlt_scene *scene, int d
     P.prims = ctx->d_prims.as<DPrim>(); P.shade = ctx->d_shade.as<DShade>(); P.bsdfs = ctx->d_bsdfs.as<DBsdf>();
     P.emitters = ctx->d_emitters.as<DEmitter>(); P.bvh = ctx->d_bvh.as<DBvhNode>(); P.filter_lut = ctx->d_lut.as<float>();
     P.n_prims = (int) ctx->prims.size(); P.n_emitters = (int) emitters.size(); P.n_bvh_nodes = (int) nodes.size();
+    P.n_bsdfs = (int) bsdfs.size();
+    // tables ride in LDS when they are small (Cornell class); 16 KB cap keeps 4+ waves per CU
+    P.tables_in_lds = (ctx->prims.size() * 64 + bsdfs.size() * 48 + emitters.size() * 32 <= 16384) ? 1 : 0;
+    if (const char *t = getenv("DRMLT_TABLES_LDS")) P.tables_in_lds = atoi(t) ? P.tables_in_lds : 0;
+    P.box_weight = cam.filter == DRMLT_FILTER_BOX ? lut[0] : 0.f;
     for (int r = 0; r < 3; ++r) for (int c = 0; c < 4; ++c) P.cam[r * 4 + c] = cam.to_world[r * 4 + c];
     P.tan_half_fov = (float) std::tan(0.5 * (double) cam.fov_x_deg * M_PI / 180.0);
     P.inv_aspect = (float) cam.height / (float) cam.width;
@@ -574,9 +580,13 @@ int drmlt_develop(drmlt_ctx *ctx, const float *direct_rgb_or_null, float *out_rg
 int drmlt_stats_get(drmlt_ctx *ctx, drmlt_stats *o) {
     if (!ctx || !o) return DRMLT_E_INVALID;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    unsigned long long v[9];
+    unsigned long long v[32];
     HIP_TRY(ctx, hipMemcpyAsync(v, ctx->d_stats.p, sizeof v, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->P.debug & 128) // diagnostic stamps of k_mutate_v2
+        fprintf(stderr, "[drmlt stamps] cycles: mh %llu trace %llu step %llu | iterations %llu mh-branches %llu tracing-lanes %llu\n",
+                v[16], v[17], v[18], v[19], v[20], v[21]),
+        fprintf(stderr, "[drmlt stamps] mh sections (lane 0 view): digest %llu splat %llu commit %llu start %llu\n", v[22], v[23], v[24], v[25]);
     memset(o, 0, sizeof *o);
     const uint64_t M = ctx->mutations;
     const uint64_t n_large = v[0], acc1_l = v[1], acc1_b = v[2], sec_l = v[3], sec_b = v[4], acc2_l = v[5], acc2_b = v[6], n_rev = v[7];

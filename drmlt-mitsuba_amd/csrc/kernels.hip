@@ -19,10 +19,13 @@ DEV void film_put(const DParams &P, float px, float py, f3 v) {
     float posx = px - 0.5f, posy = py - 0.5f;
     int minx = max((int) ceilf(posx - P.filter_radius), 0), miny = max((int) ceilf(posy - P.filter_radius), 0);
     int maxx = min((int) floorf(posx + P.filter_radius), P.width - 1), maxy = min((int) floorf(posy + P.filter_radius), P.height - 1);
+    const bool box = P.box_weight > 0.f; // box table = one constant in entries 0..30 and 0 in entry 31
     for (int y = miny; y <= maxy; ++y) {
-        float wy = P.filter_lut[min((int) fabsf(((float) y - posy) * P.filter_scale), 31)];
+        const int iy = min((int) fabsf(((float) y - posy) * P.filter_scale), 31);
+        float wy = box ? (iy < 31 ? P.box_weight : 0.f) : P.filter_lut[iy];
         for (int x = minx; x <= maxx; ++x) {
-            float w = P.filter_lut[min((int) fabsf(((float) x - posx) * P.filter_scale), 31)] * wy;
+            const int ix = min((int) fabsf(((float) x - posx) * P.filter_scale), 31);
+            float w = (box ? (ix < 31 ? P.box_weight : 0.f) : P.filter_lut[ix]) * wy;
             float *dst = P.film + ((size_t) y * P.width + x) * 3;
             atomicAdd(dst + 0, w * v.x);
             atomicAdd(dst + 1, w * v.y);
@@ -271,8 +274,11 @@ DEV void start_path(const DParams &P, LdsSampler &smp, PathState &ps, int stage)
 // Digest a finished path evaluation of this lane: advance the mutation's stage machine, finish
 // the mutation (splats, counters, commit) when decided, and start the next evaluation.
 // Returns false when the lane has completed all its mutations.
+struct MhStamps { unsigned long long digest, splat, commit, start; };
+#define MSTAMP() (stamps ? __builtin_amdgcn_s_memtime() : 0ull)
 DEV bool mh_advance(const DParams &P, ChainState &cs, LdsSampler &smp, PathState &ps, Counters &ct, uint32_t n_mut,
-                    uint32_t mut_base, uint32_t lane) {
+                    uint32_t mut_base, uint32_t lane, MhStamps &ms, bool stamps) {
+    const unsigned long long m0 = MSTAMP();
     const bool mix = P.use_mixture != 0;
     const bool amap = P.acceptance_map != 0;
     const int D = P.eff_dim;
@@ -344,6 +350,8 @@ DEV bool mh_advance(const DParams &P, ChainState &cs, LdsSampler &smp, PathState
             decided = true;
         }
     }
+    const unsigned long long m1 = MSTAMP();
+    ms.digest += m1 - m0;
     if (decided) {
         const DSplat &cur = cs.cur, &y = cs.y, &z = cs.z;
         if (!mix) {
@@ -368,9 +376,11 @@ DEV bool mh_advance(const DParams &P, ChainState &cs, LdsSampler &smp, PathState
             if (cs.do_second) ct.secb_acc2l += 1u;
             if (acc2) ct.acc2b_rev += 1u;
         }
+        const unsigned long long m2 = MSTAMP();
+        ms.splat += m2 - m1;
         if (acc1 || acc2) {
             smp.mode = acc1 ? SM_STAGE1 : SM_STAGE2;
-            for (int k = 0; k < D; ++k) lds_x[k * 64 + lane] = smp.next((uint32_t) k);
+            for (int k = 0; k < D; ++k) lds_x[(uint32_t) k * smp.stride + lane] = smp.next((uint32_t) k);
             cs.cur = acc1 ? cs.y : cs.z;
             if (amap && !mix) {
                 if (acc1) { if (!cs.large) film_put(P, cs.cur.px, cs.cur.py, mk3(1.f, 0.f, 0.f)); }
@@ -379,7 +389,9 @@ DEV bool mh_advance(const DParams &P, ChainState &cs, LdsSampler &smp, PathState
         }
         cs.it++;
         cs.stage = -1;
+        ms.commit += MSTAMP() - m2;
     }
+    const unsigned long long m3 = MSTAMP();
     // start the next mutation
     if (cs.it >= n_mut) { ps.phase = PH_IDLE; return false; }
     const uint32_t m = mut_base + cs.it;
@@ -392,16 +404,20 @@ DEV bool mh_advance(const DParams &P, ChainState &cs, LdsSampler &smp, PathState
     cs.do_second = false;
     cs.nd1 = cs.nd2 = 0u;
     start_path(P, smp, ps, 0);
+    ms.start += MSTAMP() - m3;
     return true;
 }
+#undef MSTAMP
 
 __global__ void __launch_bounds__(CHAIN_BLOCK) k_mutate_v2(DParams P, uint32_t n_mut, uint32_t mut_base) {
     const uint32_t lane = threadIdx.x;
-    const uint32_t c = blockIdx.x * CHAIN_BLOCK + lane;
-    const bool live = c < P.n_chains;
+    // experiment (DRMLT_DEBUG bit 512): 32 chains per wave in lanes 0..31, twice the waves
+    const uint32_t per_wave = (P.debug & 512) ? 32u : 64u;
+    const uint32_t c = blockIdx.x * per_wave + lane;
+    const bool live = lane < per_wave && c < P.n_chains;
     const uint32_t cc = live ? c : P.n_chains - 1;
     const int D = P.eff_dim;
-    for (int k = 0; k < D; ++k) lds_x[k * 64 + lane] = P.x[(size_t) k * P.n_chains + cc];
+    for (int k = 0; k < D; ++k) lds_x[(uint32_t) k * per_wave + lane] = P.x[(size_t) k * P.n_chains + cc];
 
     ChainState cs;
     cs.cur.lum = P.cur_lum[cc]; cs.cur.px = P.cur_px[cc]; cs.cur.py = P.cur_py[cc];
@@ -414,29 +430,61 @@ __global__ void __launch_bounds__(CHAIN_BLOCK) k_mutate_v2(DParams P, uint32_t n
     smp.key0 = P.key0; smp.key1 = P.key1; smp.chain = P.chain_offset + cc; smp.major = 0u;
     smp.mode = SM_STAGE1; smp.type = P.type; smp.large = false; smp.sigma2 = P.sigma2; smp.lane = lane;
     const uint32_t D4 = ((uint32_t) D + 3u) & ~3u;
-    smp.u1_off = (uint32_t) D * 64u;
-    smp.s2_off = smp.u1_off + D4 * 64u;
+    smp.stride = per_wave;
+    smp.u1_off = (uint32_t) D * per_wave;
+    smp.s2_off = smp.u1_off + D4 * per_wave;
+    smp.timing_probe = (P.debug & 256) != 0;
     Counters ct = {0u, 0u, 0u, 0u, 0u};
     PathState ps;
     path_init(P, ps);
     ps.phase = (live && n_mut > 0u) ? PH_DONE : PH_IDLE; // PH_DONE with stage -1: "start the first mutation"
     Hit h{-1, 0.f, 0.f, 0.f};
     const int batch = P.mh_batch;
+    // scene tables: staged in LDS behind the sampler rows when they are small
+    LdsTables LT;
+    LT.shade_off = smp.s2_off + D4 * per_wave;
+    LT.bsdf_off = LT.shade_off + (uint32_t) P.n_prims * 16u;
+    LT.emit_off = LT.bsdf_off + (uint32_t) P.n_bsdfs * 12u;
+    const GlobalTables GT{P.shade, P.bsdfs, P.emitters};
+    const bool lds_tables = P.tables_in_lds != 0;
+    if (lds_tables) stage_tables(P, LT, lane);
 
+    // diagnostic stamps (DRMLT_DEBUG bit 128): per-wave cycle shares of the three loop sections
+    const bool stamps = (P.debug & 128) != 0;
+    unsigned long long t_mh = 0, t_trace = 0, t_step = 0, n_iter = 0, n_mh = 0, n_busy = 0;
+    MhStamps ms = {0, 0, 0, 0};
+#define STAMP() (stamps ? __builtin_amdgcn_s_memtime() : 0ull)
     for (;;) {
         const bool parked = ps.phase == PH_DONE;
         const unsigned long long pmask = __ballot(parked);
         const unsigned long long rmask = __ballot(ps.phase != PH_DONE && ps.phase != PH_IDLE);
         if (!pmask && !rmask) break;
+        const unsigned long long s0 = STAMP();
         if (pmask && (__popcll(pmask) >= batch || !rmask)) {
-            if (parked) mh_advance(P, cs, smp, ps, ct, n_mut, mut_base, lane);
+            if (parked) mh_advance(P, cs, smp, ps, ct, n_mut, mut_base, lane, ms, stamps);
+            n_mh++;
         }
-        if (ps.phase == PH_CLOSEST || ps.phase == PH_SHADOW) h = trace(P, ps.o, ps.d, ps.tmin, ps.tmax, ps.phase == PH_SHADOW);
-        if (ps.phase != PH_DONE && ps.phase != PH_IDLE) path_step(P, ps, smp, h);
+        const unsigned long long s1 = STAMP();
+        const bool tracing = ps.phase == PH_CLOSEST || ps.phase == PH_SHADOW;
+        if (stamps) n_busy += __popcll(__ballot(tracing));
+        if (tracing) h = trace(P, ps.o, ps.d, ps.tmin, ps.tmax, ps.phase == PH_SHADOW);
+        const unsigned long long s2 = STAMP();
+        if (ps.phase != PH_DONE && ps.phase != PH_IDLE) {
+            if (lds_tables) path_step(P, LT, ps, smp, h);
+            else path_step(P, GT, ps, smp, h);
+        }
+        const unsigned long long s3 = STAMP();
+        t_mh += s1 - s0; t_trace += s2 - s1; t_step += s3 - s2; n_iter++;
+    }
+#undef STAMP
+    if (stamps && lane == 0) {
+        atomicAdd(P.stats + 16, t_mh); atomicAdd(P.stats + 17, t_trace); atomicAdd(P.stats + 18, t_step);
+        atomicAdd(P.stats + 19, n_iter); atomicAdd(P.stats + 20, n_mh); atomicAdd(P.stats + 21, n_busy);
+        atomicAdd(P.stats + 22, ms.digest); atomicAdd(P.stats + 23, ms.splat); atomicAdd(P.stats + 24, ms.commit); atomicAdd(P.stats + 25, ms.start);
     }
 
     if (live) {
-        for (int k = 0; k < D; ++k) P.x[(size_t) k * P.n_chains + c] = lds_x[k * 64 + lane];
+        for (int k = 0; k < D; ++k) P.x[(size_t) k * P.n_chains + c] = lds_x[(uint32_t) k * per_wave + lane];
         P.cur_lum[c] = cs.cur.lum; P.cur_px[c] = cs.cur.px; P.cur_py[c] = cs.cur.py;
         P.cur_r[c] = cs.cur.r; P.cur_g[c] = cs.cur.g; P.cur_b[c] = cs.cur.b;
     }
@@ -510,7 +558,10 @@ void launch_mutate(const DParams &P, uint32_t n_mut, uint32_t mut_base, hipStrea
     if (P.kernel_variant == 1) {
         hipLaunchKernelGGL(k_mutate, grid, block, D * 64 * sizeof(float), st, P, n_mut, mut_base);
     } else { // x + first-stage uniforms + second-stage values, one 256 B row per dimension
-        hipLaunchKernelGGL(k_mutate_v2, grid, block, (D + 2 * D4) * 64 * sizeof(float), st, P, n_mut, mut_base);
+        size_t lds = (D + 2 * D4) * 64 * sizeof(float);
+        if (P.debug & 512) { grid = dim3((P.n_chains + 31) / 32); lds /= 2; }
+        if (P.tables_in_lds) lds += (size_t) P.n_prims * 64 + (size_t) P.n_bsdfs * 48 + (size_t) P.n_emitters * 32;
+        hipLaunchKernelGGL(k_mutate_v2, grid, block, lds, st, P, n_mut, mut_base);
     }
 }
 void launch_eval_paths(const DParams &P, const float *u, uint32_t n, uint32_t dim, float *out8, hipStream_t st) {
