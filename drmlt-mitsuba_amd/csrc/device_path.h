@@ -176,26 +176,26 @@ struct LdsSampler {
     DEV float u1(uint32_t k) const { return lds_x[u1_off + k * stride + lane]; }
     DEV float s2(uint32_t k) const { return lds_x[s2_off + k * stride + lane]; }
 
-    // all first-stage draws of this mutation: rows [0, D4) of lds_u1
-    DEV void fill_stage1(uint32_t D4) {
-        for (uint32_t b = 0; b < D4 / 4u; ++b) {
+    // first-stage draws of this mutation, Philox blocks [b0, b1): rows 4b .. 4b+3 of lds_u1
+    DEV void fill_stage1(uint32_t b0, uint32_t b1) {
+        for (uint32_t b = b0; b < b1; ++b) {
             u4 r = timing_probe ? u4{b * 2654435761u ^ major, chain * 40503u + b, major * 2246822519u, b + chain}
                                 : philox4x32_10(key0, key1, b, major, chain, TAG_S1);
             float *dst = &lds_x[u1_off + b * 4u * stride + lane];
             dst[0] = u32_to_unit(r.x); dst[stride] = u32_to_unit(r.y); dst[2u * stride] = u32_to_unit(r.z); dst[3u * stride] = u32_to_unit(r.w);
         }
     }
-    // second-stage values (see layout above)
-    DEV void fill_stage2(uint32_t D4) {
+    // second-stage values (see layout above); blocks first, first + step, ... (step 2 = shared by two lanes)
+    DEV void fill_stage2(uint32_t D4, uint32_t first, uint32_t step) {
         if (large || type == 2) {
             const uint32_t rows = large ? D4 : (D4 / 2u + 3u) & ~3u; // uniforms: one per dim, or one per pair
-            for (uint32_t b = 0; b < rows / 4u; ++b) {
+            for (uint32_t b = first; b < rows / 4u; b += step) {
                 u4 r = philox4x32_10(key0, key1, b, major, chain, TAG_S2);
                 float *dst = &lds_x[s2_off + b * 4u * stride + lane];
                 dst[0] = u32_to_unit(r.x); dst[stride] = u32_to_unit(r.y); dst[2u * stride] = u32_to_unit(r.z); dst[3u * stride] = u32_to_unit(r.w);
             }
         } else {
-            for (uint32_t b = 0; b < D4 / 2u; ++b) { // draws (2k, 2k+1) -> Gaussian sample of dim k
+            for (uint32_t b = first; b < D4 / 2u; b += step) { // draws (2k, 2k+1) -> Gaussian sample of dim k
                 u4 r = philox4x32_10(key0, key1, b, major, chain, TAG_S2);
                 float *dst = &lds_x[s2_off + b * 2u * stride + lane];
                 dst[0] = gaussian_sample(u32_to_unit(r.x), u32_to_unit(r.y), sigma2);
@@ -435,7 +435,7 @@ DEV void stage_tables(const DParams &P, const LdsTables &T, uint32_t lane) {
 // All PSS components a step needs are drawn at ONE site (the `next` loop below): the sampler
 // code (Philox + transition kernels) is the bulk of the instruction footprint, so it is
 // instantiated once per kernel instead of once per consumer.
-enum { PH_DONE = 0, PH_BEGIN = 1, PH_CLOSEST = 2, PH_SHADOW = 3, PH_IDLE = 4 };
+enum { PH_DONE = 0, PH_BEGIN = 1, PH_CLOSEST = 2, PH_SHADOW = 3, PH_IDLE = 4, PH_FLUSH = 5 };
 
 struct PathState {
     f3 o, d;          // ray to trace next (o doubles as the current surface point)
@@ -451,6 +451,14 @@ struct PathState {
     uint32_t k;       // next PSS dimension
     uint32_t nrays;
     bool non_specular, direct_on, has_bounce, bdelta, refn_zero;
+    bool shadow_pending; // dual-lane mode: ps.nee waits for the partner lane's occlusion result
+};
+
+// shadow ray handed to the partner lane (dual-lane mode)
+struct ShadowRay {
+    f3 o, d;
+    float tmin, tmax;
+    bool valid;
 };
 
 DEV float ray_eps_closest(f3 o) { // skdtree.cpp:125-129
@@ -498,22 +506,37 @@ DEV void path_init(const DParams &P, PathState &ps) {
     ps.direct_on = P.exclude_direct == 0; // pathsampler.cpp:558-561
     ps.has_bounce = false;
     ps.refn_zero = false;
+    ps.shadow_pending = false;
     ps.px = ps.py = 0.f;
 }
 
 // Consume the result of the ray query issued for `ps` (none in PH_BEGIN) and either issue the
 // next ray (PH_CLOSEST / PH_SHADOW) or finish the path (PH_DONE, radiance in ps.Li).
-template <class SamplerT, class TablesT>
-DEV void path_step(const DParams &P, const TablesT &T, PathState &ps, SamplerT &smp, const Hit &hit) {
+// DUAL = false: one lane per chain, shadow rays take a step of their own (PH_SHADOW).
+// DUAL = true : two lanes per chain. This lane traces the camera/bounce rays, its partner traces
+//   the shadow ray of the SAME vertex concurrently; `shadow_clear` is the partner's result for the
+//   ray handed over in the previous step (`sr`), so a bounce costs one step instead of two. The
+//   order of the radiance additions is the same in both modes (NEE of vertex i, then MIS of i+1).
+template <bool DUAL, class SamplerT, class TablesT>
+DEV void path_step(const DParams &P, const TablesT &T, PathState &ps, SamplerT &smp, const Hit &hit, bool shadow_clear,
+                   ShadowRay &sr) {
     // ---------------- part 1: digest the ray query, decide which PSS components are needed
     bool want_rr = false, want_nee = false;
     int need = 0;
     float rr_q = 1.f;
     f3 p = ps.o, n = ps.n, s = ps.s;
     DBsdf B;
+    if (DUAL) {
+        sr.valid = false;
+        if (ps.shadow_pending) {
+            if (shadow_clear) ps.Li = ps.Li + ps.nee;
+            ps.shadow_pending = false;
+        }
+        if (ps.phase == PH_FLUSH) { ps.phase = PH_DONE; return; }
+    }
     if (ps.phase == PH_BEGIN) {
         need = 2; // film position, pathsampler.cpp:538-543
-    } else if (ps.phase == PH_SHADOW) {
+    } else if (!DUAL && ps.phase == PH_SHADOW) {
         if (hit.prim < 0) ps.Li = ps.Li + ps.nee; // unoccluded
         B = T.bsdf(ps.bsdf);
     } else {
@@ -647,12 +670,20 @@ DEV void path_step(const DParams &P, const TablesT &T, PathState &ps, SamplerT &
                     f3 c = ps.thr * value * bsdfVal * (a / (a + b));
                     if (!is_zero3(c)) {
                         ps.nee = c;
-                        ps.d = dd;
-                        ps.tmin = ray_eps_shadow(p);
-                        ps.tmax = dist * (1.f - SHADOW_EPSILON_F);
-                        ps.phase = PH_SHADOW;
                         ps.nrays++;
-                        return;
+                        if (DUAL) { // partner lane traces it while this lane traces the bounce ray
+                            sr.o = p; sr.d = dd;
+                            sr.tmin = ray_eps_shadow(p);
+                            sr.tmax = dist * (1.f - SHADOW_EPSILON_F);
+                            sr.valid = true;
+                            ps.shadow_pending = true;
+                        } else {
+                            ps.d = dd;
+                            ps.tmin = ray_eps_shadow(p);
+                            ps.tmax = dist * (1.f - SHADOW_EPSILON_F);
+                            ps.phase = PH_SHADOW;
+                            return;
+                        }
                     }
                 }
             }
@@ -662,7 +693,7 @@ DEV void path_step(const DParams &P, const TablesT &T, PathState &ps, SamplerT &
     ps.k += 2u;
     f3 wo;
     if (B.type == 0) { // diffuse.cpp:139-149
-        if (!(ps.wi.z > 0.f)) { ps.phase = PH_DONE; return; }
+        if (!(ps.wi.z > 0.f)) { ps.phase = (DUAL && ps.shadow_pending) ? PH_FLUSH : PH_DONE; return; }
         wo = square_to_cosine_hemisphere(ps.bx, ps.by);
         ps.bpdf = INV_PI_F * wo.z;
         ps.bweight = ld3(B.rgb);
@@ -687,10 +718,10 @@ DEV void path_step(const DParams &P, const TablesT &T, PathState &ps, SamplerT &
             ps.bweight = mk3(factor * factor, factor * factor, factor * factor);
         }
     } else {
-        ps.phase = PH_DONE;
+        ps.phase = (DUAL && ps.shadow_pending) ? PH_FLUSH : PH_DONE;
         return;
     }
-    if (is_zero3(ps.bweight)) { ps.phase = PH_DONE; return; }
+    if (is_zero3(ps.bweight)) { ps.phase = (DUAL && ps.shadow_pending) ? PH_FLUSH : PH_DONE; return; }
     ps.non_specular = ps.non_specular || !ps.bdelta;
     f3 t = cross3(ps.n, ps.s);
     ps.d = fma3(ps.s, wo.x, fma3(t, wo.y, ps.n * wo.z));
@@ -708,9 +739,10 @@ DEV DSplat eval_path(const DParams &P, Sampler &smp, uint32_t &nrays, uint32_t &
     path_init(P, ps);
     Hit h{-1, 0.f, 0.f, 0.f};
     const GlobalTables T{P.shade, P.bsdfs, P.emitters};
+    ShadowRay sr_unused;
     for (;;) {
         if (ps.phase != PH_BEGIN) h = trace(P, ps.o, ps.d, ps.tmin, ps.tmax, ps.phase == PH_SHADOW);
-        path_step(P, T, ps, smp, h);
+        path_step<false>(P, T, ps, smp, h, false, sr_unused);
         if (ps.phase == PH_DONE) break;
     }
     DSplat out;

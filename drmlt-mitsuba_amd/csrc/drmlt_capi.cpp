@@ -391,8 +391,8 @@ drmlt_ctx *drmlt_create(const drmlt_config *cfg, const drmlt_scene *scene, int d
     P.error_flag = ctx->d_err.as<int32_t>();
     P.debug = 0;
     if (const char *d = getenv("DRMLT_DEBUG")) P.debug = atoi(d);
-    P.kernel_variant = 2;
-    if (const char *k = getenv("DRMLT_KERNEL")) P.kernel_variant = atoi(k) == 1 ? 1 : 2;
+    P.kernel_variant = 3;
+    if (const char *k = getenv("DRMLT_KERNEL")) { int kv = atoi(k); P.kernel_variant = (kv >= 1 && kv <= 3) ? kv : 2; }
     P.mh_batch = 32;
     if (const char *k = getenv("DRMLT_MH_BATCH")) P.mh_batch = std::max(1, std::min(64, atoi(k)));
     if (hipDeviceSynchronize() != hipSuccess) return bail(ctx, "device synchronisation failed after setup");

@@ -263,151 +263,168 @@ struct ChainState {
     bool large, do_second;
 };
 
-DEV void start_path(const DParams &P, LdsSampler &smp, PathState &ps, int stage) {
-    smp.mode = stage == 0 ? SM_STAGE1 : (stage == 1 ? SM_STAGE2 : SM_REVERSE);
-    const uint32_t D4 = ((uint32_t) P.eff_dim + 3u) & ~3u;
-    if (stage == 0) smp.fill_stage1(D4);       // every draw this mutation's proposals can use,
-    else if (stage == 1) smp.fill_stage2(D4);  // produced by all lanes that start an evaluation now
-    path_init(P, ps);
-}
-
-// Digest a finished path evaluation of this lane: advance the mutation's stage machine, finish
-// the mutation (splats, counters, commit) when decided, and start the next evaluation.
-// Returns false when the lane has completed all its mutations.
 struct MhStamps { unsigned long long digest, splat, commit, start; };
-#define MSTAMP() (stamps ? __builtin_amdgcn_s_memtime() : 0ull)
-DEV bool mh_advance(const DParams &P, ChainState &cs, LdsSampler &smp, PathState &ps, Counters &ct, uint32_t n_mut,
-                    uint32_t mut_base, uint32_t lane, MhStamps &ms, bool stamps) {
-    const unsigned long long m0 = MSTAMP();
+
+// The bookkeeping branch in four pieces so that k_mutate_v3 can share the two heavy ones
+// (committing D_eff dimensions, drawing the next mutation's uniforms) between a chain lane and
+// its helper lane:
+//   mh_decide  digest the finished evaluation; if the mutation is decided: splats + counters,
+//              returns the commit mode (0 none, SM_STAGE1 = adopt y, SM_STAGE2 = adopt z)
+//   commit     x[k] = wrap(proposal[k]) for a range of dimensions           (shareable)
+//   mh_start   advance to the next evaluation (next stage or next mutation); returns which
+//              uniforms must be drawn (0 none, 1 first stage, 2 second stage)
+//   fill       Philox draws into LDS for a range of blocks                    (shareable)
+DEV int mh_decide(const DParams &P, ChainState &cs, LdsSampler &smp, PathState &ps, Counters &ct) {
     const bool mix = P.use_mixture != 0;
     const bool amap = P.acceptance_map != 0;
-    const int D = P.eff_dim;
+    if (cs.stage < 0) return 0; // nothing evaluated yet (first call of a launch)
     bool decided = false;
     float a2 = 0.f;
     bool acc1 = false, acc2 = false;
-    if (cs.stage >= 0) {
-        DSplat res;
-        res.px = ps.px; res.py = ps.py; res.r = ps.Li.x; res.g = ps.Li.y; res.b = ps.Li.z;
-        res.lum = luminance3(ps.Li);
-        normalize_splat(res);
-        ct.rays += ps.nrays;
-        if (cs.stage == 0) {
-            cs.y = res; cs.nd1 = ps.k;
+    DSplat res;
+    res.px = ps.px; res.py = ps.py; res.r = ps.Li.x; res.g = ps.Li.y; res.b = ps.Li.z;
+    res.lum = luminance3(ps.Li);
+    normalize_splat(res);
+    ct.rays += ps.nrays;
+    if (cs.stage == 0) {
+        cs.y = res; cs.nd1 = ps.k;
+        cs.a1 = 0.f;
+        if (!(mix ? lum_invalid_mix(res.lum) : lum_invalid(res.lum))) cs.a1 = fminf(1.f, res.lum / cs.cur.lum);
+        acc1 = cs.a1 >= 1.f || (cs.a1 > 0.f && cs.coin_acc1 < cs.a1);
+        if (!mix) cs.do_second = !acc1 && (P.timid_after_large || !cs.large);
+        else cs.do_second = !cs.large && cs.coin_mix < 0.5f;
+        if (cs.do_second) { cs.stage = 1; return 0; }
+        decided = true;
+    } else if (cs.stage == 1) {
+        cs.z = res; cs.nd2 = ps.k;
+        acc1 = false;
+        if (mix) {
             cs.a1 = 0.f;
-            if (!(mix ? lum_invalid_mix(res.lum) : lum_invalid(res.lum))) cs.a1 = fminf(1.f, res.lum / cs.cur.lum);
-            acc1 = cs.a1 >= 1.f || (cs.a1 > 0.f && cs.coin_acc1 < cs.a1);
-            if (!mix) cs.do_second = !acc1 && (P.timid_after_large || !cs.large);
-            else cs.do_second = !cs.large && cs.coin_mix < 0.5f;
-            if (cs.do_second) { cs.stage = 1; start_path(P, smp, ps, 1); return true; }
-            decided = true;
-        } else if (cs.stage == 1) {
-            cs.z = res; cs.nd2 = ps.k;
-            acc1 = false;
-            if (mix) {
-                cs.a1 = 0.f;
-                if (!lum_invalid_mix(res.lum)) {
-                    a2 = fminf(1.f, res.lum / cs.cur.lum);
-                    acc2 = a2 >= 1.f || cs.coin_acc2 < a2;
-                }
-            } else if (!lum_invalid(res.lum)) {
-                if (P.type == 0) { cs.stage = 2; start_path(P, smp, ps, 2); return true; }
-                if (P.type == 1) {
-                    float aRev = fminf(1.f, cs.y.lum / res.lum);
-                    if (!(aRev >= 1.f)) {
-                        float ratio = 1.f;
-                        if (!cs.large) {
-                            uint32_t dimStage = max(cs.nd1, cs.nd2) - 1u;
-                            float num = 0.f, den = 0.f;
-                            for (uint32_t i = 0; i < dimStage; ++i) {
-                                float yi = smp.y_raw(i);
-                                num += kelemen_logpdf(smp.z_raw(i) - yi);
-                                den += kelemen_logpdf(smp.x(i) - yi);
-                            }
-                            ratio = __expf(num - den);
+            if (!lum_invalid_mix(res.lum)) {
+                a2 = fminf(1.f, res.lum / cs.cur.lum);
+                acc2 = a2 >= 1.f || cs.coin_acc2 < a2;
+            }
+        } else if (!lum_invalid(res.lum)) {
+            if (P.type == 0) { cs.stage = 2; return 0; } // Green: evaluate the reverse move first
+            if (P.type == 1) {
+                float aRev = fminf(1.f, cs.y.lum / res.lum);
+                if (!(aRev >= 1.f)) {
+                    float ratio = 1.f;
+                    if (!cs.large) {
+                        uint32_t dimStage = max(cs.nd1, cs.nd2) - 1u;
+                        float num = 0.f, den = 0.f;
+                        for (uint32_t i = 0; i < dimStage; ++i) {
+                            float yi = smp.y_raw(i);
+                            num += kelemen_logpdf(smp.z_raw(i) - yi);
+                            den += kelemen_logpdf(smp.x(i) - yi);
                         }
-                        if (!lum_invalid(ratio)) {
-                            a2 = fminf(1.f, (res.lum / cs.cur.lum) * ratio * (1.f - aRev) / (1.f - cs.a1));
-                            acc2 = a2 >= 1.f || cs.coin_acc2 < a2;
-                        }
+                        ratio = __expf(num - den);
                     }
-                } else {
-                    if (res.lum < cs.y.lum) { a2 = 0.f; }
-                    else if (res.lum >= cs.cur.lum) { a2 = 1.f; acc2 = true; }
-                    else {
-                        a2 = (res.lum - cs.y.lum) / (cs.cur.lum - cs.y.lum);
+                    if (!lum_invalid(ratio)) {
+                        a2 = fminf(1.f, (res.lum / cs.cur.lum) * ratio * (1.f - aRev) / (1.f - cs.a1));
                         acc2 = a2 >= 1.f || cs.coin_acc2 < a2;
                     }
                 }
+            } else {
+                if (res.lum < cs.y.lum) { a2 = 0.f; }
+                else if (res.lum >= cs.cur.lum) { a2 = 1.f; acc2 = true; }
+                else {
+                    a2 = (res.lum - cs.y.lum) / (cs.cur.lum - cs.y.lum);
+                    acc2 = a2 >= 1.f || cs.coin_acc2 < a2;
+                }
             }
-            decided = true;
-        } else {
-            ct.acc2b_rev += 1u << 16;
-            float aRev = lum_invalid(res.lum) ? 0.f : fminf(1.f, res.lum / cs.z.lum);
-            if (aRev != 1.f) {
-                a2 = fminf(1.f, (cs.z.lum / cs.cur.lum) * (1.f - aRev) / (1.f - cs.a1));
-                acc2 = a2 >= 1.f || cs.coin_acc2 < a2;
-            }
-            decided = true;
+        }
+        decided = true;
+    } else {
+        ct.acc2b_rev += 1u << 16;
+        float aRev = lum_invalid(res.lum) ? 0.f : fminf(1.f, res.lum / cs.z.lum);
+        if (aRev != 1.f) {
+            a2 = fminf(1.f, (cs.z.lum / cs.cur.lum) * (1.f - aRev) / (1.f - cs.a1));
+            acc2 = a2 >= 1.f || cs.coin_acc2 < a2;
+        }
+        decided = true;
+    }
+    if (!decided) return 0;
+    const DSplat &cur = cs.cur, &y = cs.y, &z = cs.z;
+    if (!mix) {
+        float w1 = cs.a1, w2 = (1.f - cs.a1) * a2, w0 = 1.f - w1 - w2;
+        if (!amap) {
+            if (w0 > 0.f) film_put(P, cur.px, cur.py, mk3(cur.r * w0, cur.g * w0, cur.b * w0));
+            if (w1 > 0.f) film_put(P, y.px, y.py, mk3(y.r * w1, y.g * w1, y.b * w1));
+            if (cs.do_second && w2 > 0.f) film_put(P, z.px, z.py, mk3(z.r * w2, z.g * w2, z.b * w2));
+        }
+    } else {
+        const float a = cs.do_second ? a2 : cs.a1;
+        const DSplat &pr = cs.do_second ? z : y;
+        if (1.f - a > 0.f) film_put(P, cur.px, cur.py, mk3(cur.r * (1.f - a), cur.g * (1.f - a), cur.b * (1.f - a)));
+        if (a > 0.f) film_put(P, pr.px, pr.py, mk3(pr.r * a, pr.g * a, pr.b * a));
+    }
+    if (cs.large) {
+        ct.large_acc1l += 1u + (acc1 ? 1u << 16 : 0u);
+        if (cs.do_second) ct.acc1b_secl += 1u << 16;
+        if (acc2) ct.secb_acc2l += 1u << 16;
+    } else {
+        if (acc1) ct.acc1b_secl += 1u;
+        if (cs.do_second) ct.secb_acc2l += 1u;
+        if (acc2) ct.acc2b_rev += 1u;
+    }
+    int commit = 0;
+    if (acc1 || acc2) {
+        commit = acc1 ? SM_STAGE1 : SM_STAGE2;
+        cs.cur = acc1 ? cs.y : cs.z;
+        if (amap && !mix) {
+            if (acc1) { if (!cs.large) film_put(P, cs.cur.px, cs.cur.py, mk3(1.f, 0.f, 0.f)); }
+            else film_put(P, cs.cur.px, cs.cur.py, mk3(0.f, 1.f, 0.f));
         }
     }
-    const unsigned long long m1 = MSTAMP();
-    ms.digest += m1 - m0;
-    if (decided) {
-        const DSplat &cur = cs.cur, &y = cs.y, &z = cs.z;
-        if (!mix) {
-            float w1 = cs.a1, w2 = (1.f - cs.a1) * a2, w0 = 1.f - w1 - w2;
-            if (!amap) {
-                if (w0 > 0.f) film_put(P, cur.px, cur.py, mk3(cur.r * w0, cur.g * w0, cur.b * w0));
-                if (w1 > 0.f) film_put(P, y.px, y.py, mk3(y.r * w1, y.g * w1, y.b * w1));
-                if (cs.do_second && w2 > 0.f) film_put(P, z.px, z.py, mk3(z.r * w2, z.g * w2, z.b * w2));
-            }
-        } else {
-            const float a = cs.do_second ? a2 : cs.a1;
-            const DSplat &pr = cs.do_second ? z : y;
-            if (1.f - a > 0.f) film_put(P, cur.px, cur.py, mk3(cur.r * (1.f - a), cur.g * (1.f - a), cur.b * (1.f - a)));
-            if (a > 0.f) film_put(P, pr.px, pr.py, mk3(pr.r * a, pr.g * a, pr.b * a));
-        }
-        if (cs.large) {
-            ct.large_acc1l += 1u + (acc1 ? 1u << 16 : 0u);
-            if (cs.do_second) ct.acc1b_secl += 1u << 16;
-            if (acc2) ct.secb_acc2l += 1u << 16;
-        } else {
-            if (acc1) ct.acc1b_secl += 1u;
-            if (cs.do_second) ct.secb_acc2l += 1u;
-            if (acc2) ct.acc2b_rev += 1u;
-        }
-        const unsigned long long m2 = MSTAMP();
-        ms.splat += m2 - m1;
-        if (acc1 || acc2) {
-            smp.mode = acc1 ? SM_STAGE1 : SM_STAGE2;
-            for (int k = 0; k < D; ++k) lds_x[(uint32_t) k * smp.stride + lane] = smp.next((uint32_t) k);
-            cs.cur = acc1 ? cs.y : cs.z;
-            if (amap && !mix) {
-                if (acc1) { if (!cs.large) film_put(P, cs.cur.px, cs.cur.py, mk3(1.f, 0.f, 0.f)); }
-                else film_put(P, cs.cur.px, cs.cur.py, mk3(0.f, 1.f, 0.f));
-            }
-        }
-        cs.it++;
-        cs.stage = -1;
-        ms.commit += MSTAMP() - m2;
-    }
-    const unsigned long long m3 = MSTAMP();
-    // start the next mutation
-    if (cs.it >= n_mut) { ps.phase = PH_IDLE; return false; }
-    const uint32_t m = mut_base + cs.it;
-    const u4 coins = philox4x32_10(P.key0, P.key1, 0u, m, smp.chain, TAG_COIN);
-    cs.large = u32_to_unit(coins.x) < P.p_large;
-    cs.coin_acc1 = u32_to_unit(coins.y); cs.coin_acc2 = u32_to_unit(coins.z); cs.coin_mix = u32_to_unit(coins.w);
-    smp.major = m;
-    smp.large = cs.large;
-    cs.stage = 0;
-    cs.do_second = false;
-    cs.nd1 = cs.nd2 = 0u;
-    start_path(P, smp, ps, 0);
-    ms.start += MSTAMP() - m3;
-    return true;
+    cs.it++;
+    cs.stage = -1;
+    return commit;
 }
-#undef MSTAMP
+
+// DRMLTSampler::accept for dimensions [k0, k1): uCurrent = wrap(chosen proposal)
+DEV void commit_range(LdsSampler &smp, int commit_mode, uint32_t k0, uint32_t k1) {
+    smp.mode = commit_mode;
+    for (uint32_t k = k0; k < k1; ++k) lds_x[k * smp.stride + smp.lane] = smp.next(k);
+}
+
+DEV int mh_start(const DParams &P, ChainState &cs, LdsSampler &smp, PathState &ps, uint32_t n_mut, uint32_t mut_base) {
+    int fill = 0;
+    if (cs.stage < 0) { // next mutation
+        if (cs.it >= n_mut) { ps.phase = PH_IDLE; return 0; }
+        const uint32_t m = mut_base + cs.it;
+        const u4 coins = philox4x32_10(P.key0, P.key1, 0u, m, smp.chain, TAG_COIN);
+        cs.large = u32_to_unit(coins.x) < P.p_large;
+        cs.coin_acc1 = u32_to_unit(coins.y); cs.coin_acc2 = u32_to_unit(coins.z); cs.coin_mix = u32_to_unit(coins.w);
+        smp.major = m;
+        smp.large = cs.large;
+        cs.stage = 0;
+        cs.do_second = false;
+        cs.nd1 = cs.nd2 = 0u;
+        fill = 1;
+    } else if (cs.stage == 1) {
+        fill = 2;
+    }
+    smp.mode = cs.stage == 0 ? SM_STAGE1 : (cs.stage == 1 ? SM_STAGE2 : SM_REVERSE);
+    path_init(P, ps);
+    return fill;
+}
+
+// one lane does everything (k_mutate_v2)
+DEV void mh_advance(const DParams &P, ChainState &cs, LdsSampler &smp, PathState &ps, Counters &ct, uint32_t n_mut,
+                    uint32_t mut_base, uint32_t lane, MhStamps &ms, bool stamps) {
+    const unsigned long long m0 = stamps ? __builtin_amdgcn_s_memtime() : 0ull;
+    const int commit = mh_decide(P, cs, smp, ps, ct);
+    const unsigned long long m1 = stamps ? __builtin_amdgcn_s_memtime() : 0ull;
+    if (commit) commit_range(smp, commit, 0u, (uint32_t) P.eff_dim);
+    const unsigned long long m2 = stamps ? __builtin_amdgcn_s_memtime() : 0ull;
+    const int fill = mh_start(P, cs, smp, ps, n_mut, mut_base);
+    const uint32_t D4 = ((uint32_t) P.eff_dim + 3u) & ~3u;
+    if (fill == 1) smp.fill_stage1(0u, D4 / 4u);
+    else if (fill == 2) smp.fill_stage2(D4, 0u, 1u);
+    ms.digest += m1 - m0; ms.commit += m2 - m1;
+    ms.start += (stamps ? __builtin_amdgcn_s_memtime() : 0ull) - m2;
+}
 
 __global__ void __launch_bounds__(CHAIN_BLOCK) k_mutate_v2(DParams P, uint32_t n_mut, uint32_t mut_base) {
     const uint32_t lane = threadIdx.x;
@@ -439,6 +456,7 @@ __global__ void __launch_bounds__(CHAIN_BLOCK) k_mutate_v2(DParams P, uint32_t n
     path_init(P, ps);
     ps.phase = (live && n_mut > 0u) ? PH_DONE : PH_IDLE; // PH_DONE with stage -1: "start the first mutation"
     Hit h{-1, 0.f, 0.f, 0.f};
+    ShadowRay sr_unused;
     const int batch = P.mh_batch;
     // scene tables: staged in LDS behind the sampler rows when they are small
     LdsTables LT;
@@ -470,8 +488,8 @@ __global__ void __launch_bounds__(CHAIN_BLOCK) k_mutate_v2(DParams P, uint32_t n
         if (tracing) h = trace(P, ps.o, ps.d, ps.tmin, ps.tmax, ps.phase == PH_SHADOW);
         const unsigned long long s2 = STAMP();
         if (ps.phase != PH_DONE && ps.phase != PH_IDLE) {
-            if (lds_tables) path_step(P, LT, ps, smp, h);
-            else path_step(P, GT, ps, smp, h);
+            if (lds_tables) path_step<false>(P, LT, ps, smp, h, false, sr_unused);
+            else path_step<false>(P, GT, ps, smp, h, false, sr_unused);
         }
         const unsigned long long s3 = STAMP();
         t_mh += s1 - s0; t_trace += s2 - s1; t_step += s3 - s2; n_iter++;
@@ -485,6 +503,133 @@ __global__ void __launch_bounds__(CHAIN_BLOCK) k_mutate_v2(DParams P, uint32_t n
 
     if (live) {
         for (int k = 0; k < D; ++k) P.x[(size_t) k * P.n_chains + c] = lds_x[(uint32_t) k * per_wave + lane];
+        P.cur_lum[c] = cs.cur.lum; P.cur_px[c] = cs.cur.px; P.cur_py[c] = cs.cur.py;
+        P.cur_r[c] = cs.cur.r; P.cur_g[c] = cs.cur.g; P.cur_b[c] = cs.cur.b;
+    }
+    unsigned long long v[9];
+    v[0] = wave_sum(ct.large_acc1l & 0xffffu); v[1] = wave_sum(ct.large_acc1l >> 16);
+    v[2] = wave_sum(ct.acc1b_secl & 0xffffu);  v[3] = wave_sum(ct.acc1b_secl >> 16);
+    v[4] = wave_sum(ct.secb_acc2l & 0xffffu);  v[5] = wave_sum(ct.secb_acc2l >> 16);
+    v[6] = wave_sum(ct.acc2b_rev & 0xffffu);   v[7] = wave_sum(ct.acc2b_rev >> 16);
+    v[8] = wave_sum(ct.rays);
+    if (lane == 0)
+        for (int i = 0; i < 9; ++i) atomicAdd(P.stats + i, v[i]);
+}
+
+// ------------------------------------------------------------------------------------------
+// k_mutate_v3: two lanes per chain. 64 k chains are only 1024 waves = ONE wave per SIMD: every
+// LDS / scalar-cache / transcendental latency is exposed and a lone wave can issue a VALU op only
+// every 4 cycles (MI355X_MICROARCH.md). Lanes 0..31 of a wave run the chain state machines of
+// k_mutate_v2; lane 32+i is the helper of lane i and traces the shadow (NEE) ray of a vertex
+// while lane i traces the BSDF-sampled ray of the same vertex. A bounce then costs one loop
+// iteration instead of two, a wave carries 32 chains, and the same 64 k chains occupy 2048
+// waves = two per SIMD, which hide each other's latencies. Per chain the arithmetic and the
+// order of all additions are those of k_mutate_v2.
+DEV float from_lower(float v) { // value of lane (l & 31) for every lane l (v_permlane32_swap)
+    unsigned u = __float_as_uint(v);
+    return __uint_as_float(__builtin_amdgcn_permlane32_swap(u, u, false, false)[0]);
+}
+DEV unsigned from_lower_u(unsigned u) { return __builtin_amdgcn_permlane32_swap(u, u, false, false)[0]; }
+DEV unsigned from_upper_u(unsigned u) { // value of lane 32 + (l & 31) for every lane l
+    return __builtin_amdgcn_permlane32_swap(u, u, false, false)[1];
+}
+
+__global__ void __launch_bounds__(CHAIN_BLOCK) k_mutate_v3(DParams P, uint32_t n_mut, uint32_t mut_base) {
+    const uint32_t lane = threadIdx.x;
+    const uint32_t sub = lane & 31u;
+    const bool helper = lane >= 32u;
+    const uint32_t c = blockIdx.x * 32u + sub;
+    const bool live = !helper && c < P.n_chains;
+    const uint32_t cc = c < P.n_chains ? c : P.n_chains - 1;
+    const int D = P.eff_dim;
+    const uint32_t D4 = ((uint32_t) D + 3u) & ~3u;
+    if (!helper)
+        for (int k = 0; k < D; ++k) lds_x[(uint32_t) k * 32u + sub] = P.x[(size_t) k * P.n_chains + cc];
+
+    ChainState cs;
+    cs.cur.lum = P.cur_lum[cc]; cs.cur.px = P.cur_px[cc]; cs.cur.py = P.cur_py[cc];
+    cs.cur.r = P.cur_r[cc]; cs.cur.g = P.cur_g[cc]; cs.cur.b = P.cur_b[cc];
+    cs.y = cs.cur; cs.z = cs.cur;
+    cs.a1 = 0.f; cs.coin_acc1 = cs.coin_acc2 = cs.coin_mix = 0.f;
+    cs.it = 0u; cs.nd1 = cs.nd2 = 0u; cs.stage = -1; cs.large = false; cs.do_second = false;
+
+    LdsSampler smp;
+    smp.key0 = P.key0; smp.key1 = P.key1; smp.chain = P.chain_offset + cc; smp.major = 0u;
+    smp.mode = SM_STAGE1; smp.type = P.type; smp.large = false; smp.sigma2 = P.sigma2; smp.lane = sub;
+    smp.stride = 32u;
+    smp.u1_off = (uint32_t) D * 32u;
+    smp.s2_off = smp.u1_off + D4 * 32u;
+    smp.timing_probe = false;
+    Counters ct = {0u, 0u, 0u, 0u, 0u};
+    PathState ps;
+    path_init(P, ps);
+    ps.phase = (live && n_mut > 0u) ? PH_DONE : PH_IDLE; // helpers stay PH_IDLE for good
+    ps.o = mk3(0.f, 0.f, 0.f); ps.d = mk3(0.f, 0.f, 1.f); ps.tmin = 0.f; ps.tmax = 0.f;
+    bool helper_has_ray = false;
+    Hit h{-1, 0.f, 0.f, 0.f};
+    const int batch = P.mh_batch > 32 ? 32 : P.mh_batch;
+    LdsTables LT;
+    LT.shade_off = smp.s2_off + D4 * 32u;
+    LT.bsdf_off = LT.shade_off + (uint32_t) P.n_prims * 16u;
+    LT.emit_off = LT.bsdf_off + (uint32_t) P.n_bsdfs * 12u;
+    const GlobalTables GT{P.shade, P.bsdfs, P.emitters};
+    const bool lds_tables = P.tables_in_lds != 0;
+    if (lds_tables) stage_tables(P, LT, lane);
+
+    for (;;) {
+        const bool parked = ps.phase == PH_DONE;
+        const unsigned long long pmask = __ballot(parked);
+        const unsigned long long rmask = __ballot(ps.phase != PH_DONE && ps.phase != PH_IDLE);
+        if (!pmask && !rmask) break;
+        if (pmask && (__popcll(pmask) >= batch || !rmask)) {
+            // decide (chain lanes) -> commit (both lanes of a pair) -> start (chain lanes) -> draw (both lanes)
+            int commit = 0;
+            if (parked) commit = mh_decide(P, cs, smp, ps, ct);
+            const int commit_pair = (int) from_lower_u((unsigned) commit);
+            const uint32_t maj_c = from_lower_u(smp.major);
+            const bool large_c = from_lower_u(smp.large ? 1u : 0u) != 0u;
+            if (helper) { smp.major = maj_c; smp.large = large_c; }
+            if (commit_pair) { // pair-aligned halves: orbital pairs never straddle the split
+                const uint32_t split = (((uint32_t) D / 2u) + 1u) & ~1u;
+                commit_range(smp, commit_pair, helper ? split : 0u, helper ? (uint32_t) D : split);
+            }
+            int fill = 0;
+            if (parked) fill = mh_start(P, cs, smp, ps, n_mut, mut_base);
+            const int fill_pair = (int) from_lower_u((unsigned) fill);
+            const uint32_t maj_f = from_lower_u(smp.major);
+            const bool large_f = from_lower_u(smp.large ? 1u : 0u) != 0u;
+            if (helper) { smp.major = maj_f; smp.large = large_f; }
+            if (fill_pair == 1) {
+                const uint32_t nb = D4 / 4u, hb = (nb + 1u) / 2u;
+                smp.fill_stage1(helper ? hb : 0u, helper ? nb : hb);
+            } else if (fill_pair == 2) {
+                smp.fill_stage2(D4, helper ? 1u : 0u, 2u);
+            }
+        }
+        // one ray per lane: chain lanes their camera / bounce ray, helpers the shadow ray they were handed
+        const bool tracing = helper ? helper_has_ray : ps.phase == PH_CLOSEST;
+        if (tracing) h = trace(P, ps.o, ps.d, ps.tmin, ps.tmax, helper);
+        const unsigned occluded = from_upper_u((helper_has_ray && h.prim >= 0) ? 1u : 0u);
+        helper_has_ray = false;
+        ShadowRay sr;
+        sr.o = ps.o; sr.d = ps.d; sr.tmin = 0.f; sr.tmax = 0.f; sr.valid = false;
+        if (!helper && ps.phase != PH_DONE && ps.phase != PH_IDLE) {
+            if (lds_tables) path_step<true>(P, LT, ps, smp, h, occluded == 0u, sr);
+            else path_step<true>(P, GT, ps, smp, h, occluded == 0u, sr);
+        }
+        // hand the shadow ray of this vertex to the helper lane
+        const float ox = from_lower(sr.o.x), oy = from_lower(sr.o.y), oz = from_lower(sr.o.z);
+        const float dx = from_lower(sr.d.x), dy = from_lower(sr.d.y), dz = from_lower(sr.d.z);
+        const float t0 = from_lower(sr.tmin), t1 = from_lower(sr.tmax);
+        const float vf = from_lower(sr.valid ? 1.f : 0.f);
+        if (helper) {
+            ps.o = mk3(ox, oy, oz); ps.d = mk3(dx, dy, dz); ps.tmin = t0; ps.tmax = t1;
+            helper_has_ray = vf != 0.f;
+        }
+    }
+
+    if (live) {
+        for (int k = 0; k < D; ++k) P.x[(size_t) k * P.n_chains + c] = lds_x[(uint32_t) k * 32u + sub];
         P.cur_lum[c] = cs.cur.lum; P.cur_px[c] = cs.cur.px; P.cur_py[c] = cs.cur.py;
         P.cur_r[c] = cs.cur.r; P.cur_g[c] = cs.cur.g; P.cur_b[c] = cs.cur.b;
     }
@@ -557,6 +702,10 @@ void launch_mutate(const DParams &P, uint32_t n_mut, uint32_t mut_base, hipStrea
     dim3 grid((P.n_chains + CHAIN_BLOCK - 1) / CHAIN_BLOCK), block(CHAIN_BLOCK);
     if (P.kernel_variant == 1) {
         hipLaunchKernelGGL(k_mutate, grid, block, D * 64 * sizeof(float), st, P, n_mut, mut_base);
+    } else if (P.kernel_variant == 3) { // 32 chains per wave, rows of 32 floats
+        size_t lds = (D + 2 * D4) * 32 * sizeof(float);
+        if (P.tables_in_lds) lds += (size_t) P.n_prims * 64 + (size_t) P.n_bsdfs * 48 + (size_t) P.n_emitters * 32;
+        hipLaunchKernelGGL(k_mutate_v3, dim3((P.n_chains + 31) / 32), block, lds, st, P, n_mut, mut_base);
     } else { // x + first-stage uniforms + second-stage values, one 256 B row per dimension
         size_t lds = (D + 2 * D4) * 64 * sizeof(float);
         if (P.debug & 512) { grid = dim3((P.n_chains + 31) / 32); lds /= 2; }

@@ -267,7 +267,8 @@ def test_state_machine_kernel_equals_nested_kernel(pkg, ob, kw, native_lib):
     cfg = pkg.abi.make_config(max_depth=8, direct_samples=-1, luminance_samples=20000, work_units=n_chains,
                               sample_count=1, **kw)
     results = []
-    for env in (dict(DRMLT_KERNEL=1), dict(DRMLT_KERNEL=2, DRMLT_MH_BATCH=1), dict(DRMLT_KERNEL=2, DRMLT_MH_BATCH=24)):
+    for env in (dict(DRMLT_KERNEL=1), dict(DRMLT_KERNEL=2, DRMLT_MH_BATCH=1), dict(DRMLT_KERNEL=2, DRMLT_MH_BATCH=24),
+                dict(DRMLT_KERNEL=3, DRMLT_MH_BATCH=12)):
         ctx = _ctx_with_env(pkg, cfg, sd, **env)
         ctx.seed(0x77)
         ctx.run(n_chains * n_mut)
@@ -289,3 +290,6 @@ def test_state_machine_kernel_equals_nested_kernel(pkg, ob, kw, native_lib):
     (c1, u1), s1, f1 = results[1]
     (c2, u2), s2, f2 = results[2]
     assert np.array_equal(u1, u2) and s1.accepted == s2.accepted and s1.rays == s2.rays
+    # ... and neither does tracing the shadow rays on a partner lane (k_mutate_v3)
+    (c3, u3), s3, f3 = results[3]
+    assert np.array_equal(u1, u3) and s1.accepted == s3.accepted and s1.rays == s3.rays
