@@ -12,6 +12,7 @@
 //   diffuse / dielectric     src/bsdfs/diffuse.cpp:110-149, dielectric.cpp:228-333
 //   perspective sensor       src/sensors/perspective.cpp:271-300
 #pragma once
+#include "device_bsdf.h"
 #include "device_math.h"
 #include "device_types.h"
 
@@ -660,10 +661,18 @@ DEV void path_step(const DParams &P, const TablesT &T, PathState &ps, SamplerT &
             float dr = ps.refn_zero ? 0.f : dot3(dd, n);
             if (dr >= 0.f && dln < 0.f && pdf != 0.f) { // AreaLight::sampleDirect
                 f3 wo = mk3(dot3(dd, s), dot3(dd, t), dot3(dd, n));
-                // diffuse eval / pdf (diffuse.cpp:110-127)
                 if (ps.wi.z > 0.f && wo.z > 0.f) {
-                    f3 bsdfVal = ld3(B.rgb) * (INV_PI_F * wo.z);
-                    float bsdfPdf = INV_PI_F * wo.z;
+                    f3 bsdfVal;
+                    float bsdfPdf;
+                    if (B.type == 0) { // diffuse eval / pdf (diffuse.cpp:110-127)
+                        bsdfVal = ld3(B.rgb) * (INV_PI_F * wo.z);
+                        bsdfPdf = INV_PI_F * wo.z;
+                    } else { // rough conductor (roughconductor.cpp:258-323)
+                        const DRoughConductor rc{DMicrofacet{B.p[7] != 0.f, fmaxf(B.p[0], 1e-4f)}, mk3(B.p[1], B.p[2], B.p[3]),
+                                                 mk3(B.p[4], B.p[5], B.p[6]), ld3(B.rgb)};
+                        bsdfVal = rc.eval(ps.wi, wo);
+                        bsdfPdf = rc.pdf(ps.wi, wo);
+                    }
                     float lpdf = pdf * emPdf;
                     float a = lpdf * lpdf, b = bsdfPdf * bsdfPdf;
                     f3 value = ld3(E.radiance) * (1.f / lpdf);
@@ -717,6 +726,13 @@ DEV void path_step(const DParams &P, const TablesT &T, PathState &ps, SamplerT &
             float factor = cosThetaT < 0.f ? invEta : eta;
             ps.bweight = mk3(factor * factor, factor * factor, factor * factor);
         }
+    } else if (B.type == 2) { // roughconductor.cpp:371-409
+        const DRoughConductor rc{DMicrofacet{B.p[7] != 0.f, fmaxf(B.p[0], 1e-4f)}, mk3(B.p[1], B.p[2], B.p[3]),
+                                 mk3(B.p[4], B.p[5], B.p[6]), ld3(B.rgb)};
+        ps.bpdf = 0.f;
+        ps.bweight = rc.sample(ps.wi, ps.bx, ps.by, wo, ps.bpdf);
+        ps.beta_eta = 1.f;
+        ps.bdelta = false;
     } else {
         ps.phase = (DUAL && ps.shadow_pending) ? PH_FLUSH : PH_DONE;
         return;

@@ -125,8 +125,11 @@ std::string build_scene(drmlt_ctx *ctx, const drmlt_scene &s, std::vector<DBsdf>
             if (!(in.p[0] > 0.f) || !(in.p[1] > 0.f)) return "dielectric: IORs must be positive";
             b.p[0] = in.p[0] / in.p[1];
             b.p[1] = 1.f / b.p[0];
+        } else if (in.type == DRMLT_BSDF_ROUGHCONDUCTOR) {
+            if (!(in.p[0] > 0.f)) return "roughconductor: alpha must be positive";
+            for (int k = 0; k < 8; ++k) b.p[k] = in.p[k];
         } else {
-            return "unsupported BSDF type " + std::to_string(in.type) + " (supported: diffuse, dielectric)";
+            return "unsupported BSDF type " + std::to_string(in.type) + " (supported: diffuse, dielectric, roughconductor)";
         }
         bsdfs.push_back(b);
     }

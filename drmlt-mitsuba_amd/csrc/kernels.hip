@@ -576,12 +576,17 @@ __global__ void __launch_bounds__(CHAIN_BLOCK) k_mutate_v3(DParams P, uint32_t n
     const bool lds_tables = P.tables_in_lds != 0;
     if (lds_tables) stage_tables(P, LT, lane);
 
+    const bool stamps = (P.debug & 128) != 0;
+    unsigned long long t_mh = 0, t_trace = 0, t_step = 0, n_iter = 0, n_mh = 0, n_busy = 0;
+#define STAMP() (stamps ? __builtin_amdgcn_s_memtime() : 0ull)
     for (;;) {
         const bool parked = ps.phase == PH_DONE;
         const unsigned long long pmask = __ballot(parked);
         const unsigned long long rmask = __ballot(ps.phase != PH_DONE && ps.phase != PH_IDLE);
         if (!pmask && !rmask) break;
+        const unsigned long long s0 = STAMP();
         if (pmask && (__popcll(pmask) >= batch || !rmask)) {
+            n_mh++;
             // decide (chain lanes) -> commit (both lanes of a pair) -> start (chain lanes) -> draw (both lanes)
             int commit = 0;
             if (parked) commit = mh_decide(P, cs, smp, ps, ct);
@@ -607,8 +612,11 @@ __global__ void __launch_bounds__(CHAIN_BLOCK) k_mutate_v3(DParams P, uint32_t n
             }
         }
         // one ray per lane: chain lanes their camera / bounce ray, helpers the shadow ray they were handed
+        const unsigned long long s1 = STAMP();
         const bool tracing = helper ? helper_has_ray : ps.phase == PH_CLOSEST;
+        if (stamps) n_busy += __popcll(__ballot(tracing));
         if (tracing) h = trace(P, ps.o, ps.d, ps.tmin, ps.tmax, helper);
+        const unsigned long long s2 = STAMP();
         const unsigned occluded = from_upper_u((helper_has_ray && h.prim >= 0) ? 1u : 0u);
         helper_has_ray = false;
         ShadowRay sr;
@@ -626,6 +634,13 @@ __global__ void __launch_bounds__(CHAIN_BLOCK) k_mutate_v3(DParams P, uint32_t n
             ps.o = mk3(ox, oy, oz); ps.d = mk3(dx, dy, dz); ps.tmin = t0; ps.tmax = t1;
             helper_has_ray = vf != 0.f;
         }
+        const unsigned long long s3 = STAMP();
+        t_mh += s1 - s0; t_trace += s2 - s1; t_step += s3 - s2; n_iter++;
+    }
+#undef STAMP
+    if (stamps && lane == 0) {
+        atomicAdd(P.stats + 16, t_mh); atomicAdd(P.stats + 17, t_trace); atomicAdd(P.stats + 18, t_step);
+        atomicAdd(P.stats + 19, n_iter); atomicAdd(P.stats + 20, n_mh); atomicAdd(P.stats + 21, n_busy);
     }
 
     if (live) {

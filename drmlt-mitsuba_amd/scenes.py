@@ -226,6 +226,25 @@ def glass_sphere(res=128):
     return sd
 
 
+def door_c3(res=256, ggx=False):
+    """closed room, partition wall with a 5 % gap hiding a quad light, rough-conductor floor."""
+    sd = SceneData("door_c3")
+    white = sd.diffuse(0.725, 0.71, 0.68)
+    red = sd.diffuse(0.63, 0.065, 0.05)
+    green = sd.diffuse(0.14, 0.45, 0.091)
+    black = sd.diffuse(0.0)
+    copper = sd.roughconductor(alpha=0.1, ggx=ggx)
+    sd.rectangle(translate(0, -1, 0) @ rotate("x", -90), copper)                      # floor: glossy metal
+    _room(sd, white, red, green, walls=("ceiling", "back", "left", "right"))
+    sd.rectangle(translate(0, 0, 1) @ rotate("y", 180), white)                        # front wall (room is closed)
+    # partition at z = -0.4 leaving a 0.1-wide gap at the right wall (5 % of the room width); two one-sided faces
+    sd.rectangle(translate(-0.05, 0, -0.4) @ scale(0.95, 1, 1), white)                # faces the camera room
+    sd.rectangle(translate(-0.05, 0, -0.42) @ rotate("y", 180) @ scale(0.95, 1, 1), white)  # faces the light room
+    sd.rectangle(translate(-0.3, 0.2, -0.99) @ scale(0.3), black, radiance=40.0)      # light on the back wall
+    sd.set_camera(lookat((0, -0.2, 0.95), (0, -0.3, -0.4), (0, 1, 0)), 70.0, res, res, abi.FILTER_BOX, 0.5)
+    return sd
+
+
 def triangle_soup(n_tris=2000, res=128, seed=7):
     """Closed room filled with small random diffuse triangles: a scene large enough that the BVH matters."""
     rng = np.random.default_rng(seed)
@@ -247,5 +266,5 @@ def triangle_soup(n_tris=2000, res=128, seed=7):
     return sd
 
 
-SCENES = {"cornell_c1": cornell_c1, "cornell_c2": cornell_c2, "glass_sphere": glass_sphere,
+SCENES = {"cornell_c1": cornell_c1, "cornell_c2": cornell_c2, "glass_sphere": glass_sphere, "door_c3": door_c3,
           "triangle_soup": triangle_soup}

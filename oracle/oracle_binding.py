@@ -57,6 +57,7 @@ def lib(native=False):
         L.oracle_film_put.argtypes = [C.c_int, C.c_int, C.c_int, C.c_double, C.c_uint32, C.c_void_p, C.c_void_p,
                                       C.c_void_p]
         L.oracle_find_max_dim.argtypes = [C.c_int, C.c_int]
+        L.oracle_roughconductor.argtypes = [C.c_int, C.c_double] + [C.c_void_p] * 3 + [C.c_uint32] + [C.c_void_p] * 7
         _libs[native] = L
     return _libs[native]
 
@@ -205,3 +206,19 @@ def film_put(w, h, filt, param, xy, rgb):
     out = np.zeros((h, w, 3), dtype=np.float32)
     lib().oracle_film_put(w, h, filt, param, xy.shape[0], xy.ctypes.data, rgb.ctypes.data, out.ctypes.data)
     return out
+
+
+def roughconductor(ggx, alpha, eta, k, wi, wo=None, sxy=None):
+    """eval/pdf for explicit directions and/or samples for explicit (sx, sy); local frame, double precision."""
+    f = lambda a: np.ascontiguousarray(a, dtype=np.float64)
+    eta, k, wi = f(eta), f(k), f(wi)
+    out = {}
+    n = len(wo) if wo is not None else len(sxy)
+    ev, pdf = np.zeros((n, 3)), np.zeros(n)
+    swo, sw, spdf = np.zeros((n, 3)), np.zeros((n, 3)), np.zeros(n)
+    wo_ = f(wo) if wo is not None else None
+    sxy_ = f(sxy) if sxy is not None else None
+    lib().oracle_roughconductor(int(ggx), alpha, eta.ctypes.data, k.ctypes.data, wi.ctypes.data, n,
+                                wo_.ctypes.data if wo_ is not None else None, sxy_.ctypes.data if sxy_ is not None else None,
+                                ev.ctypes.data, pdf.ctypes.data, swo.ctypes.data, sw.ctypes.data, spdf.ctypes.data)
+    return dict(eval=ev, pdf=pdf, wo=swo, weight=sw, spdf=spdf)

@@ -355,6 +355,29 @@ int oracle_film_put(int w, int h, int filter, double param, uint32_t n, const fl
     return 0;
 }
 
+// rough conductor in local coordinates (double): eval/pdf of (wi, wo) pairs and samples for (sx, sy) pairs
+void oracle_roughconductor(int ggx, double alpha, const double *eta, const double *k, const double *wi, uint32_t n, const double *wo_in,
+                           const double *sxy, double *eval_out, double *pdf_out, double *wo_out, double *weight_out, double *spdf_out) {
+    RoughConductor<double> rc{Microfacet<double>(ggx != 0, alpha), V3<double>(eta[0], eta[1], eta[2]), V3<double>(k[0], k[1], k[2]), V3<double>(1, 1, 1)};
+    V3<double> w(wi[0], wi[1], wi[2]);
+    for (uint32_t i = 0; i < n; ++i) {
+        if (wo_in) {
+            V3<double> wo(wo_in[3 * i], wo_in[3 * i + 1], wo_in[3 * i + 2]);
+            V3<double> e = rc.eval(w, wo);
+            eval_out[3 * i] = e.x; eval_out[3 * i + 1] = e.y; eval_out[3 * i + 2] = e.z;
+            pdf_out[i] = rc.pdf(w, wo);
+        }
+        if (sxy) {
+            V3<double> wo;
+            double pdf = 0;
+            V3<double> wt = rc.sample(w, sxy[2 * i], sxy[2 * i + 1], wo, pdf);
+            wo_out[3 * i] = wo.x; wo_out[3 * i + 1] = wo.y; wo_out[3 * i + 2] = wo.z;
+            weight_out[3 * i] = wt.x; weight_out[3 * i + 1] = wt.y; weight_out[3 * i + 2] = wt.z;
+            spdf_out[i] = wt.isZero() ? 0.0 : pdf;
+        }
+    }
+}
+
 int oracle_find_max_dim(int maxDepth, int rrDepth) { return findMaxDimensionsPath(maxDepth, rrDepth); }
 
 } // extern "C"

@@ -14,6 +14,7 @@
 // result is the same as testing every primitive, which is what the oracle does.
 #pragma once
 #include "../include/drmlt_abi.h"
+#include "oracle_microfacet.hpp"
 #include "oracle_sampler.hpp"
 #include <string>
 
@@ -28,6 +29,10 @@ template <typename F> struct Bsdf {
     int type;
     V3<F> rgb;
     F eta = 1, invEta = 1; // dielectric: intIOR/extIOR
+    bool ggx = false;      // rough conductor
+    F alpha = F(0.1);
+    V3<F> cEta, cK;
+    RoughConductor<F> rough() const { return RoughConductor<F>{Microfacet<F>(ggx, alpha), cEta, cK, rgb}; }
     bool smooth() const { return type == DRMLT_BSDF_DIFFUSE || type == DRMLT_BSDF_ROUGHCONDUCTOR; }
     // DirectSamplingRecord(its): refN is zeroed for transmissive / two-sided BSDFs
     bool transmissiveOrBackside() const { return type == DRMLT_BSDF_DIELECTRIC; }
@@ -117,6 +122,11 @@ public:
             if (b.type == DRMLT_BSDF_DIELECTRIC) {
                 o.eta = (F) b.p[0] / (F) b.p[1];
                 o.invEta = 1 / o.eta;
+            } else if (b.type == DRMLT_BSDF_ROUGHCONDUCTOR) {
+                o.alpha = b.p[0];
+                o.cEta = V3<F>(b.p[1], b.p[2], b.p[3]);
+                o.cK = V3<F>(b.p[4], b.p[5], b.p[6]);
+                o.ggx = b.p[7] != 0.f;
             } else if (b.type != DRMLT_BSDF_DIFFUSE) {
                 return "oracle: unsupported bsdf type";
             }
@@ -434,6 +444,7 @@ public:
             if (wi.z <= 0 || wo.z <= 0) return V3<F>(0);
             return b.rgb * (F(kInvPi) * wo.z);
         }
+        if (b.type == DRMLT_BSDF_ROUGHCONDUCTOR) return b.rough().eval(wi, wo);
         return V3<F>(0); // delta BSDFs evaluate to zero under the solid-angle measure
     }
     F bsdfPdf(const Bsdf<F> &b, const V3<F> &wi, const V3<F> &wo) const {
@@ -441,6 +452,7 @@ public:
             if (wi.z <= 0 || wo.z <= 0) return 0;
             return squareToCosineHemispherePdf(wo);
         }
+        if (b.type == DRMLT_BSDF_ROUGHCONDUCTOR) return b.rough().pdf(wi, wo);
         return 0;
     }
     // returns weight = f*cos/pdf; `delta`: sampled a Dirac component
@@ -452,6 +464,7 @@ public:
             pdf = squareToCosineHemispherePdf(wo);
             return b.rgb;
         }
+        if (b.type == DRMLT_BSDF_ROUGHCONDUCTOR) return b.rough().sample(wi, sx, sy, wo, pdf);
         // dielectric.cpp:270-333, both components enabled
         delta = true;
         F cosThetaT;
