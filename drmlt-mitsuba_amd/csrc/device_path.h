@@ -244,13 +244,13 @@ struct Hit {
 
 // One primitive against one ray. `P` is wave-uniform in the brute-force loop (SGPR operands).
 // Flat primitives are branch-free (selects only): no exec-mask traffic in the hot loop.
-DEV void intersect_prim(const DPrim &P, int idx, f3 o, f3 d, float tmin, Hit &h) {
+template <int FEAT = 15> DEV void intersect_prim(const DPrim &P, int idx, f3 o, f3 d, float tmin, Hit &h) {
     f3 lo = mk3(fmaf(P.m[0], o.x, fmaf(P.m[1], o.y, fmaf(P.m[2], o.z, P.m[3]))),
                 fmaf(P.m[4], o.x, fmaf(P.m[5], o.y, fmaf(P.m[6], o.z, P.m[7]))),
                 fmaf(P.m[8], o.x, fmaf(P.m[9], o.y, fmaf(P.m[10], o.z, P.m[11]))));
     f3 ld = mk3(fmaf(P.m[0], d.x, fmaf(P.m[1], d.y, P.m[2] * d.z)), fmaf(P.m[4], d.x, fmaf(P.m[5], d.y, P.m[6] * d.z)),
                 fmaf(P.m[8], d.x, fmaf(P.m[9], d.y, P.m[10] * d.z)));
-    if (P.type != PRIM_SPHERE) { // wave-uniform branch
+    if (!(FEAT & 4) || P.type != PRIM_SPHERE) { // wave-uniform branch (compiled out for sphere-free scenes)
         float t = -lo.z * fast_rcp(ld.z);
         float u = fmaf(t, ld.x, lo.x), v = fmaf(t, ld.y, lo.y);
         // triangle: u >= 0, v >= 0, u + v <= 1   rectangle: |u| <= 1, |v| <= 1
@@ -289,7 +289,7 @@ DEV void intersect_prim(const DPrim &P, int idx, f3 o, f3 d, float tmin, Hit &h)
 // and feeds the VALU ops as SGPR operands: no VGPRs, no vector-memory latency in the loop.
 typedef const DPrim __attribute__((address_space(4))) *ScalarPrimPtr;
 
-DEV Hit trace_brute(const DParams &P, f3 o, f3 d, float tmin, float tmax) {
+template <int FEAT = 15> DEV Hit trace_brute(const DParams &P, f3 o, f3 d, float tmin, float tmax) {
     Hit h{-1, tmax, 0.f, 0.f};
     const int n = P.n_prims;
     if (P.debug & 64) { // A/B: vector-memory path
@@ -314,10 +314,10 @@ DEV Hit trace_brute(const DParams &P, f3 o, f3 d, float tmin, float tmax) {
     for (int i = 0; i < n; i += 2) {
         PIN(A);
         load(i + 1 < n ? i + 1 : i, B);
-        intersect_prim(A, i, o, d, tmin, h);
+        intersect_prim<FEAT>(A, i, o, d, tmin, h);
         PIN(B);
         load(i + 2 < n ? i + 2 : i, A);
-        if (i + 1 < n) intersect_prim(B, i + 1, o, d, tmin, h);
+        if (i + 1 < n) intersect_prim<FEAT>(B, i + 1, o, d, tmin, h);
     }
 #undef PIN
     return h;
@@ -376,9 +376,9 @@ DEV Hit trace_bvh(const DParams &P, f3 o, f3 d, float tmin, float tmax, bool any
     return h;
 }
 
-DEV Hit trace(const DParams &P, f3 o, f3 d, float tmin, float tmax, bool any_hit) {
-    if (P.use_bvh) return trace_bvh(P, o, d, tmin, tmax, any_hit);
-    return trace_brute(P, o, d, tmin, tmax);
+template <int FEAT = 15> DEV Hit trace(const DParams &P, f3 o, f3 d, float tmin, float tmax, bool any_hit) {
+    if ((FEAT & 8) && P.use_bvh) return trace_bvh(P, o, d, tmin, tmax, any_hit);
+    return trace_brute<FEAT>(P, o, d, tmin, tmax);
 }
 
 // ------------------------------------------------------------------ scene tables
@@ -394,28 +394,33 @@ struct GlobalTables {
 };
 struct LdsTables {
     uint32_t shade_off, bsdf_off, emit_off; // float offsets into lds_x, multiples of 4
+    // explicit field assignment from four 16 B LDS reads: going through a float* view of the struct
+    // would park the record in scratch memory
     DEV DShade shade(int i) const {
+        const float4 *q = reinterpret_cast<const float4 *>(&lds_x[shade_off + (uint32_t) i * 16u]);
+        const float4 a = q[0], b = q[1], c = q[2], d = q[3];
         DShade s;
-        float *d = reinterpret_cast<float *>(&s);
-        const uint32_t o = shade_off + (uint32_t) i * 16u;
-#pragma unroll
-        for (int k = 0; k < 16; ++k) d[k] = lds_x[o + k];
+        s.origin[0] = a.x; s.origin[1] = a.y; s.origin[2] = a.z; s.eu[0] = a.w;
+        s.eu[1] = b.x; s.eu[2] = b.y; s.ev[0] = b.z; s.ev[1] = b.w;
+        s.ev[2] = c.x; s.n[0] = c.y; s.n[1] = c.z; s.n[2] = c.w;
+        s.inv_len_eu = d.x; s.bsdf = __float_as_int(d.y); s.emitter = __float_as_int(d.z); s.inv_area = d.w;
         return s;
     }
     DEV DBsdf bsdf(int i) const {
-        DBsdf b;
-        float *d = reinterpret_cast<float *>(&b);
-        const uint32_t o = bsdf_off + (uint32_t) i * 12u;
-#pragma unroll
-        for (int k = 0; k < 12; ++k) d[k] = lds_x[o + k];
-        return b;
+        const float4 *q = reinterpret_cast<const float4 *>(&lds_x[bsdf_off + (uint32_t) i * 12u]);
+        const float4 a = q[0], b = q[1], c = q[2];
+        DBsdf r;
+        r.type = __float_as_int(a.x); r.rgb[0] = a.y; r.rgb[1] = a.z; r.rgb[2] = a.w;
+        r.p[0] = b.x; r.p[1] = b.y; r.p[2] = b.z; r.p[3] = b.w;
+        r.p[4] = c.x; r.p[5] = c.y; r.p[6] = c.z; r.p[7] = c.w;
+        return r;
     }
     DEV DEmitter emitter(int i) const {
+        const float4 *q = reinterpret_cast<const float4 *>(&lds_x[emit_off + (uint32_t) i * 8u]);
+        const float4 a = q[0], b = q[1];
         DEmitter e;
-        float *d = reinterpret_cast<float *>(&e);
-        const uint32_t o = emit_off + (uint32_t) i * 8u;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) d[k] = lds_x[o + k];
+        e.radiance[0] = a.x; e.radiance[1] = a.y; e.radiance[2] = a.z; e.prim = __float_as_int(a.w);
+        e.cdf_lo = b.x; e.cdf_hi = b.y; e.pad[0] = b.z; e.pad[1] = b.w;
         return e;
     }
     DEV float emitter_cdf_lo(int i) const { return lds_x[emit_off + (uint32_t) i * 8u + 4u]; }
@@ -518,7 +523,9 @@ DEV void path_init(const DParams &P, PathState &ps) {
 //   the shadow ray of the SAME vertex concurrently; `shadow_clear` is the partner's result for the
 //   ray handed over in the previous step (`sr`), so a bounce costs one step instead of two. The
 //   order of the radiance additions is the same in both modes (NEE of vertex i, then MIS of i+1).
-template <bool DUAL, class SamplerT, class TablesT>
+// FEAT: scene features compiled in (bit 0 rough conductor, bit 1 dielectric, bit 2 spheres, bit 3 BVH); kernels for
+// plain diffuse polygon scenes (the Cornell configs) carry none of the other code or its registers.
+template <bool DUAL, int FEAT, class SamplerT, class TablesT>
 DEV void path_step(const DParams &P, const TablesT &T, PathState &ps, SamplerT &smp, const Hit &hit, bool shadow_clear,
                    ShadowRay &sr) {
     // ---------------- part 1: digest the ray query, decide which PSS components are needed
@@ -545,7 +552,7 @@ DEV void path_step(const DParams &P, const TablesT &T, PathState &ps, SamplerT &
         const DShade S = T.shade(hit.prim);
         const int ptype = S.bsdf >> 24; // primitive kind rides in the top byte
         // surface point + shading frame (skdtree.h:340-429, rectangle.cpp:155-168, sphere.cpp:207-255)
-        if (ptype != PRIM_SPHERE) {
+        if (!(FEAT & 4) || ptype != PRIM_SPHERE) {
             p = fma3(ld3(S.eu), hit.u, fma3(ld3(S.ev), hit.v, ld3(S.origin)));
             n = ld3(S.n);
             s = ld3(S.eu) * S.inv_len_eu;
@@ -592,8 +599,8 @@ DEV void path_step(const DParams &P, const TablesT &T, PathState &ps, SamplerT &
         ps.o = p; ps.n = n; ps.s = s;
         ps.bsdf = S.bsdf & 0xffffff;
         B = T.bsdf(ps.bsdf);
-        ps.refn_zero = B.type == 1; // transmissive / two-sided: DirectSamplingRecord(its) zeroes refN
-        want_nee = ps.direct_on && (B.type == 0 || B.type == 2);
+        ps.refn_zero = (FEAT & 2) && B.type == 1; // transmissive / two-sided: DirectSamplingRecord(its) zeroes refN
+        want_nee = ps.direct_on && (B.type == 0 || ((FEAT & 1) && B.type == 2));
         need = (want_rr ? 1 : 0) + (want_nee ? 2 : 0) + 2;
     }
 
@@ -664,7 +671,7 @@ DEV void path_step(const DParams &P, const TablesT &T, PathState &ps, SamplerT &
                 if (ps.wi.z > 0.f && wo.z > 0.f) {
                     f3 bsdfVal;
                     float bsdfPdf;
-                    if (B.type == 0) { // diffuse eval / pdf (diffuse.cpp:110-127)
+                    if (!(FEAT & 1) || B.type == 0) { // diffuse eval / pdf (diffuse.cpp:110-127)
                         bsdfVal = ld3(B.rgb) * (INV_PI_F * wo.z);
                         bsdfPdf = INV_PI_F * wo.z;
                     } else { // rough conductor (roughconductor.cpp:258-323)
@@ -708,7 +715,7 @@ DEV void path_step(const DParams &P, const TablesT &T, PathState &ps, SamplerT &
         ps.bweight = ld3(B.rgb);
         ps.beta_eta = 1.f;
         ps.bdelta = false;
-    } else if (B.type == 1) { // dielectric.cpp:270-306
+    } else if ((FEAT & 2) && B.type == 1) { // dielectric.cpp:270-306
         float eta = B.p[0], invEta = B.p[1];
         float cosThetaT;
         float F = fresnel_dielectric_ext(ps.wi.z, cosThetaT, eta);
@@ -726,7 +733,7 @@ DEV void path_step(const DParams &P, const TablesT &T, PathState &ps, SamplerT &
             float factor = cosThetaT < 0.f ? invEta : eta;
             ps.bweight = mk3(factor * factor, factor * factor, factor * factor);
         }
-    } else if (B.type == 2) { // roughconductor.cpp:371-409
+    } else if ((FEAT & 1) && B.type == 2) { // roughconductor.cpp:371-409
         const DRoughConductor rc{DMicrofacet{B.p[7] != 0.f, fmaxf(B.p[0], 1e-4f)}, mk3(B.p[1], B.p[2], B.p[3]),
                                  mk3(B.p[4], B.p[5], B.p[6]), ld3(B.rgb)};
         ps.bpdf = 0.f;
@@ -758,7 +765,7 @@ DEV DSplat eval_path(const DParams &P, Sampler &smp, uint32_t &nrays, uint32_t &
     ShadowRay sr_unused;
     for (;;) {
         if (ps.phase != PH_BEGIN) h = trace(P, ps.o, ps.d, ps.tmin, ps.tmax, ps.phase == PH_SHADOW);
-        path_step<false>(P, T, ps, smp, h, false, sr_unused);
+        path_step<false, 15>(P, T, ps, smp, h, false, sr_unused);
         if (ps.phase == PH_DONE) break;
     }
     DSplat out;

@@ -396,6 +396,11 @@ drmlt_ctx *drmlt_create(const drmlt_config *cfg, const drmlt_scene *scene, int d
     if (const char *d = getenv("DRMLT_DEBUG")) P.debug = atoi(d);
     P.kernel_variant = 3;
     if (const char *k = getenv("DRMLT_KERNEL")) { int kv = atoi(k); P.kernel_variant = (kv >= 1 && kv <= 3) ? kv : 2; }
+    P.features = 0;
+    for (const DBsdf &b : bsdfs) P.features |= b.type == DRMLT_BSDF_ROUGHCONDUCTOR ? 1 : (b.type == DRMLT_BSDF_DIELECTRIC ? 2 : 0);
+    for (const DPrim &g : ctx->prims) if (g.type == PRIM_SPHERE) P.features |= 4;
+    if (P.use_bvh) P.features |= 8;
+    if (getenv("DRMLT_FEAT_ALL")) P.features = 15;
     P.mh_batch = 32;
     if (const char *k = getenv("DRMLT_MH_BATCH")) P.mh_batch = std::max(1, std::min(64, atoi(k)));
     if (hipDeviceSynchronize() != hipSuccess) return bail(ctx, "device synchronisation failed after setup");

@@ -34,6 +34,14 @@ DEV void film_put(const DParams &P, float px, float py, f3 v) {
     }
 }
 
+// per-field select: a reference/pointer select between two structs would force them into scratch memory
+DEV DSplat select_splat(bool c, const DSplat &a, const DSplat &b) {
+    DSplat r;
+    r.lum = c ? a.lum : b.lum; r.px = c ? a.px : b.px; r.py = c ? a.py : b.py;
+    r.r = c ? a.r : b.r; r.g = c ? a.g : b.g; r.b = c ? a.b : b.b;
+    return r;
+}
+
 DEV void normalize_splat(DSplat &s) { // SplatList::normalize, pathsampler.cpp:1021-1027
     if (s.lum > 0.f) {
         float inv = 1.f / s.lum;
@@ -355,7 +363,7 @@ DEV int mh_decide(const DParams &P, ChainState &cs, LdsSampler &smp, PathState &
         }
     } else {
         const float a = cs.do_second ? a2 : cs.a1;
-        const DSplat &pr = cs.do_second ? z : y;
+        const DSplat pr = select_splat(cs.do_second, z, y);
         if (1.f - a > 0.f) film_put(P, cur.px, cur.py, mk3(cur.r * (1.f - a), cur.g * (1.f - a), cur.b * (1.f - a)));
         if (a > 0.f) film_put(P, pr.px, pr.py, mk3(pr.r * a, pr.g * a, pr.b * a));
     }
@@ -371,7 +379,7 @@ DEV int mh_decide(const DParams &P, ChainState &cs, LdsSampler &smp, PathState &
     int commit = 0;
     if (acc1 || acc2) {
         commit = acc1 ? SM_STAGE1 : SM_STAGE2;
-        cs.cur = acc1 ? cs.y : cs.z;
+        cs.cur = select_splat(acc1, cs.y, cs.z);
         if (amap && !mix) {
             if (acc1) { if (!cs.large) film_put(P, cs.cur.px, cs.cur.py, mk3(1.f, 0.f, 0.f)); }
             else film_put(P, cs.cur.px, cs.cur.py, mk3(0.f, 1.f, 0.f));
@@ -488,8 +496,8 @@ __global__ void __launch_bounds__(CHAIN_BLOCK) k_mutate_v2(DParams P, uint32_t n
         if (tracing) h = trace(P, ps.o, ps.d, ps.tmin, ps.tmax, ps.phase == PH_SHADOW);
         const unsigned long long s2 = STAMP();
         if (ps.phase != PH_DONE && ps.phase != PH_IDLE) {
-            if (lds_tables) path_step<false>(P, LT, ps, smp, h, false, sr_unused);
-            else path_step<false>(P, GT, ps, smp, h, false, sr_unused);
+            if (lds_tables) path_step<false, 15>(P, LT, ps, smp, h, false, sr_unused);
+            else path_step<false, 15>(P, GT, ps, smp, h, false, sr_unused);
         }
         const unsigned long long s3 = STAMP();
         t_mh += s1 - s0; t_trace += s2 - s1; t_step += s3 - s2; n_iter++;
@@ -534,6 +542,7 @@ DEV unsigned from_upper_u(unsigned u) { // value of lane 32 + (l & 31) for every
     return __builtin_amdgcn_permlane32_swap(u, u, false, false)[1];
 }
 
+template <int FEAT>
 __global__ void __launch_bounds__(CHAIN_BLOCK) k_mutate_v3(DParams P, uint32_t n_mut, uint32_t mut_base) {
     const uint32_t lane = threadIdx.x;
     const uint32_t sub = lane & 31u;
@@ -615,15 +624,15 @@ __global__ void __launch_bounds__(CHAIN_BLOCK) k_mutate_v3(DParams P, uint32_t n
         const unsigned long long s1 = STAMP();
         const bool tracing = helper ? helper_has_ray : ps.phase == PH_CLOSEST;
         if (stamps) n_busy += __popcll(__ballot(tracing));
-        if (tracing) h = trace(P, ps.o, ps.d, ps.tmin, ps.tmax, helper);
+        if (tracing) h = trace<FEAT>(P, ps.o, ps.d, ps.tmin, ps.tmax, helper);
         const unsigned long long s2 = STAMP();
         const unsigned occluded = from_upper_u((helper_has_ray && h.prim >= 0) ? 1u : 0u);
         helper_has_ray = false;
         ShadowRay sr;
         sr.o = ps.o; sr.d = ps.d; sr.tmin = 0.f; sr.tmax = 0.f; sr.valid = false;
         if (!helper && ps.phase != PH_DONE && ps.phase != PH_IDLE) {
-            if (lds_tables) path_step<true>(P, LT, ps, smp, h, occluded == 0u, sr);
-            else path_step<true>(P, GT, ps, smp, h, occluded == 0u, sr);
+            if (lds_tables) path_step<true, FEAT>(P, LT, ps, smp, h, occluded == 0u, sr);
+            else path_step<true, FEAT>(P, GT, ps, smp, h, occluded == 0u, sr);
         }
         // hand the shadow ray of this vertex to the helper lane
         const float ox = from_lower(sr.o.x), oy = from_lower(sr.o.y), oz = from_lower(sr.o.z);
@@ -720,7 +729,8 @@ void launch_mutate(const DParams &P, uint32_t n_mut, uint32_t mut_base, hipStrea
     } else if (P.kernel_variant == 3) { // 32 chains per wave, rows of 32 floats
         size_t lds = (D + 2 * D4) * 32 * sizeof(float);
         if (P.tables_in_lds) lds += (size_t) P.n_prims * 64 + (size_t) P.n_bsdfs * 48 + (size_t) P.n_emitters * 32;
-        hipLaunchKernelGGL(k_mutate_v3, dim3((P.n_chains + 31) / 32), block, lds, st, P, n_mut, mut_base);
+        if (P.features == 0) hipLaunchKernelGGL(k_mutate_v3<0>, dim3((P.n_chains + 31) / 32), block, lds, st, P, n_mut, mut_base);
+        else hipLaunchKernelGGL(k_mutate_v3<15>, dim3((P.n_chains + 31) / 32), block, lds, st, P, n_mut, mut_base);
     } else { // x + first-stage uniforms + second-stage values, one 256 B row per dimension
         size_t lds = (D + 2 * D4) * 64 * sizeof(float);
         if (P.debug & 512) { grid = dim3((P.n_chains + 31) / 32); lds /= 2; }

@@ -11,7 +11,7 @@ chains = int(os.environ.get("CHAINS", 65536))
 spp = int(os.environ.get("SPP", 64))
 res = int(os.environ.get("RES", 512))
 typ = os.environ.get("TYPE", "orbital")
-sd = scenes.cornell_c2(res)
+sd = scenes.SCENES[os.environ.get("SCENE", "cornell_c2")](res)
 ctxs = {}
 for v in variants:
     env = dict(kv.split("=") for kv in v.split("+") if "=" in kv)
