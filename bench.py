@@ -85,7 +85,7 @@ def cpu_baseline(pkg, cfg_kw, res, target_seconds):
     cfg = abi.make_config(work_units=chains, luminance_samples=20000, **cfg_kw)
     orc = ob.Oracle(abi, cfg, sd, precision=64, native=True)
     orc.seed(0x5EED)
-    probe = chains * 64
+    probe = chains * 2048
     t = time.time()
     orc.run(probe, cores)
     rate = probe / max(time.time() - t, 1e-6)
@@ -207,7 +207,7 @@ def main():
                        "mutations_per_step_per_gpu": step_mutations, "parallelism": "chains partitioned x%d" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "k_mutate", "avg_launch_ms": launch_ms, "launches": launches,
+                         "kernel": "k_mutate_v3", "avg_launch_ms": launch_ms, "launches": launches,
                          "algorithmic_bytes_per_mutation": bytes_per_mut,
                          "mutations_per_launch": muts_per_launch},
             "accepted_mutations_per_s": world * accepted / elapsed,
