@@ -253,11 +253,19 @@ template <int FEAT = 15> DEV void intersect_prim(const DPrim &P, int idx, f3 o, 
     if (!(FEAT & 4) || P.type != PRIM_SPHERE) { // wave-uniform branch (compiled out for sphere-free scenes)
         float t = -lo.z * fast_rcp(ld.z);
         float u = fmaf(t, ld.x, lo.x), v = fmaf(t, ld.y, lo.y);
-        // triangle: u >= 0, v >= 0, u + v <= 1   rectangle: |u| <= 1, |v| <= 1
-        bool tri = P.type == PRIM_TRIANGLE;
-        float a = tri ? u : 1.f - fabsf(u), b = tri ? v : 1.f - fabsf(v), c = tri ? 1.f - (u + v) : 0.f;
-        bool hit = fminf(fminf(a, b), c) >= 0.f && t >= tmin && t <= h.t;
-        h.prim = hit ? idx : h.prim;
+        // triangle: u, v, 1-u-v >= 0; parallelogram (rectangle or merged triangle pair): u, v, 1-u, 1-v >= 0.
+        // The kind is wave-uniform (SGPR), so this is selects on a scalar condition, no exec-mask traffic.
+        const bool tri = P.type == PRIM_TRIANGLE;
+        const float w = tri ? 1.f - (u + v) : fminf(1.f - u, 1.f - v);
+        bool hit = fminf(fminf(u, v), w) >= 0.f && t >= tmin && t <= h.t;
+        int id = idx;
+        if (P.type == PRIM_QUAD2) { // sub-triangle (a,b,c) for v <= u, (a,c,d) otherwise; its own barycentrics
+            const bool second = v > u;
+            id = idx + (second ? 1 : 0);
+            const float uu = second ? u : u - v, vv = second ? v - u : v;
+            u = uu; v = vv;
+        }
+        h.prim = hit ? id : h.prim;
         h.t = hit ? t : h.t;
         h.u = hit ? u : h.u;
         h.v = hit ? v : h.v;
@@ -293,7 +301,7 @@ template <int FEAT = 15> DEV Hit trace_brute(const DParams &P, f3 o, f3 d, float
     Hit h{-1, tmax, 0.f, 0.f};
     const int n = P.n_prims;
     if (P.debug & 64) { // A/B: vector-memory path
-        for (int i = 0; i < n; ++i) intersect_prim(P.prims[i], i, o, d, tmin, h);
+        for (int i = 0; i < n; ++i) intersect_prim(P.prims[i], P.prims[i].shade, o, d, tmin, h);
         return h;
     }
     ScalarPrimPtr sp = (ScalarPrimPtr) (uintptr_t) P.prims;
@@ -302,22 +310,24 @@ template <int FEAT = 15> DEV Hit trace_brute(const DParams &P, f3 o, f3 d, float
     auto load = [&](int i, DPrim &G) {
 #pragma unroll
         for (int k = 0; k < 12; ++k) G.m[k] = sp[i].m[k];
-        G.type = sp[i].type;
+        const int ks = sp[i].kind_shade; // one scalar dword: kind in the low byte, shading record index above
+        G.type = ks & 0xff;
+        G.shade = ks >> 8;
     };
     // SMEM returns out of order, so the only wait is lgkmcnt(0) = "everything outstanding". The
     // empty asm pins that wait on record X BEFORE the request for the other record is issued;
     // otherwise the compiler's wait for X (placed at X's first use) would also wait for the
     // record just requested and the pipeline would collapse to one load at a time.
-#define PIN(G) asm volatile("" ::"s"(G.m[0]), "s"(G.m[4]), "s"(G.m[8]), "s"(G.type))
+#define PIN(G) asm volatile("" ::"s"(G.m[0]), "s"(G.m[4]), "s"(G.m[8]), "s"(G.type), "s"(G.shade))
     DPrim A, B;
     load(0, A);
     for (int i = 0; i < n; i += 2) {
         PIN(A);
         load(i + 1 < n ? i + 1 : i, B);
-        intersect_prim<FEAT>(A, i, o, d, tmin, h);
+        intersect_prim<FEAT>(A, A.shade, o, d, tmin, h);
         PIN(B);
         load(i + 2 < n ? i + 2 : i, A);
-        if (i + 1 < n) intersect_prim<FEAT>(B, i + 1, o, d, tmin, h);
+        if (i + 1 < n) intersect_prim<FEAT>(B, B.shade, o, d, tmin, h);
     }
 #undef PIN
     return h;
@@ -348,13 +358,13 @@ DEV Hit trace_bvh(const DParams &P, f3 o, f3 d, float tmin, float tmax, bool any
         int cA = N.c0, cB = N.c1, nA = N.n0, nB = N.n1;
         if (hitA && cA < 0) {
             int first = ~cA;
-            for (int i = 0; i < nA; ++i) intersect_prim(P.prims[first + i], first + i, o, d, tmin, h);
+            for (int i = 0; i < nA; ++i) intersect_prim(P.prims[first + i], P.prims[first + i].shade, o, d, tmin, h);
             hitA = false;
         }
         if (hitB && cB < 0) {
             int first = ~cB;
             if (nearB <= h.t)
-                for (int i = 0; i < nB; ++i) intersect_prim(P.prims[first + i], first + i, o, d, tmin, h);
+                for (int i = 0; i < nB; ++i) intersect_prim(P.prims[first + i], P.prims[first + i].shade, o, d, tmin, h);
             hitB = false;
         }
         if (any_hit && h.prim >= 0) return h;
@@ -428,7 +438,7 @@ struct LdsTables {
 // cooperative copy of the three tables into LDS by one wave
 DEV void stage_tables(const DParams &P, const LdsTables &T, uint32_t lane) {
     const float *src = reinterpret_cast<const float *>(P.shade);
-    for (uint32_t i = lane; i < (uint32_t) P.n_prims * 16u; i += 64u) lds_x[T.shade_off + i] = src[i];
+    for (uint32_t i = lane; i < (uint32_t) P.n_shade * 16u; i += 64u) lds_x[T.shade_off + i] = src[i];
     src = reinterpret_cast<const float *>(P.bsdfs);
     for (uint32_t i = lane; i < (uint32_t) P.n_bsdfs * 12u; i += 64u) lds_x[T.bsdf_off + i] = src[i];
     src = reinterpret_cast<const float *>(P.emitters);
@@ -654,7 +664,7 @@ DEV void path_step(const DParams &P, const TablesT &T, PathState &ps, SamplerT &
             const DShade L = T.shade(E.prim);
             f3 lp;
             if ((L.bsdf >> 24) == PRIM_RECTANGLE) { // rectangle.cpp:210-216
-                lp = fma3(ld3(L.eu), sx * 2.f - 1.f, fma3(ld3(L.ev), sy * 2.f - 1.f, ld3(L.origin)));
+                lp = fma3(ld3(L.eu), sx, fma3(ld3(L.ev), sy, ld3(L.origin))); // origin = corner (-1,-1), eu/ev = full edges
             } else { // single triangle: squareToUniformTriangle
                 float a = sqrtf(fmaxf(0.f, 1.f - sx));
                 lp = fma3(ld3(L.eu), 1.f - a, fma3(ld3(L.ev), a * sy, ld3(L.origin)));

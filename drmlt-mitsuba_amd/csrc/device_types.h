@@ -13,7 +13,9 @@
 
 #define DRMLT_MAX_LDS_PRIMS 96
 
-enum { PRIM_TRIANGLE = 0, PRIM_RECTANGLE = 1, PRIM_SPHERE = 2 };
+// PRIM_QUAD2: two triangles (a,b,c), (a,c,d) that form a parallelogram, intersected once; the hit is
+// attributed to the sub-triangle it falls in (two consecutive shading records), so f(u) is unchanged
+enum { PRIM_TRIANGLE = 0, PRIM_RECTANGLE = 1, PRIM_SPHERE = 2, PRIM_QUAD2 = 3 };
 
 // World -> primitive space affine map (rows), so that one transform serves all three
 // primitive kinds: triangle -> barycentric (u,v,w); rectangle -> Mitsuba object space
@@ -21,7 +23,9 @@ enum { PRIM_TRIANGLE = 0, PRIM_RECTANGLE = 1, PRIM_SPHERE = 2 };
 struct DPrim {
     float m[12];
     int32_t type;
-    int32_t pad[3];
+    int32_t shade;      // index of the (first) shading record of this primitive
+    int32_t kind_shade; // type | shade << 8 (what the scalar loop loads)
+    int32_t pad;
 };
 
 struct DShade {
@@ -64,6 +68,7 @@ struct DParams {
     const DBvhNode *bvh;
     const float *filter_lut; // 32 entries (MTS_FILTER_RESOLUTION + 1)
     int32_t n_prims, n_emitters, n_bvh_nodes, use_bvh, n_bsdfs, tables_in_lds;
+    int32_t n_shade; // shading records (>= n_prims: a merged pair has two)
     // sensor + film
     float cam[12]; // camera-to-world rows (3x4)
     float tan_half_fov, inv_aspect, near_clip, far_clip;

@@ -172,10 +172,14 @@ std::string build_scene(drmlt_ctx *ctx, const drmlt_scene &s, std::vector<DBsdf>
             double n[3] = {inv[8], inv[9], inv[10]};
             double ln = std::sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
             g.type = PRIM_RECTANGLE;
+            // parametrise the rectangle on [0,1]^2 from its (-1,-1) corner: u' = (u + 1) / 2 (same test as a merged
+            // triangle pair). Shading record: origin = that corner, eu / ev = the full edge vectors.
+            for (int c = 0; c < 4; ++c) { inv[c] = 0.5 * inv[c] + (c == 3 ? 0.5 : 0.0); inv[4 + c] = 0.5 * inv[4 + c] + (c == 3 ? 0.5 : 0.0); }
             for (int k = 0; k < 3; ++k) {
-                sh.origin[k] = (float) m[k * 4 + 3]; sh.eu[k] = (float) eu[k]; sh.ev[k] = (float) ev[k]; sh.n[k] = (float) (n[k] / ln);
+                sh.origin[k] = (float) (m[k * 4 + 3] - eu[k] - ev[k]); sh.eu[k] = (float) (2.0 * eu[k]); sh.ev[k] = (float) (2.0 * ev[k]);
+                sh.n[k] = (float) (n[k] / ln);
             }
-            sh.inv_len_eu = (float) (1.0 / lu);
+            sh.inv_len_eu = (float) (1.0 / (2.0 * lu));
             sh.inv_area = (float) (1.0 / (4.0 * lu * lv)); // |dpdu| |dpdv| with dpdu = 2 eu
             for (int k = 0; k < 3; ++k) {
                 double c = m[k * 4 + 3], ext = std::fabs(eu[k]) + std::fabs(ev[k]);
@@ -196,9 +200,53 @@ std::string build_scene(drmlt_ctx *ctx, const drmlt_scene &s, std::vector<DBsdf>
         }
         for (int k = 0; k < 12; ++k) g.m[k] = (float) inv[k];
         sh.bsdf |= g.type << 24;
+        g.shade = (int32_t) ctx->shade.size();
         ctx->prims.push_back(g);
         ctx->shade.push_back(sh);
         bounds.push_back(pb);
+    }
+    // ---- merge triangle pairs (a,b,c),(a,c,d) that form a parallelogram into one intersection record.
+    // Exact: the hit is attributed to the sub-triangle it falls in, with that triangle's barycentrics and
+    // shading record, so every path is the one two separate triangles would give -- at half the tests.
+    if (!getenv("DRMLT_NO_QUAD_MERGE")) {
+        std::vector<DPrim> merged;
+        std::vector<PrimBounds> mb;
+        for (size_t i = 0; i < ctx->prims.size(); ++i) {
+            bool did = false;
+            if (i + 1 < ctx->prims.size() && s.shapes[i].type == DRMLT_SHAPE_TRIANGLE && s.shapes[i + 1].type == DRMLT_SHAPE_TRIANGLE &&
+                s.shapes[i].bsdf == s.shapes[i + 1].bsdf && s.shapes[i].emitter < 0 && s.shapes[i + 1].emitter < 0) {
+                const float *A = s.shapes[i].data, *B = s.shapes[i + 1].data; // A: a,b,c   B: a',c',d
+                bool shared = true;
+                for (int k = 0; k < 3; ++k) shared = shared && A[k] == B[k] && A[6 + k] == B[3 + k];
+                double a[3], b[3], c[3], d[3], e1[3], e2[3], n[3], err = 0, scale = 0;
+                for (int k = 0; k < 3; ++k) {
+                    a[k] = A[k]; b[k] = A[3 + k]; c[k] = A[6 + k]; d[k] = B[6 + k];
+                    err = std::max(err, std::fabs(d[k] - (a[k] + c[k] - b[k])));
+                    scale = std::max(scale, std::max(std::fabs(c[k] - a[k]), std::fabs(b[k] - a[k])));
+                    e1[k] = b[k] - a[k]; e2[k] = d[k] - a[k];
+                }
+                if (shared && err <= 1e-6 * scale) {
+                    n[0] = e1[1] * e2[2] - e1[2] * e2[1]; n[1] = e1[2] * e2[0] - e1[0] * e2[2]; n[2] = e1[0] * e2[1] - e1[1] * e2[0];
+                    double len = std::sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
+                    double m[12], inv[12];
+                    for (int r = 0; r < 3; ++r) { m[r * 4] = e1[r]; m[r * 4 + 1] = e2[r]; m[r * 4 + 2] = n[r] / len; m[r * 4 + 3] = a[r]; }
+                    if (len > 0 && invert3x4(m, inv)) {
+                        DPrim g{};
+                        for (int k = 0; k < 12; ++k) g.m[k] = (float) inv[k];
+                        g.type = PRIM_QUAD2;
+                        g.shade = (int32_t) i; // records i (a,b,c) and i+1 (a,c,d)
+                        PrimBounds pb = bounds[i];
+                        for (int k = 0; k < 3; ++k) { pb.lo[k] = std::min(pb.lo[k], bounds[i + 1].lo[k]); pb.hi[k] = std::max(pb.hi[k], bounds[i + 1].hi[k]); }
+                        merged.push_back(g); mb.push_back(pb);
+                        ++i;
+                        did = true;
+                    }
+                }
+            }
+            if (!did) { merged.push_back(ctx->prims[i]); mb.push_back(bounds[i]); }
+        }
+        ctx->prims.swap(merged);
+        bounds.swap(mb);
     }
     // emitters + DiscreteDistribution over sampling weights (scene.cpp m_emitterPDF, pmf.h:109-121)
     double total = 0;
@@ -325,15 +373,13 @@ drmlt_ctx *drmlt_create(const drmlt_config *cfg, const drmlt_scene *scene, int d
     if (P.use_bvh) {
         std::vector<int> order;
         build_bvh(bounds, nodes, order);
-        // reorder primitives into leaf order; remap emitter -> prim links
+        // intersection records go into leaf order; shading records stay where the emitters expect them
         std::vector<DPrim> np(order.size());
-        std::vector<DShade> ns(order.size());
-        std::vector<int> where(order.size());
-        for (size_t i = 0; i < order.size(); ++i) { np[i] = ctx->prims[order[i]]; ns[i] = ctx->shade[order[i]]; where[order[i]] = (int) i; }
-        ctx->prims.swap(np); ctx->shade.swap(ns);
-        for (auto &em : emitters) em.prim = where[em.prim];
+        for (size_t i = 0; i < order.size(); ++i) np[i] = ctx->prims[order[i]];
+        ctx->prims.swap(np);
     }
 
+    for (DPrim &g : ctx->prims) g.kind_shade = g.type | (g.shade << 8);
     auto up = [&](DevBuf &b, const void *src, size_t bytes) -> bool {
         if (b.alloc(std::max<size_t>(bytes, 64)) != hipSuccess) return false;
         return hipMemcpy(b.p, src, bytes, hipMemcpyHostToDevice) == hipSuccess;
@@ -357,10 +403,10 @@ drmlt_ctx *drmlt_create(const drmlt_config *cfg, const drmlt_scene *scene, int d
 
     P.prims = ctx->d_prims.as<DPrim>(); P.shade = ctx->d_shade.as<DShade>(); P.bsdfs = ctx->d_bsdfs.as<DBsdf>();
     P.emitters = ctx->d_emitters.as<DEmitter>(); P.bvh = ctx->d_bvh.as<DBvhNode>(); P.filter_lut = ctx->d_lut.as<float>();
-    P.n_prims = (int) ctx->prims.size(); P.n_emitters = (int) emitters.size(); P.n_bvh_nodes = (int) nodes.size();
+    P.n_prims = (int) ctx->prims.size(); P.n_shade = (int) ctx->shade.size(); P.n_emitters = (int) emitters.size(); P.n_bvh_nodes = (int) nodes.size();
     P.n_bsdfs = (int) bsdfs.size();
     // tables ride in LDS when they are small (Cornell class); 16 KB cap keeps 4+ waves per CU
-    P.tables_in_lds = (ctx->prims.size() * 64 + bsdfs.size() * 48 + emitters.size() * 32 <= 16384) ? 1 : 0;
+    P.tables_in_lds = (ctx->shade.size() * 64 + bsdfs.size() * 48 + emitters.size() * 32 <= 16384) ? 1 : 0;
     if (const char *t = getenv("DRMLT_TABLES_LDS")) P.tables_in_lds = atoi(t) ? P.tables_in_lds : 0;
     P.box_weight = cam.filter == DRMLT_FILTER_BOX ? lut[0] : 0.f;
     for (int r = 0; r < 3; ++r) for (int c = 0; c < 4; ++c) P.cam[r * 4 + c] = cam.to_world[r * 4 + c];

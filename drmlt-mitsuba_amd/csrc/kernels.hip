@@ -469,7 +469,7 @@ __global__ void __launch_bounds__(CHAIN_BLOCK) k_mutate_v2(DParams P, uint32_t n
     // scene tables: staged in LDS behind the sampler rows when they are small
     LdsTables LT;
     LT.shade_off = smp.s2_off + D4 * per_wave;
-    LT.bsdf_off = LT.shade_off + (uint32_t) P.n_prims * 16u;
+    LT.bsdf_off = LT.shade_off + (uint32_t) P.n_shade * 16u;
     LT.emit_off = LT.bsdf_off + (uint32_t) P.n_bsdfs * 12u;
     const GlobalTables GT{P.shade, P.bsdfs, P.emitters};
     const bool lds_tables = P.tables_in_lds != 0;
@@ -579,7 +579,7 @@ __global__ void __launch_bounds__(CHAIN_BLOCK) k_mutate_v3(DParams P, uint32_t n
     const int batch = P.mh_batch > 32 ? 32 : P.mh_batch;
     LdsTables LT;
     LT.shade_off = smp.s2_off + D4 * 32u;
-    LT.bsdf_off = LT.shade_off + (uint32_t) P.n_prims * 16u;
+    LT.bsdf_off = LT.shade_off + (uint32_t) P.n_shade * 16u;
     LT.emit_off = LT.bsdf_off + (uint32_t) P.n_bsdfs * 12u;
     const GlobalTables GT{P.shade, P.bsdfs, P.emitters};
     const bool lds_tables = P.tables_in_lds != 0;
@@ -728,13 +728,13 @@ void launch_mutate(const DParams &P, uint32_t n_mut, uint32_t mut_base, hipStrea
         hipLaunchKernelGGL(k_mutate, grid, block, D * 64 * sizeof(float), st, P, n_mut, mut_base);
     } else if (P.kernel_variant == 3) { // 32 chains per wave, rows of 32 floats
         size_t lds = (D + 2 * D4) * 32 * sizeof(float);
-        if (P.tables_in_lds) lds += (size_t) P.n_prims * 64 + (size_t) P.n_bsdfs * 48 + (size_t) P.n_emitters * 32;
+        if (P.tables_in_lds) lds += (size_t) P.n_shade * 64 + (size_t) P.n_bsdfs * 48 + (size_t) P.n_emitters * 32;
         if (P.features == 0) hipLaunchKernelGGL(k_mutate_v3<0>, dim3((P.n_chains + 31) / 32), block, lds, st, P, n_mut, mut_base);
         else hipLaunchKernelGGL(k_mutate_v3<15>, dim3((P.n_chains + 31) / 32), block, lds, st, P, n_mut, mut_base);
     } else { // x + first-stage uniforms + second-stage values, one 256 B row per dimension
         size_t lds = (D + 2 * D4) * 64 * sizeof(float);
         if (P.debug & 512) { grid = dim3((P.n_chains + 31) / 32); lds /= 2; }
-        if (P.tables_in_lds) lds += (size_t) P.n_prims * 64 + (size_t) P.n_bsdfs * 48 + (size_t) P.n_emitters * 32;
+        if (P.tables_in_lds) lds += (size_t) P.n_shade * 64 + (size_t) P.n_bsdfs * 48 + (size_t) P.n_emitters * 32;
         hipLaunchKernelGGL(k_mutate_v2, grid, block, lds, st, P, n_mut, mut_base);
     }
 }
