@@ -74,7 +74,7 @@ struct drmlt_ctx {
     double kernel_ms = 0.0, seed_ms = 0.0;
     double kt_ms = 0.0; uint64_t kt_launches = 0; // drmlt_kernel_time window
     uint64_t host_counters[9] = {0};
-    int slice = 256;
+    int slice = 1024; // mutations per chain per launch (<= 32768: the per-lane event counters are 16 bit)
 
     ~drmlt_ctx() {
         if (own_stream && stream) (void) hipStreamDestroy(stream);
@@ -567,7 +567,9 @@ int drmlt_run(drmlt_ctx *ctx, uint64_t total_mutations, volatile int *stop, drml
     int rc = DRMLT_OK;
     while (done < per_chain) {
         if (stop && *stop) { rc = DRMLT_E_CANCELLED; break; }
-        uint32_t n = (uint32_t) std::min<uint64_t>((uint64_t) ctx->slice, per_chain - done);
+        // shorter launches when somebody is watching (cancellation / progress latency ~ tens of ms)
+        const uint64_t slice = (stop || cb) ? std::min(ctx->slice, 256) : ctx->slice;
+        uint32_t n = (uint32_t) std::min<uint64_t>(slice, per_chain - done);
         hipEvent_t a, b;
         HIP_TRY(ctx, hipEventCreate(&a));
         HIP_TRY(ctx, hipEventCreate(&b));
