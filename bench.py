@@ -126,8 +126,11 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the DRMLT path has no CPU fallback")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    # BENCH_FORCE_DIST=1 rehearses the RCCL path (process group, zero-copy film tensor, exchange) on one GPU
+    use_dist = world > 1 or os.environ.get("BENCH_FORCE_DIST") == "1"
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29512")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     pkg = entry.load_package()
@@ -146,13 +149,13 @@ def main():
     step_mutations = npix * args.spp                                # per GPU
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
     def step():
         ctx.run(step_mutations)
-        if world > 1:  # the render's film exchange: sum of the per-GPU films, mean of the per-GPU b estimates
+        if use_dist:  # the render's film exchange: sum of the per-GPU films, mean of the per-GPU b estimates
             pkg.exchange.exchange_film(film, b_t, dist, out=film_sum, b_out=b_sum)
 
     for _ in range(args.warmup):
@@ -166,7 +169,7 @@ def main():
         step()
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         et = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(et, op=dist.ReduceOp.MAX)
         elapsed = float(et.item())
@@ -192,7 +195,8 @@ def main():
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc):
             try:
-                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+                # PMC passes were taken on 1.68e7-mutation launches; traffic is proportional to the mutation count
+                traffic = json.load(open(pmc)).get("hbm_bytes_per_mutation") * muts_per_launch
             except Exception:
                 traffic = None
         out = {
@@ -218,7 +222,7 @@ def main():
     # ---- image quality at the accumulated budget (outside the timed region)
     if not args.no_quality:
         b_mean = b_local
-        if world > 1:  # the local films hold `steps` renders each: combine them once and develop the sum
+        if use_dist:  # the local films hold `steps` renders each: combine them once and develop the sum
             pkg.exchange.exchange_film(film, b_t, dist, out=film_sum, b_out=b_sum)
             film.copy_(film_sum)
             torch.cuda.synchronize()
@@ -239,7 +243,7 @@ def main():
     if rank == 0:
         print(json.dumps(_clean(out)))
     ctx.close()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
