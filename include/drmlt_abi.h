@@ -104,7 +104,8 @@ typedef struct drmlt_config {
     int32_t  use_mixture;        /* "useMixture"       default 0                   */
     int32_t  kelemen_style_weights;  /* pssmlt: Kelemen weights (default 1)        */
     int32_t  kelemen_style_mutation; /* pssmlt: Kelemen (1) or Gaussian (0)        */
-    int32_t  reserved[8];
+    int32_t  no_light_image;     /* 1 = "lightImage" false (mmlt; default: true)   */
+    int32_t  reserved[7];
 } drmlt_config;
 
 /* ---- flat scene description -------------------------------------------- */

@@ -41,6 +41,10 @@ def lib(native=False):
         L.oracle_chain_state.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]
         L.oracle_render_pt.argtypes = [C.c_void_p, C.c_uint32, C.c_uint64, C.c_int, C.c_void_p]
         L.oracle_bootstrap_lum.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_void_p]
+        L.oracle_mmlt_render.argtypes = [C.c_void_p, C.c_int, C.c_uint64, C.c_uint64, C.c_int, C.c_int, C.c_void_p,
+                                         C.c_void_p]
+        L.oracle_mmlt_eval.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32,
+                                       C.c_uint32, C.c_void_p, C.c_void_p]
         L.oracle_philox.argtypes = [C.c_uint32] * 6 + [C.c_void_p]
         L.oracle_uniforms.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
                                       C.c_void_p]
@@ -57,6 +61,7 @@ def lib(native=False):
         L.oracle_film_put.argtypes = [C.c_int, C.c_int, C.c_int, C.c_double, C.c_uint32, C.c_void_p, C.c_void_p,
                                       C.c_void_p]
         L.oracle_find_max_dim.argtypes = [C.c_int, C.c_int]
+        L.oracle_find_max_dim_mmlt.argtypes = [C.c_int]
         L.oracle_roughconductor.argtypes = [C.c_int, C.c_double] + [C.c_void_p] * 3 + [C.c_uint32] + [C.c_void_p] * 7
         _libs[native] = L
     return _libs[native]
@@ -135,6 +140,25 @@ class Oracle:
         out = np.empty((self.height, self.width, 3), dtype=np.float32)
         self._chk(self.L.oracle_render_pt(self.h, spp, seed, nthreads, out.ctypes.data))
         return out
+
+    def mmlt_render(self, depth, n, seed=1, light_image=True, nthreads=1):
+        """Independent-sample image of the depth-`depth` paths with the multiplexed estimator (radiance units)."""
+        out = np.empty((self.height, self.width, 3), dtype=np.float32)
+        strat = np.zeros(depth + 2)
+        self._chk(self.L.oracle_mmlt_render(self.h, depth, n, seed, int(light_image), nthreads, out.ctypes.data,
+                                            strat.ctypes.data))
+        return out, strat
+
+    def mmlt_eval(self, depth, u_sensor, u_emitter, u_direct, light_image=True):
+        us = np.ascontiguousarray(u_sensor, dtype=np.float32)
+        ue = np.ascontiguousarray(u_emitter, dtype=np.float32)
+        ud = np.ascontiguousarray(u_direct, dtype=np.float32)
+        n, dim = us.shape
+        out = (self.abi.Splat * n)()
+        st = np.zeros((n, 2), dtype=np.int32)
+        self._chk(self.L.oracle_mmlt_eval(self.h, depth, int(light_image), us.ctypes.data, ue.ctypes.data,
+                                          ud.ctypes.data, n, dim, out, st.ctypes.data))
+        return np.frombuffer(out, dtype=SPLAT_DTYPE).copy(), st
 
     def bootstrap_lum(self, seed, stream, n):
         out = np.empty(n, dtype=np.float32)

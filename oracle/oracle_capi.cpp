@@ -4,6 +4,7 @@
 // loaded by tests/ through ctypes. Consumes the same POD structs as the product
 // ABI (include/drmlt_abi.h) so both sides see identical inputs.
 #include "oracle_process.hpp"
+#include "oracle_bidir.hpp"
 #include <atomic>
 #include <cstdio>
 #include <thread>
@@ -34,6 +35,9 @@ struct CtxBase {
     virtual int chainState(drmlt_splat *cur, float *u, uint32_t dim) = 0;
     virtual int renderPT(uint32_t spp, uint64_t seed, int nthreads, float *out) = 0;
     virtual int bootstrapLum(uint64_t seed, uint32_t stream, uint32_t n, float *out) = 0;
+    virtual int mmltRender(int depth, uint64_t n, uint64_t seed, int lightImage, int nthreads, float *out, double *strat) = 0;
+    virtual int mmltEval(int depth, int lightImage, const float *uSensor, const float *uEmitter, const float *uDirect,
+                         uint32_t n, uint32_t dim, drmlt_splat *out, int *st) = 0;
     std::string error;
 };
 
@@ -44,6 +48,10 @@ template <typename F> struct Ctx : CtxBase {
     SceneEvaluator<F> eval;
     std::vector<std::unique_ptr<DRChain<F, SceneEvaluator<F>>>> chains;
     std::vector<std::unique_ptr<PSSMLTChain<F, SceneEvaluator<F>>>> pchains;
+    using MChain = DRChain<F, MMLTEvaluator<F>, MMLTSamplers<F>>;
+    MMLTEvaluator<F> meval;
+    std::vector<std::unique_ptr<MChain>> mchains;
+    bool mmlt = false;
     std::vector<double> accum;
     Stats st;
     double b = 0;
@@ -51,7 +59,15 @@ template <typename F> struct Ctx : CtxBase {
 
     std::string init(const drmlt_config &in, const drmlt_scene &s) {
         cfg = in;
-        if (in.technique != DRMLT_TECH_PATH) return "oracle: only technique=path is restated";
+        if (in.technique != DRMLT_TECH_PATH && in.technique != DRMLT_TECH_MMLT) return "oracle: technique=bdpt is not restated";
+        mmlt = in.technique == DRMLT_TECH_MMLT;
+        if (mmlt && in.max_depth <= 0) return "Impossible to use MMLT with no max depth"; // drmlt.cpp:213-215
+        if (mmlt && in.algo == DRMLT_ALGO_PSSMLT) return "oracle: pssmlt over technique=mmlt is not restated";
+        // A rejected large step re-draws the strategy; its second stage (and Green's reverse path) then reads an
+        // emitter state that may be empty (drmlt_sampler.cpp:189-191 with an unused emitter sampler): undefined
+        // behaviour in the reference, refused here.
+        if (mmlt && in.timid_after_large) return "timidAfterLarge is not defined for technique=mmlt";
+        if (!mmlt && in.fix_emitter_path) return "Impossible to use fixEmitterPath without MMLT"; // drmlt.cpp:333-337
         if (in.max_depth <= 0) return "technique=path requires a finite maxDepth (pssmlt_utils.h:63)";
         if (in.scale_second > 1) return "scaleSecond is bigger than the first stage";
         if (in.work_units <= 0) return "work_units must be positive";
@@ -64,6 +80,8 @@ template <typename F> struct Ctx : CtxBase {
         c.kelemenMutation = in.kelemen_style_mutation != 0;
         c.pLarge = in.p_large; c.sigma = in.sigma; c.scaleSecond = in.scale_second;
         c.maxDim = findMaxDimensionsPath(in.max_depth, in.rr_depth);
+        c.fixEmitterPath = in.fix_emitter_path != 0; c.lightImage = in.no_light_image == 0;
+        meval = MMLTEvaluator<F>{&scene, c.maxDepth, c.separateDirect, c.lightImage};
         if (c.acceptanceMap && scene.filterType != DRMLT_FILTER_BOX) return "Box filter required for acceptance map!";
         eval = SceneEvaluator<F>{&scene, c.maxDepth, c.rrDepth, c.separateDirect};
         accum.assign((size_t) scene.width * scene.height * 3, 0.0);
@@ -89,6 +107,7 @@ template <typename F> struct Ctx : CtxBase {
         SplatList<F> l;
         for (uint32_t i = 0; i < n; ++i) {
             s.setSampleIndex(i);
+            if (mmlt) { s.depth = (int) (i % (uint32_t) cfg.max_depth) + 1; meval(s, l, nullptr); out[i] = (float) l.luminance; continue; }
             eval(s, l, nullptr);
             out[i] = (float) l.luminance;
         }
@@ -98,16 +117,22 @@ template <typename F> struct Ctx : CtxBase {
     int seed(uint64_t seedv, uint32_t chainOffset, double *bOut) override {
         Random boot(seedv, chainOffset);
         std::vector<PathSeed> seeds;
-        size_t lumSamples = (size_t) std::max(cfg.luminance_samples, cfg.work_units * 10); // drmlt.cpp:454-466
-        b = generateSeeds<F>(eval, boot, lumSamples, (size_t) cfg.work_units, seeds);
+        // drmlt.cpp:454-473; technique=mmlt: x50 and one share per depth (initialisation on one core)
+        size_t lumSamples = (size_t) std::max(cfg.luminance_samples, cfg.work_units * (mmlt ? 50 : 10));
+        if (mmlt) lumSamples *= (size_t) cfg.max_depth;
+        b = mmlt ? generateSeeds<F>(meval, boot, lumSamples, (size_t) cfg.work_units, seeds, nullptr, cfg.max_depth)
+                 : generateSeeds<F>(eval, boot, lumSamples, (size_t) cfg.work_units, seeds);
         if (b == 0) { error = "The average image luminance appears to be zero!"; return DRMLT_E_ZERO_LUM; }
         if (cfg.acceptance_map) b = 1.0;                               // drmlt.cpp:550-552
         else if (cfg.average_luminance != -1.0f) b = cfg.average_luminance; // :555-558
         c.luminance = (F) b;
-        chains.clear(); pchains.clear();
+        chains.clear(); pchains.clear(); mchains.clear();
         for (int i = 0; i < cfg.work_units; ++i) {
             bool ok;
-            if (cfg.algo == DRMLT_ALGO_PSSMLT) {
+            if (mmlt) {
+                mchains.emplace_back(new MChain(c, meval, seedv, chainOffset + i, chainOffset));
+                ok = mchains.back()->init(seeds[i]);
+            } else if (cfg.algo == DRMLT_ALGO_PSSMLT) {
                 pchains.emplace_back(new PSSMLTChain<F, SceneEvaluator<F>>(c, eval, seedv, chainOffset + i, chainOffset));
                 ok = pchains.back()->init(seeds[i]);
             } else {
@@ -134,7 +159,8 @@ template <typename F> struct Ctx : CtxBase {
             for (;;) {
                 int i = next.fetch_add(1);
                 if (i >= cfg.work_units) break;
-                if (cfg.algo == DRMLT_ALGO_PSSMLT) pchains[i]->run(perChain, *films[t], tstats[t]);
+                if (mmlt) mchains[i]->run(perChain, *films[t], tstats[t]);
+                else if (cfg.algo == DRMLT_ALGO_PSSMLT) pchains[i]->run(perChain, *films[t], tstats[t]);
                 else chains[i]->run(perChain, *films[t], tstats[t]);
             }
         };
@@ -163,8 +189,8 @@ template <typename F> struct Ctx : CtxBase {
     }
     int chainState(drmlt_splat *cur, float *u, uint32_t dim) override {
         for (int i = 0; i < cfg.work_units; ++i) {
-            const SplatList<F> &l = cfg.algo == DRMLT_ALGO_PSSMLT ? pchains[i]->current() : chains[i]->current();
-            const std::vector<F> &x = cfg.algo == DRMLT_ALGO_PSSMLT ? pchains[i]->state() : chains[i]->state();
+            const SplatList<F> &l = mmlt ? mchains[i]->current() : cfg.algo == DRMLT_ALGO_PSSMLT ? pchains[i]->current() : chains[i]->current();
+            const std::vector<F> x = mmlt ? mchains[i]->state() : cfg.algo == DRMLT_ALGO_PSSMLT ? pchains[i]->state() : chains[i]->state();
             if (cur) {
                 cur[i].luminance = (float) l.luminance; cur[i].x = (float) l.px; cur[i].y = (float) l.py;
                 cur[i].rgb[0] = (float) l.value.x; cur[i].rgb[1] = (float) l.value.y; cur[i].rgb[2] = (float) l.value.z;
@@ -203,6 +229,66 @@ template <typename F> struct Ctx : CtxBase {
         // E[f(u) on pixel p] * (W*H) = pixel radiance estimate (samplePos uniform over the film)
         double scale = 1.0 / (double) spp;
         for (size_t i = 0; i < acc.size(); ++i) out[i] = (float) (acc[i] * scale);
+        return 0;
+    }
+
+    // independent-sample rendering with the multiplexed estimator at one path depth: n uniform PSS points,
+    // box-splatted, scaled to radiance units. strat[s] = mean luminance contributed by strategy s (MIS-weighted).
+    int mmltRender(int depth, uint64_t n, uint64_t seedv, int lightImage, int nthreads, float *out, double *strat) override {
+        nthreads = std::max(1, nthreads);
+        Bidir<F> bd(scene);
+        std::vector<std::vector<double>> acc(nthreads, std::vector<double>((size_t) scene.width * scene.height * 3, 0.0));
+        std::vector<std::vector<double>> ss(nthreads, std::vector<double>(depth + 2, 0.0));
+        auto work = [&](int t) {
+            Random rs(seedv, (uint32_t) (3 * t)), re(seedv, (uint32_t) (3 * t + 1)), rd(seedv, (uint32_t) (3 * t + 2));
+            ReplayableSampler<F> sensor(&rs), emitter(&re), direct(&rd);
+            SplatList<F> l;
+            for (uint64_t i = (uint64_t) t; i < n; i += (uint64_t) nthreads) {
+                uint32_t major = (uint32_t) (i / (uint64_t) nthreads);
+                rs.seek(TAG_PT, major, 0); re.seek(TAG_PT, major, 0); rd.seek(TAG_PT, major, 0);
+                int s_, t_;
+                bd.sampleSplatsMMLT(emitter, sensor, direct, depth, cfg.max_depth, cfg.direct_samples >= 0, lightImage != 0, l, s_, t_);
+                if (l.luminance > 0 && spectrumValid(l.value)) {
+                    int x = std::min(std::max((int) std::floor(l.px), 0), scene.width - 1);
+                    int y = std::min(std::max((int) std::floor(l.py), 0), scene.height - 1);
+                    double *px = &acc[t][((size_t) y * scene.width + x) * 3];
+                    px[0] += l.value.x; px[1] += l.value.y; px[2] += l.value.z;
+                    ss[t][s_] += l.luminance;
+                }
+            }
+        };
+        std::vector<std::thread> th;
+        for (int t = 1; t < nthreads; ++t) th.emplace_back(work, t);
+        work(0);
+        for (auto &x : th) x.join();
+        double scale = (double) scene.width * scene.height / (double) n;
+        for (size_t i = 0; i < acc[0].size(); ++i) {
+            double v = 0;
+            for (int t = 0; t < nthreads; ++t) v += acc[t][i];
+            out[i] = (float) (v * scale);
+        }
+        if (strat) for (int s_ = 0; s_ <= depth + 1; ++s_) {
+            double v = 0;
+            for (int t = 0; t < nthreads; ++t) v += ss[t][s_];
+            strat[s_] = v / (double) n;
+        }
+        return 0;
+    }
+
+    int mmltEval(int depth, int lightImage, const float *uSensor, const float *uEmitter, const float *uDirect, uint32_t n,
+                 uint32_t dim, drmlt_splat *out, int *st) override {
+        Bidir<F> bd(scene);
+        for (uint32_t i = 0; i < n; ++i) {
+            ArraySampler<F> sensor(uSensor + (size_t) i * dim, dim), emitter(uEmitter + (size_t) i * dim, dim), direct(uDirect + i, 1);
+            SplatList<F> l;
+            int s_, t_;
+            bd.sampleSplatsMMLT(emitter, sensor, direct, depth, cfg.max_depth, cfg.direct_samples >= 0, lightImage != 0, l, s_, t_);
+            out[i].luminance = (float) l.luminance;
+            out[i].x = (float) l.px; out[i].y = (float) l.py;
+            out[i].rgb[0] = (float) l.value.x; out[i].rgb[1] = (float) l.value.y; out[i].rgb[2] = (float) l.value.z;
+            out[i].n_dims = (int) (sensor.sampleIndex + emitter.sampleIndex + direct.sampleIndex); out[i].n_rays = l.nRays;
+            if (st) { st[2 * i] = s_; st[2 * i + 1] = t_; }
+        }
         return 0;
     }
 };
@@ -250,6 +336,8 @@ int oracle_stats_get(void *p, drmlt_stats *out) { GUARD(static_cast<CtxBase *>(p
 int oracle_chain_state(void *p, drmlt_splat *cur, float *u, uint32_t dim) { GUARD(static_cast<CtxBase *>(p)->chainState(cur, u, dim)) }
 int oracle_render_pt(void *p, uint32_t spp, uint64_t seed, int nthreads, float *out) { GUARD(static_cast<CtxBase *>(p)->renderPT(spp, seed, nthreads, out)) }
 int oracle_bootstrap_lum(void *p, uint64_t seed, uint32_t stream, uint32_t n, float *out) { GUARD(static_cast<CtxBase *>(p)->bootstrapLum(seed, stream, n, out)) }
+int oracle_mmlt_render(void *p, int depth, uint64_t n, uint64_t seed, int lightImage, int nthreads, float *out, double *strat) { GUARD(static_cast<CtxBase *>(p)->mmltRender(depth, n, seed, lightImage, nthreads, out, strat)) }
+int oracle_mmlt_eval(void *p, int depth, int lightImage, const float *uSensor, const float *uEmitter, const float *uDirect, uint32_t n, uint32_t dim, drmlt_splat *out, int *st) { GUARD(static_cast<CtxBase *>(p)->mmltEval(depth, lightImage, uSensor, uEmitter, uDirect, n, dim, out, st)) }
 
 // ---- unit-level entry points ------------------------------------------------
 
@@ -379,5 +467,6 @@ void oracle_roughconductor(int ggx, double alpha, const double *eta, const doubl
 }
 
 int oracle_find_max_dim(int maxDepth, int rrDepth) { return findMaxDimensionsPath(maxDepth, rrDepth); }
+int oracle_find_max_dim_mmlt(int depth) { return findMaxDimensionsMMLT(depth); }
 
 } // extern "C"

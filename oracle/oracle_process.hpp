@@ -101,6 +101,7 @@ struct Stats {
 struct PathSeed {
     uint32_t sampleIndex;
     double luminance;
+    int depth = -1; // technique=mmlt: the chain's fixed path depth
 };
 
 template <typename F> struct Config {
@@ -109,6 +110,7 @@ template <typename F> struct Config {
     F pLarge, sigma, scaleSecond;
     F luminance = 1; // b (pssmlt Kelemen weights)
     int maxDim;
+    bool fixEmitterPath = false, lightImage = true; // technique=mmlt
 };
 
 // Evaluator over a scene: PathSampler::sampleSplats(EUnidirectional)
@@ -152,7 +154,7 @@ template <typename F> struct ToyEvaluator {
 // pathsampler.cpp:859-960. Returns b; seeds sorted by sample index.
 template <typename F, typename Eval>
 inline double generateSeeds(const Eval &eval, Random &bootRandom, size_t sampleCount, size_t seedCount,
-                            std::vector<PathSeed> &seeds, std::vector<float> *lumOut = nullptr) {
+                            std::vector<PathSeed> &seeds, std::vector<float> *lumOut = nullptr, int mmltMaxDepth = 0) {
     ReplayableSampler<F> sampler(&bootRandom);
     std::vector<PathSeed> tempSeeds;
     tempSeeds.reserve(sampleCount);
@@ -161,16 +163,19 @@ inline double generateSeeds(const Eval &eval, Random &bootRandom, size_t sampleC
     if (lumOut) lumOut->assign(sampleCount, 0.f);
     for (size_t i = 0; i < sampleCount; ++i) {
         sampler.setSampleIndex((uint32_t) i);
+        int depth = mmltMaxDepth > 0 ? (int) (i % (size_t) mmltMaxDepth) + 1 : -1; // :884-890
+        sampler.depth = depth;
         eval(sampler, list, nullptr);
         F lum = list.luminance;
         if (lumOut) (*lumOut)[i] = (float) lum;
         if (std::isnan(lum)) continue;
         tok += 1;
-        if (lum != 0) tempSeeds.push_back(PathSeed{(uint32_t) i, (double) lum});
+        if (lum != 0) tempSeeds.push_back(PathSeed{(uint32_t) i, (double) lum, depth});
         F delta = lum - mean; // Knuth / Welford
         mean += delta / tok;
         variance += delta * (lum - mean);
     }
+    if (mmltMaxDepth > 0) mean *= (F) mmltMaxDepth; // "As we split the path by corresponding depth", :932-934
     if (mean == 0) return 0;
     // DiscreteDistribution over the non-zero samples (pmf.h)
     std::vector<F> cdf(tempSeeds.size() + 1);
@@ -202,16 +207,17 @@ template <typename F> inline bool flipCoin(F x, Random &random, uint32_t mutatio
 
 // One DRMLT Markov chain: drmlt_proc.cpp:386-771 (and :161-380 when useMixture).
 // `mutationBase` is the chain-local index of the first mutation (continues across calls).
-template <typename F, typename Eval> class DRChain {
+// `SamplerT` is one DRMLTSampler (technique=path) or the sensor/emitter/direct triple of technique=mmlt.
+template <typename F, typename Eval, typename SamplerT = DRMLTSampler<F>> class DRChain {
 public:
     DRChain(const Config<F> &cfg, const Eval &eval, uint64_t seed, uint32_t chainId, uint32_t bootStream)
-        : m_cfg(cfg), m_eval(eval), m_random(seed, chainId), m_boot(seed, bootStream),
-          m_sampler((DRType) cfg.type, cfg.sigma, cfg.scaleSecond, &m_random) {
+        : m_cfg(cfg), m_eval(eval), m_random(seed, chainId), m_boot(seed, bootStream), m_sampler(cfg, &m_random) {
         m_sampler.setMaxDim((size_t) cfg.maxDim);
     }
 
     // seed replay, drmlt_proc.cpp:467-514. Returns false on luminance mismatch.
     bool init(const PathSeed &seed) {
+        m_sampler.configureForSeed(seed.depth); // per-depth dimensions, :452-464
         m_sampler.reset();
         m_boot.seek(TAG_BOOT, seed.sampleIndex, 0);
         m_sampler.setRandom(&m_boot);
@@ -232,7 +238,7 @@ public:
     }
 
     const SplatList<F> &current() const { return m_current; }
-    const std::vector<F> &state() const { return m_sampler.uCurrent; }
+    std::vector<F> state() const { return m_sampler.stateVector(); }
     uint32_t mutationIndex() const { return m_mutation; }
 
 private:
@@ -271,7 +277,8 @@ private:
             if (!m_cfg.timidAfterLarge) doSecond = doSecond && !largeStep;
 
             if (doSecond) {
-                m_sampler.nextStage();
+                // fixEmitterPath: the emitter sampler moves in the second stage only for pure light tracing (:566-573)
+                m_sampler.nextStage(m_cfg.fixEmitterPath && m_current.t == 1);
                 m_eval(m_sampler, second, &st);
                 second.normalize();
                 if (!isInvalid(second.luminance)) {
@@ -369,7 +376,7 @@ private:
             bool doSecond = false;
             if (!largeStep) doSecond = flipCoin(F(0.5), m_random, m, 3);
             if (doSecond) {
-                m_sampler.nextStage();
+                m_sampler.nextStage(m_cfg.fixEmitterPath && m_current.t == 1); // :306-312
                 m_eval(m_sampler, proposed, &st);
                 proposed.normalize();
                 if (isInvalid(proposed.luminance)) { a = 0; accept = false; }
@@ -398,7 +405,7 @@ private:
     Config<F> m_cfg;
     Eval m_eval;
     Random m_random, m_boot;
-    DRMLTSampler<F> m_sampler;
+    SamplerT m_sampler;
     SplatList<F> m_current;
     uint32_t m_mutation = 0;
 };

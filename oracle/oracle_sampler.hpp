@@ -179,6 +179,7 @@ template <typename F> struct Sampler {
 template <typename F> struct ReplayableSampler : Sampler<F> {
     Random *random;
     uint32_t current = 0;
+    int depth = -1; // technique=mmlt: path depth of the bootstrap sample being drawn (pathsampler.cpp:884-890)
     explicit ReplayableSampler(Random *r) : random(r) {}
     void setSampleIndex(uint32_t i) { current = i; random->seek(TAG_BOOT, i, 0); this->sampleIndex = 0; }
     F next1D() override { ++this->sampleIndex; return (F) random->nextFloat(); }
@@ -194,6 +195,9 @@ public:
         : m_random(random), m_type(type), m_sigma(sigma), m_scaleSecond(scaleSecond) {
         configureStages();
     }
+    template <typename Cfg>
+    DRMLTSampler(const Cfg &cfg, Random *random) : DRMLTSampler((DRType) cfg.type, cfg.sigma, cfg.scaleSecond, random) {}
+    void configureForSeed(int /*depth*/) {} // technique=path: dimensions do not depend on the seed
 
     // drmlt_sampler.cpp:121-164
     void configureStages() {
@@ -224,6 +228,10 @@ public:
     void setMaxDim(size_t d) { m_maxDim = d; }
     void setRandom(Random *r) { m_random = r; }
     void setMutation(uint32_t m) { m_mutation = m; }
+    // first draw index of this sampler inside a (tag, mutation) stream: the three samplers of
+    // technique=mmlt share one Random (drmlt_proc.cpp:489-492) and get disjoint index ranges here
+    void setDrawBase(uint32_t b) { m_drawBase = b; }
+    std::vector<F> stateVector() const { return uCurrent; }
     void setReverse(bool v) { this->sampleIndex = 0; isReverse = v; } // Green only
     void nextStage(bool lightTracing = false) {
         this->sampleIndex = 0;
@@ -300,7 +308,7 @@ private:
     // drmlt_sampler.cpp:313-332 (iid) and :339-394 (orbital, pairwise)
     void fillSpace(bool first) {
         std::vector<F> &uProposed = first ? uFirst : uSecond;
-        m_random->seek(first ? TAG_S1 : TAG_S2, m_mutation, 0);
+        m_random->seek(first ? TAG_S1 : TAG_S2, m_mutation, m_drawBase);
         const TransitionKernel<F> &kern = currentKernel();
         for (size_t i = 0; i < m_maxDim; ++i) {
             if (m_largeStep) {
@@ -342,7 +350,7 @@ private:
     const F m_rho = std::exp(F(-0.25)), m_kelemenScale = F(1.9); // :204-205
     size_t m_maxDim = 80;
     bool m_largeStep = false, m_replay = false;
-    uint32_t m_mutation = 0;
+    uint32_t m_mutation = 0, m_drawBase = 0;
 };
 
 // ---------------------------------------------------------------- PSSMLTSampler

@@ -456,7 +456,9 @@ public:
         return 0;
     }
     // returns weight = f*cos/pdf; `delta`: sampled a Dirac component
-    V3<F> bsdfSample(const Bsdf<F> &b, const V3<F> &wi, F sx, F sy, V3<F> &wo, F &pdf, F &eta, bool &delta) const {
+    // `mode`: 1 = ERadiance (default), 0 = EImportance -- only the dielectric's radiance scaling depends on it
+    V3<F> bsdfSample(const Bsdf<F> &b, const V3<F> &wi, F sx, F sy, V3<F> &wo, F &pdf, F &eta, bool &delta,
+                     int mode = 1) const {
         eta = 1; delta = false;
         if (b.type == DRMLT_BSDF_DIFFUSE) {
             if (wi.z <= 0) return V3<F>(0);
@@ -478,8 +480,36 @@ public:
         wo = V3<F>(scale * wi.x, scale * wi.y, cosThetaT);
         eta = cosThetaT < 0 ? b.eta : b.invEta;
         pdf = 1 - Fr;
-        F factor = cosThetaT < 0 ? b.invEta : b.eta; // radiance scaling across the interface
+        F factor = mode == 1 ? (cosThetaT < 0 ? b.invEta : b.eta) : F(1); // radiance scaling across the interface
         return V3<F>(factor * factor);
+    }
+    // dielectric.cpp:227-276, discrete measure (used by the bidirectional vertices for the reverse quantities)
+    static constexpr F DeltaEpsilon = F(1e-3);
+    bool dielectricMatch(const Bsdf<F> &b, const V3<F> &wi, const V3<F> &wo, F &Fr, F &cosThetaT, bool &reflection) const {
+        Fr = fresnelDielectricExt(wi.z, cosThetaT, b.eta);
+        if (wi.z * wo.z >= 0) {
+            reflection = true;
+            return !(std::abs(dot(V3<F>(-wi.x, -wi.y, wi.z), wo) - 1) > DeltaEpsilon);
+        }
+        reflection = false;
+        F scale = -(cosThetaT < 0 ? b.invEta : b.eta);
+        return !(std::abs(dot(V3<F>(scale * wi.x, scale * wi.y, cosThetaT), wo) - 1) > DeltaEpsilon);
+    }
+    F bsdfPdfDelta(const Bsdf<F> &b, const V3<F> &wi, const V3<F> &wo) const {
+        if (b.type != DRMLT_BSDF_DIELECTRIC) return 0;
+        F Fr, cosThetaT;
+        bool refl;
+        if (!dielectricMatch(b, wi, wo, Fr, cosThetaT, refl)) return 0;
+        return refl ? Fr : 1 - Fr;
+    }
+    V3<F> bsdfEvalDelta(const Bsdf<F> &b, const V3<F> &wi, const V3<F> &wo, int mode) const {
+        if (b.type != DRMLT_BSDF_DIELECTRIC) return V3<F>(0);
+        F Fr, cosThetaT;
+        bool refl;
+        if (!dielectricMatch(b, wi, wo, Fr, cosThetaT, refl)) return V3<F>(0);
+        if (refl) return V3<F>(Fr);
+        F factor = mode == 1 ? (cosThetaT < 0 ? b.invEta : b.eta) : F(1);
+        return V3<F>(factor * factor * (1 - Fr));
     }
 
     // ---- sensor: perspective.cpp:271-300 ---------------------------------
@@ -523,6 +553,7 @@ template <typename F> struct SplatList {
     V3<F> value;
     F luminance = 0;
     int nDims = 0, nRays = 0;
+    int s = 0, t = 0; // technique=mmlt: SplatList::setStrategy (pathsampler.cpp:129)
     void normalize() { // pathsampler.cpp:1001-1028 (no importance map)
         if (luminance > 0) value *= F(1) / luminance;
     }
