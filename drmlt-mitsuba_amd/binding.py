@@ -142,6 +142,21 @@ class Context:
         self._chk(self.L.drmlt_eval_paths(self.h, u.ctypes.data, n, dim, out))
         return np.frombuffer(out, dtype=SPLAT_DTYPE).copy()
 
+    def eval_paths_mmlt(self, depth, u_sensor, u_emitter, u_direct):
+        """technique=mmlt: points are [sensor S | emitter E | direct | depth]; returns (splats, (s, t))."""
+        S, E = 2 * (self.cfg.max_depth + 1), 2 * self.cfg.max_depth
+        us, ue = np.asarray(u_sensor, dtype=np.float32), np.asarray(u_emitter, dtype=np.float32)
+        n = us.shape[0]
+        u = np.zeros((n, S + E + 2), dtype=np.float32)
+        u[:, :min(S, us.shape[1])] = us[:, :S]
+        u[:, S:S + min(E, ue.shape[1])] = ue[:, :E]
+        u[:, S + E] = np.asarray(u_direct, dtype=np.float32)
+        u[:, S + E + 1] = depth
+        sp = self.eval_paths(u)
+        st = np.stack([(sp["n_dims"] >> 8) & 0xff, (sp["n_dims"] >> 16) & 0xff], axis=1)
+        sp["n_dims"] &= 0xff
+        return sp, st
+
     def film(self):
         out = np.empty((self.height, self.width, 3), dtype=np.float32)
         self._chk(self.L.drmlt_film_read(self.h, out.ctypes.data))

@@ -91,6 +91,14 @@ struct DParams {
     int32_t kernel_variant; // 1: k_mutate (nested loops), 2: k_mutate_v2 (lane state machines), 3: k_mutate_v3 (2 lanes per chain)
     int32_t features;       // bit 0 rough conductor, bit 1 dielectric, bit 2 spheres, bit 3 BVH traversal needed
     int32_t mh_batch;       // k_mutate_v2: parked lanes needed before the bookkeeping branch is taken
+    // technique=mmlt (device_bidir.h)
+    int32_t technique;        // DRMLT_TECH_*
+    int32_t light_image;      // "lightImage"
+    int32_t fix_emitter_path; // "fixEmitterPath"
+    int32_t mmlt_S, mmlt_E;   // state rows of the sensor / emitter segments: 2 (maxDepth + 1), 2 maxDepth
+    int32_t mmlt_dmax;        // findMaxDimensions of the deepest chain: draw bases 2 dmax (emitter), 4 dmax (direct)
+    int32_t *chain_depth;     // [n] path depth of each chain (fixed by its seed)
+    int32_t *cur_t;           // [n] sensor-subpath length t of the current state (light tracing: t == 1)
 };
 
 // result of one PSS evaluation, SoA-friendly

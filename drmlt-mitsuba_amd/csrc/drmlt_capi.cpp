@@ -21,6 +21,11 @@ void launch_bootstrap(const DParams &P, uint32_t n, float *lum_out, hipStream_t 
 void launch_init_chains(const DParams &P, const uint32_t *seed_index, const float *seed_lum, hipStream_t st);
 void launch_mutate(const DParams &P, uint32_t n_mut, uint32_t mut_base, hipStream_t st);
 void launch_eval_paths(const DParams &P, const float *u, uint32_t n, uint32_t dim, float *out8, hipStream_t st);
+// technique=mmlt (kernels_mmlt.hip)
+void launch_bootstrap_mmlt(const DParams &P, uint32_t n, float *lum_out, hipStream_t st);
+void launch_init_chains_mmlt(const DParams &P, const uint32_t *seed_index, const float *seed_lum, hipStream_t st);
+void launch_mutate_mmlt(const DParams &P, uint32_t n_mut, uint32_t mut_base, hipStream_t st);
+void launch_eval_paths_mmlt(const DParams &P, const float *u, uint32_t n, uint32_t dim, float *out8, hipStream_t st);
 void launch_render_pt(const DParams &P, uint64_t n_samples, uint32_t stream, float scale, hipStream_t st);
 void launch_lum_sum(const float *film, uint32_t n_pixels, double *sum, hipStream_t st);
 void launch_develop(const float *film, const float *direct, float factor, uint32_t n, float *out, hipStream_t st);
@@ -62,7 +67,7 @@ struct drmlt_ctx {
     DParams P{};
     std::string error;
 
-    DevBuf d_prims, d_shade, d_bsdfs, d_emitters, d_bvh, d_lut, d_film, d_x, d_cur, d_stats, d_err, d_scratch;
+    DevBuf d_prims, d_shade, d_bsdfs, d_emitters, d_bvh, d_lut, d_film, d_x, d_cur, d_stats, d_err, d_scratch, d_chain_i;
     std::vector<DPrim> prims;
     std::vector<DShade> shade;
 
@@ -337,8 +342,13 @@ drmlt_ctx *drmlt_create(const drmlt_config *cfg, const drmlt_scene *scene, int d
     if (cfg->technique == DRMLT_TECH_MMLT && cfg->max_depth == -1) return bail(nullptr, "Impossible to use MMLT with no max depth");
     if (cfg->fix_emitter_path && cfg->technique != DRMLT_TECH_MMLT) return bail(nullptr, "Impossible to use fixEmitterPath without MMLT");
     if (cfg->scale_second > 1.0f) return bail(nullptr, "scaleSecond is bigger than the first stage");
-    if (cfg->technique != DRMLT_TECH_PATH) return bail(nullptr, "technique: only `path` has a device implementation so far (bdpt/mmlt: SURVEY 8f)");
+    if (cfg->technique == DRMLT_TECH_BDPT) return bail(nullptr, "technique=bdpt has no device implementation yet (SURVEY 8f)");
+    const bool mmlt = cfg->technique == DRMLT_TECH_MMLT;
     if (cfg->max_depth <= 0) return bail(nullptr, "technique=path needs a finite maxDepth (pssmlt_utils.h:63)");
+    if (mmlt && cfg->max_depth > 24) return bail(nullptr, "technique=mmlt: maxDepth above 24 is not supported on the device");
+    // a rejected large step re-draws the strategy; its second stage would read an emitter state that may be
+    // empty (drmlt_sampler.cpp:189-191 with an unused emitter sampler): undefined in the reference, refused here
+    if (mmlt && cfg->timid_after_large) return bail(nullptr, "timidAfterLarge is not defined for technique=mmlt");
     if (cfg->sample_count <= 0) return bail(nullptr, "sample_count must be positive");
     if (!(cfg->p_large >= 0.f && cfg->p_large <= 1.f)) return bail(nullptr, "pLarge must be in [0,1]");
     const drmlt_camera &cam = scene->camera;
@@ -397,7 +407,8 @@ drmlt_ctx *drmlt_create(const drmlt_config *cfg, const drmlt_scene *scene, int d
     // ---- derived quantities of DRMLT::render (drmlt.cpp:434-476)
     const uint64_t budget = (uint64_t) cam.width * cam.height * (uint64_t) cfg->sample_count;
     int work_units = cfg->work_units;
-    if (work_units <= 0) work_units = (int) std::max<uint64_t>(1, (budget + 200000 - 1) / 200000);
+    const uint64_t per_unit = mmlt ? 100000 : 200000; // desiredMutationsPerWorkUnit, drmlt.cpp:434-444
+    if (work_units <= 0) work_units = (int) std::max<uint64_t>(1, (budget + per_unit - 1) / per_unit);
     ctx->cfg.work_units = work_units;
     ctx->n_chains = (uint32_t) work_units;
 
@@ -422,12 +433,22 @@ drmlt_ctx *drmlt_create(const drmlt_config *cfg, const drmlt_scene *scene, int d
     P.eff_dim = std::min(P.max_dim, effective_dim_path(cfg->max_depth, cfg->rr_depth));
     P.p_large = cfg->p_large; P.sigma2 = cfg->scale_second * cfg->sigma;
     P.n_chains = ctx->n_chains;
+    P.technique = cfg->technique; P.light_image = cfg->no_light_image ? 0 : 1; P.fix_emitter_path = cfg->fix_emitter_path;
+    P.mmlt_S = P.mmlt_E = P.mmlt_dmax = 0;
+    if (mmlt) { // PSS layout of a chain: [sensor S | emitter E | direct] (device_bidir.h)
+        P.mmlt_S = 2 * (cfg->max_depth + 1); P.mmlt_E = 2 * cfg->max_depth;
+        P.mmlt_dmax = (cfg->max_depth + 2) * 3; P.mmlt_dmax += P.mmlt_dmax & 1; // pssmlt_utils.h:58-63
+        P.max_dim = 2 * P.mmlt_dmax + 1;
+        P.eff_dim = P.mmlt_S + P.mmlt_E + 1;
+    }
 
     const size_t film_bytes = (size_t) cam.width * cam.height * 3 * sizeof(float);
     ok = ctx->d_film.alloc(film_bytes) == hipSuccess && ctx->d_x.alloc((size_t) P.eff_dim * ctx->n_chains * sizeof(float)) == hipSuccess &&
          ctx->d_cur.alloc((size_t) 6 * ctx->n_chains * sizeof(float)) == hipSuccess && ctx->d_stats.alloc(32 * sizeof(unsigned long long)) == hipSuccess &&
-         ctx->d_err.alloc(64) == hipSuccess;
+         ctx->d_err.alloc(64) == hipSuccess && ctx->d_chain_i.alloc((size_t) 2 * ctx->n_chains * sizeof(int32_t)) == hipSuccess;
     if (!ok) return bail(ctx, "device allocation of chain state / film failed");
+    (void) hipMemset(ctx->d_chain_i.p, 0, (size_t) 2 * ctx->n_chains * sizeof(int32_t));
+    P.chain_depth = ctx->d_chain_i.as<int32_t>(); P.cur_t = P.chain_depth + ctx->n_chains;
     (void) hipMemset(ctx->d_film.p, 0, film_bytes);
     (void) hipMemset(ctx->d_stats.p, 0, 32 * sizeof(unsigned long long));
     (void) hipMemset(ctx->d_err.p, 0, 64);
@@ -481,10 +502,17 @@ int drmlt_seed(drmlt_ctx *ctx, uint64_t seed, uint32_t chain_offset, double *b_o
     P.chain_offset = chain_offset; P.boot_stream = chain_offset;
     ctx->chain_offset = chain_offset;
     // luminance sample floor: max(luminanceSamples, 10 * workUnits), drmlt.cpp:454-466
-    uint32_t n = (uint32_t) std::max<int64_t>(ctx->cfg.luminance_samples, (int64_t) ctx->n_chains * 10);
+    // technique=mmlt: x50, and as many again per depth; b is scaled by maxDepth below (drmlt.cpp:456-473,
+    // pathsampler.cpp:884-890,932-934). One bootstrap stream per GPU, as with nCores = 1 in the reference.
+    const bool mmlt = ctx->cfg.technique == DRMLT_TECH_MMLT;
+    uint64_t n64 = (uint64_t) std::max<int64_t>(ctx->cfg.luminance_samples, (int64_t) ctx->n_chains * (mmlt ? 50 : 10));
+    if (mmlt) n64 *= (uint64_t) ctx->cfg.max_depth;
+    if (n64 > 0x7fffffffull) return ctx->fail(DRMLT_E_INVALID, "too many luminance samples");
+    uint32_t n = (uint32_t) n64;
     DevBuf d_lum;
     HIP_TRY(ctx, d_lum.alloc((size_t) n * sizeof(float)));
-    launch_bootstrap(P, n, d_lum.as<float>(), ctx->stream);
+    if (mmlt) launch_bootstrap_mmlt(P, n, d_lum.as<float>(), ctx->stream);
+    else launch_bootstrap(P, n, d_lum.as<float>(), ctx->stream);
     HIP_TRY(ctx, hipGetLastError());
     std::vector<float> lum(n);
     HIP_TRY(ctx, hipMemcpyAsync(lum.data(), d_lum.p, (size_t) n * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
@@ -503,6 +531,7 @@ int drmlt_seed(drmlt_ctx *ctx, uint64_t seed, uint32_t chain_offset, double *b_o
         if (l != 0.f) { idx.push_back(i); cdf.push_back(cdf.back() + (double) l); }
     }
     double mean = tok > 0 ? sum / tok : 0.0;
+    if (mmlt) mean *= (double) ctx->cfg.max_depth; // "As we split the path by corresponding depth"
     if (!(mean > 0.0) || idx.empty())
         return ctx->fail(DRMLT_E_ZERO_LUM, "The average image luminance appears to be zero! This could indicate a problem with the scene setup.");
     const double norm = 1.0 / cdf.back();
@@ -529,7 +558,8 @@ int drmlt_seed(drmlt_ctx *ctx, uint64_t seed, uint32_t chain_offset, double *b_o
     HIP_TRY(ctx, hipMemcpyAsync(d_si.p, seed_index.data(), seed_index.size() * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(d_sl.p, seed_lum.data(), seed_lum.size() * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(ctx, hipMemsetAsync(ctx->d_err.p, 0, 64, ctx->stream));
-    launch_init_chains(P, d_si.as<uint32_t>(), d_sl.as<float>(), ctx->stream);
+    if (mmlt) launch_init_chains_mmlt(P, d_si.as<uint32_t>(), d_sl.as<float>(), ctx->stream);
+    else launch_init_chains(P, d_si.as<uint32_t>(), d_sl.as<float>(), ctx->stream);
     HIP_TRY(ctx, hipGetLastError());
     int32_t flag = 0;
     HIP_TRY(ctx, hipMemcpyAsync(&flag, ctx->d_err.p, sizeof flag, hipMemcpyDeviceToHost, ctx->stream));
@@ -574,7 +604,8 @@ int drmlt_run(drmlt_ctx *ctx, uint64_t total_mutations, volatile int *stop, drml
         HIP_TRY(ctx, hipEventCreate(&a));
         HIP_TRY(ctx, hipEventCreate(&b));
         HIP_TRY(ctx, hipEventRecord(a, ctx->stream));
-        launch_mutate(ctx->P, n, ctx->mutation_base, ctx->stream);
+        if (ctx->cfg.technique == DRMLT_TECH_MMLT) launch_mutate_mmlt(ctx->P, n, ctx->mutation_base, ctx->stream);
+        else launch_mutate(ctx->P, n, ctx->mutation_base, ctx->stream);
         HIP_TRY(ctx, hipGetLastError());
         HIP_TRY(ctx, hipEventRecord(b, ctx->stream));
         evs.emplace_back(a, b);
@@ -676,14 +707,17 @@ int drmlt_stats_get(drmlt_ctx *ctx, drmlt_stats *o) {
 
 int drmlt_eval_paths(drmlt_ctx *ctx, const float *u, uint32_t n, uint32_t dim, drmlt_splat *out) {
     if (!ctx || !u || !out) return DRMLT_E_INVALID;
-    if ((int) dim < ctx->P.eff_dim) return ctx->fail(DRMLT_E_INVALID, "eval_paths: need at least %d PSS dimensions per point", ctx->P.eff_dim);
+    const bool mmlt = ctx->cfg.technique == DRMLT_TECH_MMLT;
+    const int need = ctx->P.eff_dim + (mmlt ? 1 : 0); // mmlt: [sensor S | emitter E | direct | depth]
+    if ((int) dim < need) return ctx->fail(DRMLT_E_INVALID, "eval_paths: need at least %d PSS dimensions per point", need);
     if (n == 0) return DRMLT_OK;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     DevBuf d_u, d_o;
     HIP_TRY(ctx, d_u.alloc((size_t) n * dim * sizeof(float)));
     HIP_TRY(ctx, d_o.alloc((size_t) n * 8 * sizeof(float)));
     HIP_TRY(ctx, hipMemcpyAsync(d_u.p, u, (size_t) n * dim * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
-    launch_eval_paths(ctx->P, d_u.as<float>(), n, dim, d_o.as<float>(), ctx->stream);
+    if (mmlt) launch_eval_paths_mmlt(ctx->P, d_u.as<float>(), n, dim, d_o.as<float>(), ctx->stream);
+    else launch_eval_paths(ctx->P, d_u.as<float>(), n, dim, d_o.as<float>(), ctx->stream);
     HIP_TRY(ctx, hipGetLastError());
     std::vector<float> h((size_t) n * 8);
     HIP_TRY(ctx, hipMemcpyAsync(h.data(), d_o.p, h.size() * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
@@ -747,6 +781,12 @@ int drmlt_chain_state(drmlt_ctx *ctx, drmlt_splat *cur, float *u, uint32_t dim) 
             cur[i].luminance = h[i]; cur[i].x = h[n + i]; cur[i].y = h[2 * (size_t) n + i];
             cur[i].rgb[0] = h[3 * (size_t) n + i]; cur[i].rgb[1] = h[4 * (size_t) n + i]; cur[i].rgb[2] = h[5 * (size_t) n + i];
             cur[i].n_dims = 0; cur[i].n_rays = 0;
+        }
+        if (ctx->cfg.technique == DRMLT_TECH_MMLT) { // n_dims: the chain's path depth, n_rays: t of the current state
+            std::vector<int32_t> ci((size_t) 2 * n);
+            HIP_TRY(ctx, hipMemcpyAsync(ci.data(), ctx->d_chain_i.p, ci.size() * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            for (uint32_t i = 0; i < n; ++i) { cur[i].n_dims = ci[i]; cur[i].n_rays = ci[n + i]; }
         }
     }
     if (u) {

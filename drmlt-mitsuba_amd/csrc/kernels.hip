@@ -8,53 +8,7 @@
 //   k_lum_sum / k_develop   DRMLTProcess::develop (drmlt_proc.cpp:824-849)
 #include "device_path.h"
 
-#define CHAIN_BLOCK 64 // one wave per workgroup: no barriers anywhere on the chain path
-
-// ImageBlock::put (imageblock.h:150-216) through the 32-entry filter table (rfilter.h:76-77).
-// The reference's work-unit blocks carry a border that is dropped when merged into m_accum;
-// clamping the footprint to the film gives the same sums.
-DEV void film_put(const DParams &P, float px, float py, f3 v) {
-    if (P.debug & 1) return;
-    if (!(isfinite(v.x) && isfinite(v.y) && isfinite(v.z)) || v.x < 0.f || v.y < 0.f || v.z < 0.f) return;
-    float posx = px - 0.5f, posy = py - 0.5f;
-    int minx = max((int) ceilf(posx - P.filter_radius), 0), miny = max((int) ceilf(posy - P.filter_radius), 0);
-    int maxx = min((int) floorf(posx + P.filter_radius), P.width - 1), maxy = min((int) floorf(posy + P.filter_radius), P.height - 1);
-    const bool box = P.box_weight > 0.f; // box table = one constant in entries 0..30 and 0 in entry 31
-    for (int y = miny; y <= maxy; ++y) {
-        const int iy = min((int) fabsf(((float) y - posy) * P.filter_scale), 31);
-        float wy = box ? (iy < 31 ? P.box_weight : 0.f) : P.filter_lut[iy];
-        for (int x = minx; x <= maxx; ++x) {
-            const int ix = min((int) fabsf(((float) x - posx) * P.filter_scale), 31);
-            float w = (box ? (ix < 31 ? P.box_weight : 0.f) : P.filter_lut[ix]) * wy;
-            float *dst = P.film + ((size_t) y * P.width + x) * 3;
-            atomicAdd(dst + 0, w * v.x);
-            atomicAdd(dst + 1, w * v.y);
-            atomicAdd(dst + 2, w * v.z);
-        }
-    }
-}
-
-// per-field select: a reference/pointer select between two structs would force them into scratch memory
-DEV DSplat select_splat(bool c, const DSplat &a, const DSplat &b) {
-    DSplat r;
-    r.lum = c ? a.lum : b.lum; r.px = c ? a.px : b.px; r.py = c ? a.py : b.py;
-    r.r = c ? a.r : b.r; r.g = c ? a.g : b.g; r.b = c ? a.b : b.b;
-    return r;
-}
-
-DEV void normalize_splat(DSplat &s) { // SplatList::normalize, pathsampler.cpp:1021-1027
-    if (s.lum > 0.f) {
-        float inv = 1.f / s.lum;
-        s.r *= inv; s.g *= inv; s.b *= inv;
-    }
-}
-
-DEV unsigned long long wave_sum(uint32_t v) {
-    unsigned long long s = v;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
-    return s;
-}
+#include "kernel_common.h"
 
 __global__ void __launch_bounds__(256) k_bootstrap(DParams P, uint32_t n, float *lum_out) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -84,18 +38,6 @@ __global__ void __launch_bounds__(256) k_init_chains(DParams P, const uint32_t *
     smp.reset_caches();
     for (uint32_t k = 0; k < (uint32_t) P.eff_dim; ++k) P.x[(size_t) k * P.n_chains + c] = smp.u_boot(k, TAG_BOOT);
 }
-
-DEV bool lum_invalid(float x) { return isnan(x) || isinf(x) || x <= 0.f; }        // drmlt_proc.cpp:428
-DEV bool lum_invalid_mix(float x) { return isnan(x) || isinf(x) || x < 0.f; }     // drmlt_proc.cpp:181
-
-// Per-lane event counters of one launch, packed 2 x 16 bit (launch length is capped at 32768).
-struct Counters {
-    uint32_t large_acc1l; // lo: large steps                hi: accepted first stage after large
-    uint32_t acc1b_secl;  // lo: accepted first stage, bold  hi: second stages after large
-    uint32_t secb_acc2l;  // lo: second stages after bold    hi: accepted second stage after large
-    uint32_t acc2b_rev;   // lo: accepted second, bold       hi: Green reverse evaluations
-    uint32_t rays;
-};
 
 __global__ void __launch_bounds__(CHAIN_BLOCK) k_mutate(DParams P, uint32_t n_mut, uint32_t mut_base) {
     const uint32_t lane = threadIdx.x;

@@ -1,0 +1,275 @@
+// HIP kernels of the DRMLT hot path for technique=mmlt (gfx950). One Markov chain per lane, one wave per workgroup.
+//
+//   k_bootstrap_mmlt    luminance samples of generateSeeds with depth = (i % maxDepth) + 1 (pathsampler.cpp:879-920)
+//   k_init_chains_mmlt  seed replay + fillReplay of the three samplers (drmlt_proc.cpp:467-514)
+//   k_mutate_mmlt       DRMLTRenderer::process / processMixture over sampleSplats(EMMLT) (drmlt_proc.cpp:161-380,518-770)
+//   k_eval_paths_mmlt   sampleSplats(EMMLT) on caller-supplied PSS points
+//
+// LDS rows (256 B each, [row][lane]): chain state [0, NX), NX = S + E + 1; then the MIS scratch of eval_mmlt.
+#include "device_bidir.h"
+#include "kernel_common.h"
+
+DEV uint32_t mmlt_nx(const DParams &P) { return (uint32_t) (P.mmlt_S + P.mmlt_E + 1); }
+
+DEV void msampler_setup(MSampler &smp, const DParams &P, uint32_t lane) {
+    smp.key0 = P.key0; smp.key1 = P.key1;
+    smp.type = P.type; smp.sigma2 = P.sigma2; smp.large = false;
+    smp.lane = lane; smp.arr = nullptr;
+    smp.S = (uint32_t) P.mmlt_S; smp.E = (uint32_t) P.mmlt_E;
+    smp.base_e = 2u * (uint32_t) P.mmlt_dmax; smp.base_d = 4u * (uint32_t) P.mmlt_dmax;
+    smp.emitter_ident2 = false;
+    smp.reset_caches();
+    smp.select(SEG_SENSOR);
+}
+
+__global__ void __launch_bounds__(CHAIN_BLOCK) k_bootstrap_mmlt(DParams P, uint32_t n, float *lum_out) {
+    const uint32_t lane = threadIdx.x;
+    const uint32_t i = blockIdx.x * CHAIN_BLOCK + lane;
+    if (i >= n) return;
+    MSampler smp;
+    msampler_setup(smp, P, lane);
+    smp.chain = P.boot_stream; smp.major = i; smp.mode = SM_BOOT;
+    const GlobalTables T{P.shade, P.bsdfs, P.emitters};
+    MmltResult R;
+    eval_mmlt(P, T, smp, (int) (i % (uint32_t) P.max_depth) + 1, mmlt_nx(P), R);
+    lum_out[i] = R.splat.lum;
+}
+
+__global__ void __launch_bounds__(CHAIN_BLOCK) k_init_chains_mmlt(DParams P, const uint32_t *seed_index, const float *seed_lum) {
+    const uint32_t lane = threadIdx.x;
+    const uint32_t c = blockIdx.x * CHAIN_BLOCK + lane;
+    if (c >= P.n_chains) return;
+    const uint32_t idx = seed_index[c];
+    const int depth = (int) (idx % (uint32_t) P.max_depth) + 1;
+    MSampler smp;
+    msampler_setup(smp, P, lane);
+    smp.chain = P.boot_stream; smp.major = idx; smp.mode = SM_BOOT;
+    const GlobalTables T{P.shade, P.bsdfs, P.emitters};
+    MmltResult R;
+    eval_mmlt(P, T, smp, depth, mmlt_nx(P), R);
+    DSplat s = R.splat;
+    // drmlt_proc.cpp:509-512: relative tolerance Epsilon. (The replay is inlined into another kernel than the
+    // bootstrap, so contraction may differ in the last bit; the reference's check is relative as well.)
+    if (!(fabsf((s.lum - seed_lum[c]) / seed_lum[c]) <= EPSILON_F)) atomicExch(P.error_flag, 1);
+    normalize_splat(s);
+    P.cur_lum[c] = s.lum; P.cur_px[c] = s.px; P.cur_py[c] = s.py;
+    P.cur_r[c] = s.r; P.cur_g[c] = s.g; P.cur_b[c] = s.b;
+    P.cur_t[c] = R.t;
+    P.chain_depth[c] = depth;
+    // The replayed stream, in call order: direct (1), sensor (n_s), emitter (n_e); fillReplay then tops up the
+    // sensor state to D components, the emitter state to D, the direct state is complete (drmlt_proc.cpp:506-509)
+    const uint32_t D = (uint32_t) mmlt_max_dim(depth), ns = R.n_sensor, ne = R.n_emitter;
+    const uint32_t S = (uint32_t) P.mmlt_S, E = (uint32_t) P.mmlt_E;
+    smp.b1_idx = 0xffffffffu;
+    for (uint32_t k = 0; k < S; ++k) P.x[(size_t) k * P.n_chains + c] = smp.u_boot(k < ns ? 1u + k : 1u + ne + k);
+    for (uint32_t k = 0; k < E; ++k) P.x[(size_t) (S + k) * P.n_chains + c] = smp.u_boot(k < ne ? 1u + ns + k : 1u + D + k);
+    P.x[(size_t) (S + E) * P.n_chains + c] = smp.u_boot(0u);
+}
+
+__global__ void __launch_bounds__(CHAIN_BLOCK) k_mutate_mmlt(DParams P, uint32_t n_mut, uint32_t mut_base) {
+    const uint32_t lane = threadIdx.x;
+    const uint32_t c = blockIdx.x * CHAIN_BLOCK + lane;
+    const bool live = c < P.n_chains;
+    const uint32_t cc = live ? c : P.n_chains - 1;
+    const uint32_t NX = mmlt_nx(P);
+    for (uint32_t k = 0; k < NX; ++k) lds_x[k * 64u + lane] = P.x[(size_t) k * P.n_chains + cc];
+
+    DSplat cur;
+    cur.lum = P.cur_lum[cc]; cur.px = P.cur_px[cc]; cur.py = P.cur_py[cc];
+    cur.r = P.cur_r[cc]; cur.g = P.cur_g[cc]; cur.b = P.cur_b[cc];
+    int cur_t = P.cur_t[cc];
+    const int depth = P.chain_depth[cc];
+    const uint32_t usedS = 2u * (uint32_t) (depth + 1), usedE = 2u * (uint32_t) depth; // components a depth-`depth` path can consume
+
+    MSampler smp;
+    msampler_setup(smp, P, lane);
+    smp.chain = P.chain_offset + cc;
+    const GlobalTables T{P.shade, P.bsdfs, P.emitters};
+    Counters ct = {0u, 0u, 0u, 0u, 0u};
+    const bool amap = P.acceptance_map != 0;
+    const bool mix = P.use_mixture != 0;
+
+    if (live) for (uint32_t it = 0; it < n_mut; ++it) {
+        const uint32_t m = mut_base + it;
+        const u4 coins = philox4x32_10(P.key0, P.key1, 0u, m, smp.chain, TAG_COIN);
+        const bool large = u32_to_unit(coins.x) < P.p_large;
+        smp.major = m;
+        smp.large = large;
+        // fixEmitterPath: the emitter sampler moves in the second stage only for pure light tracing (drmlt_proc.cpp:566-573)
+        smp.emitter_ident2 = P.fix_emitter_path != 0 && cur_t != 1;
+        DSplat y, z;
+        y.lum = 0.f; y.px = y.py = y.r = y.g = y.b = 0.f;
+        z = y;
+        int y_t = 0, z_t = 0;
+        uint32_t ns1 = 0, ne1 = 0, ns2 = 0, ne2 = 0;
+        float a1 = 0.f, a2 = 0.f;
+        bool acc1 = false, acc2 = false, doSecond = false;
+
+#pragma nounroll
+        for (int stage = 0; stage < 3; ++stage) {
+            smp.mode = stage == 0 ? SM_STAGE1 : (stage == 1 ? SM_STAGE2 : SM_REVERSE);
+            MmltResult R;
+            eval_mmlt(P, T, smp, depth, NX, R);
+            ct.rays += R.nrays;
+            DSplat res = R.splat;
+            normalize_splat(res);
+            if (stage == 0) {
+                y = res; y_t = R.t; ns1 = R.n_sensor; ne1 = R.n_emitter;
+                if (!(mix ? lum_invalid_mix(y.lum) : lum_invalid(y.lum))) {
+                    a1 = fminf(1.f, y.lum / cur.lum);
+                    acc1 = a1 >= 1.f || u32_to_unit(coins.y) < a1;
+                }
+                if (!mix) doSecond = !acc1 && !large;                  // timidAfterLarge is refused for mmlt
+                else doSecond = !large && u32_to_unit(coins.w) < 0.5f;
+                if (!doSecond) break;
+            } else if (stage == 1) {
+                z = res; z_t = R.t; ns2 = R.n_sensor; ne2 = R.n_emitter;
+                if (mix) {
+                    acc1 = false;
+                    a1 = 0.f;
+                    if (!lum_invalid_mix(z.lum)) {
+                        a2 = fminf(1.f, z.lum / cur.lum);
+                        acc2 = a2 >= 1.f || u32_to_unit(coins.z) < a2;
+                    }
+                    break;
+                }
+                if (lum_invalid(z.lum)) break;
+                if (P.type == 0) continue;
+                if (P.type == 1) { // Tierney & Mira: product of the three samplers' ratios (drmlt_proc.cpp:633-637)
+                    float aRev = fminf(1.f, y.lum / z.lum);
+                    if (!(aRev >= 1.f)) {
+                        float num = 0.f, den = 0.f;
+                        for (int sg = 0; sg < 2; ++sg) { // the direct sampler's first stage is the identity: ratio 1
+                            const uint32_t nmax = sg == 0 ? max(ns1, ns2) : max(ne1, ne2);
+                            const uint32_t dimStage = nmax > 0u ? nmax - 1u : 0u;
+                            smp.select(sg);
+                            for (uint32_t i = 0; i < dimStage; ++i) {
+                                float yi = smp.y_raw(i);
+                                num += kelemen_logpdf(smp.z_raw(i) - yi);
+                                den += kelemen_logpdf(smp.x(i) - yi);
+                            }
+                        }
+                        float ratio = __expf(num - den);
+                        if (!lum_invalid(ratio)) {
+                            a2 = fminf(1.f, (z.lum / cur.lum) * ratio * (1.f - aRev) / (1.f - a1));
+                            acc2 = a2 >= 1.f || u32_to_unit(coins.z) < a2;
+                        }
+                    }
+                } else {
+                    if (z.lum < y.lum) { a2 = 0.f; }
+                    else if (z.lum >= cur.lum) { a2 = 1.f; acc2 = true; }
+                    else {
+                        a2 = (z.lum - y.lum) / (cur.lum - y.lum);
+                        acc2 = a2 >= 1.f || u32_to_unit(coins.z) < a2;
+                    }
+                }
+                break;
+            } else {
+                ct.acc2b_rev += 1u << 16;
+                float aRev = lum_invalid(res.lum) ? 0.f : fminf(1.f, res.lum / z.lum);
+                if (aRev != 1.f) {
+                    a2 = fminf(1.f, (z.lum / cur.lum) * (1.f - aRev) / (1.f - a1));
+                    acc2 = a2 >= 1.f || u32_to_unit(coins.z) < a2;
+                }
+            }
+        }
+
+        if (!mix) {
+            float w1 = a1, w2 = (1.f - a1) * a2, w0 = 1.f - w1 - w2;
+            if (!amap) {
+                if (w0 > 0.f) film_put(P, cur.px, cur.py, mk3(cur.r * w0, cur.g * w0, cur.b * w0));
+                if (w1 > 0.f) film_put(P, y.px, y.py, mk3(y.r * w1, y.g * w1, y.b * w1));
+                if (doSecond && w2 > 0.f) film_put(P, z.px, z.py, mk3(z.r * w2, z.g * w2, z.b * w2));
+            }
+        } else {
+            const float a = doSecond ? a2 : a1;
+            const DSplat pr = select_splat(doSecond, z, y);
+            if (1.f - a > 0.f) film_put(P, cur.px, cur.py, mk3(cur.r * (1.f - a), cur.g * (1.f - a), cur.b * (1.f - a)));
+            if (a > 0.f) film_put(P, pr.px, pr.py, mk3(pr.r * a, pr.g * a, pr.b * a));
+        }
+
+        if (large) {
+            ct.large_acc1l += 1u + (acc1 ? 1u << 16 : 0u);
+            if (doSecond) ct.acc1b_secl += 1u << 16;
+            if (acc2) ct.secb_acc2l += 1u << 16;
+        } else {
+            if (acc1) ct.acc1b_secl += 1u;
+            if (doSecond) ct.secb_acc2l += 1u;
+            if (acc2) ct.acc2b_rev += 1u;
+        }
+
+        if (acc1 || acc2) {
+            // DRMLTSampler::accept on the three samplers: every component a path of this depth can consume
+            for (int sg = 0; sg < 3; ++sg) {
+                smp.select(sg);
+                const uint32_t nk = sg == 0 ? usedS : (sg == 1 ? usedE : 1u);
+                for (uint32_t k = 0; k < nk; ++k) {
+                    const float v = wrap01(acc1 ? smp.y_raw(k) : smp.z_raw(k));
+                    lds_x[(smp.x_off + k) * 64u + lane] = v;
+                    if (smp.type == 2 && (k & 1u)) smp.pair_base = 0xffffffffu; // the pair cache holds the old x
+                }
+            }
+            cur = select_splat(acc1, y, z);
+            cur_t = acc1 ? y_t : z_t;
+            if (amap) {
+                if (acc1) { if (!large && !mix) film_put(P, cur.px, cur.py, mk3(1.f, 0.f, 0.f)); }
+                else if (!mix) film_put(P, cur.px, cur.py, mk3(0.f, 1.f, 0.f));
+            }
+        }
+    }
+
+    if (live) {
+        for (uint32_t k = 0; k < NX; ++k) P.x[(size_t) k * P.n_chains + c] = lds_x[k * 64u + lane];
+        P.cur_lum[c] = cur.lum; P.cur_px[c] = cur.px; P.cur_py[c] = cur.py;
+        P.cur_r[c] = cur.r; P.cur_g[c] = cur.g; P.cur_b[c] = cur.b;
+        P.cur_t[c] = cur_t;
+    }
+    unsigned long long v[9];
+    v[0] = wave_sum(ct.large_acc1l & 0xffffu); v[1] = wave_sum(ct.large_acc1l >> 16);
+    v[2] = wave_sum(ct.acc1b_secl & 0xffffu);  v[3] = wave_sum(ct.acc1b_secl >> 16);
+    v[4] = wave_sum(ct.secb_acc2l & 0xffffu);  v[5] = wave_sum(ct.secb_acc2l >> 16);
+    v[6] = wave_sum(ct.acc2b_rev & 0xffffu);   v[7] = wave_sum(ct.acc2b_rev >> 16);
+    v[8] = wave_sum(ct.rays);
+    if (lane == 0)
+        for (int i = 0; i < 9; ++i) atomicAdd(P.stats + i, v[i]);
+}
+
+// u: [sensor S | emitter E | direct | depth] per point, dim >= S + E + 2
+__global__ void __launch_bounds__(CHAIN_BLOCK) k_eval_paths_mmlt(DParams P, const float *u, uint32_t n, uint32_t dim, float *out8) {
+    const uint32_t lane = threadIdx.x;
+    const uint32_t i = blockIdx.x * CHAIN_BLOCK + lane;
+    if (i >= n) return;
+    MSampler smp;
+    msampler_setup(smp, P, lane);
+    smp.chain = 0u; smp.major = 0u; smp.mode = SM_ARRAY;
+    smp.arr = u + (size_t) i * dim;
+    const int depth = (int) smp.arr[P.mmlt_S + P.mmlt_E + 1];
+    const GlobalTables T{P.shade, P.bsdfs, P.emitters};
+    MmltResult R;
+    R.s = R.t = 0;
+    if (depth >= 1 && depth <= P.max_depth) eval_mmlt(P, T, smp, depth, mmlt_nx(P), R);
+    else { R.splat.lum = R.splat.px = R.splat.py = R.splat.r = R.splat.g = R.splat.b = 0.f; R.nrays = R.n_sensor = R.n_emitter = R.n_direct = 0u; }
+    float *o = out8 + (size_t) i * 8;
+    o[0] = R.splat.lum; o[1] = R.splat.px; o[2] = R.splat.py; o[3] = R.splat.r; o[4] = R.splat.g; o[5] = R.splat.b;
+    // n_dims carries the strategy as well: dims | s << 8 | t << 16
+    o[6] = __int_as_float((int) (R.n_sensor + R.n_emitter + R.n_direct) | (R.s << 8) | (R.t << 16));
+    o[7] = __int_as_float((int) R.nrays);
+}
+
+static size_t mmlt_lds_bytes(const DParams &P) {
+    return ((size_t) P.mmlt_S + P.mmlt_E + 1 + 3 * ((size_t) P.max_depth + 3)) * 64 * sizeof(float);
+}
+void launch_bootstrap_mmlt(const DParams &P, uint32_t n, float *lum_out, hipStream_t st) {
+    hipLaunchKernelGGL(k_bootstrap_mmlt, dim3((n + CHAIN_BLOCK - 1) / CHAIN_BLOCK), dim3(CHAIN_BLOCK), mmlt_lds_bytes(P), st, P, n, lum_out);
+}
+void launch_init_chains_mmlt(const DParams &P, const uint32_t *seed_index, const float *seed_lum, hipStream_t st) {
+    hipLaunchKernelGGL(k_init_chains_mmlt, dim3((P.n_chains + CHAIN_BLOCK - 1) / CHAIN_BLOCK), dim3(CHAIN_BLOCK), mmlt_lds_bytes(P), st, P,
+                       seed_index, seed_lum);
+}
+void launch_mutate_mmlt(const DParams &P, uint32_t n_mut, uint32_t mut_base, hipStream_t st) {
+    hipLaunchKernelGGL(k_mutate_mmlt, dim3((P.n_chains + CHAIN_BLOCK - 1) / CHAIN_BLOCK), dim3(CHAIN_BLOCK), mmlt_lds_bytes(P), st, P, n_mut,
+                       mut_base);
+}
+void launch_eval_paths_mmlt(const DParams &P, const float *u, uint32_t n, uint32_t dim, float *out8, hipStream_t st) {
+    hipLaunchKernelGGL(k_eval_paths_mmlt, dim3((n + CHAIN_BLOCK - 1) / CHAIN_BLOCK), dim3(CHAIN_BLOCK), mmlt_lds_bytes(P), st, P, u, n, dim, out8);
+}

@@ -423,8 +423,8 @@ public:
             Ray<F> ray{vt.p, d, vt.isOnSurface() ? Consts<F>::Epsilon : F(0), length * (vs.isOnSurface() ? (1 - Consts<F>::ShadowEpsilon) : F(1))};
             Intersection<F> its;
             ++rays;
-            if (scene.rayIntersect(ray, its)) return;
             list.nRays = (int) rays;
+            if (scene.rayIntersect(ray, its)) return;
             // generalised geometric term (edge.cpp:221-271 with both cosine flags)
             geo = F(1) / (length * length);
             if (vs.isOnSurface() && vs.isConnectable()) geo *= absDot(vsShadingNormal(vs), d);
@@ -459,12 +459,14 @@ inline int findMaxDimensionsMMLT(int depth) {
 
 // The sensor / emitter / direct samplers of one chain (drmlt_proc.cpp:84-141). They share the chain's
 // Random; here each gets its own draw-index range inside a (tag, mutation) stream:
-// sensor [0, 2D), emitter [2D, 4D), direct [4D, ...), D = findMaxDimensionsMMLT(depth).
+// sensor [0, 2D), emitter [2D, 4D), direct [4D, ...), D = findMaxDimensionsMMLT(maxDepth) for every chain.
 template <typename F> struct MMLTSamplers {
     DRMLTSampler<F> sensor, emitter, direct;
     int depth = -1;
+    uint32_t dmax;
     template <typename Cfg>
-    MMLTSamplers(const Cfg &cfg, Random *r) : sensor(cfg, r), emitter(cfg, r), direct(cfg, r) {
+    MMLTSamplers(const Cfg &cfg, Random *r)
+        : sensor(cfg, r), emitter(cfg, r), direct(cfg, r), dmax((uint32_t) findMaxDimensionsMMLT(cfg.maxDepth)) {
         direct.setStagesToIdentity();                      // the strategy stays fixed in small steps (:133-135)
         if (cfg.fixEmitterPath) emitter.handleLightTracing(); // :136-140
     }
@@ -473,7 +475,7 @@ template <typename F> struct MMLTSamplers {
         depth = d;
         size_t D = (size_t) findMaxDimensionsMMLT(d);
         sensor.setMaxDim(D); emitter.setMaxDim(D); direct.setMaxDim(1);
-        sensor.setDrawBase(0); emitter.setDrawBase((uint32_t) (2 * D)); direct.setDrawBase((uint32_t) (4 * D));
+        sensor.setDrawBase(0); emitter.setDrawBase(2 * dmax); direct.setDrawBase(4 * dmax);
     }
     void reset() { emitter.reset(); sensor.reset(); direct.reset(); }
     void setRandom(Random *r) { sensor.setRandom(r); emitter.setRandom(r); direct.setRandom(r); }

@@ -154,6 +154,7 @@ class Oracle:
         ue = np.ascontiguousarray(u_emitter, dtype=np.float32)
         ud = np.ascontiguousarray(u_direct, dtype=np.float32)
         n, dim = us.shape
+        assert ue.shape == us.shape and ud.shape == (n,)
         out = (self.abi.Splat * n)()
         st = np.zeros((n, 2), dtype=np.int32)
         self._chk(self.L.oracle_mmlt_eval(self.h, depth, int(light_image), us.ctypes.data, ue.ctypes.data,

@@ -188,6 +188,27 @@ template <typename F> struct Ctx : CtxBase {
         return 0;
     }
     int chainState(drmlt_splat *cur, float *u, uint32_t dim) override {
+        if (mmlt) { // the product's layout: [sensor S | emitter E | direct], S = 2 (maxDepth + 1), E = 2 maxDepth
+            const uint32_t S = 2u * (uint32_t) (cfg.max_depth + 1), E = 2u * (uint32_t) cfg.max_depth;
+            if (u && dim < S + E + 1) throw std::runtime_error("chain_state: need S + E + 1 dims for technique=mmlt");
+            for (int i = 0; i < cfg.work_units; ++i) {
+                const SplatList<F> &l = mchains[i]->current();
+                const MMLTSamplers<F> &ms = mchains[i]->sampler();
+                if (cur) {
+                    cur[i].luminance = (float) l.luminance; cur[i].x = (float) l.px; cur[i].y = (float) l.py;
+                    cur[i].rgb[0] = (float) l.value.x; cur[i].rgb[1] = (float) l.value.y; cur[i].rgb[2] = (float) l.value.z;
+                    cur[i].n_dims = ms.depth; cur[i].n_rays = l.t; // as drmlt_chain_state: depth and t
+                }
+                if (u) {
+                    float *row = u + (size_t) i * dim;
+                    for (uint32_t k = 0; k < dim; ++k) row[k] = 0.f;
+                    for (uint32_t k = 0; k < S && k < ms.sensor.uCurrent.size(); ++k) row[k] = (float) ms.sensor.uCurrent[k];
+                    for (uint32_t k = 0; k < E && k < ms.emitter.uCurrent.size(); ++k) row[S + k] = (float) ms.emitter.uCurrent[k];
+                    if (!ms.direct.uCurrent.empty()) row[S + E] = (float) ms.direct.uCurrent[0];
+                }
+            }
+            return 0;
+        }
         for (int i = 0; i < cfg.work_units; ++i) {
             const SplatList<F> &l = mmlt ? mchains[i]->current() : cfg.algo == DRMLT_ALGO_PSSMLT ? pchains[i]->current() : chains[i]->current();
             const std::vector<F> x = mmlt ? mchains[i]->state() : cfg.algo == DRMLT_ALGO_PSSMLT ? pchains[i]->state() : chains[i]->state();

@@ -239,6 +239,7 @@ public:
 
     const SplatList<F> &current() const { return m_current; }
     std::vector<F> state() const { return m_sampler.stateVector(); }
+    const SamplerT &sampler() const { return m_sampler; }
     uint32_t mutationIndex() const { return m_mutation; }
 
 private:
