@@ -22,7 +22,8 @@
  *                     src/integrators/drmlt/drmlt_proc.cpp:813-854
  *   drmlt_stats       the StatsCounter block
  *                     src/integrators/drmlt/drmlt_proc.cpp:34-49
- *   drmlt_eval_paths  PathSampler::sampleSplats (EUnidirectional)
+ *   drmlt_eval_paths  PathSampler::sampleSplats (EUnidirectional; EMMLT:
+ *                     src/libbidir/pathsampler.cpp:84-320)
  *                     include/mitsuba/bidir/pathsampler.h:124,
  *                     src/libbidir/pathsampler.cpp:529-567
  *   drmlt_film_*      ImageBlock accumulation  (m_accum)
@@ -221,7 +222,11 @@ int drmlt_develop(drmlt_ctx *ctx, const float *direct_rgb_or_null, float *out_rg
 
 int drmlt_stats_get(drmlt_ctx *ctx, drmlt_stats *out);
 
-/* f(u): evaluate n PSS points (row-major n x dim floats in [0,1], host). */
+/* f(u): evaluate n PSS points (row-major n x dim floats in [0,1], host).
+ * technique=mmlt: a point is [sensor S | emitter E | direct | depth] with
+ * S = 2 (maxDepth + 1), E = 2 maxDepth (the components the three samplers can
+ * hand to a path), depth as a float; n_dims of the result carries the
+ * strategy as well: dims | s << 8 | t << 16. */
 int drmlt_eval_paths(drmlt_ctx *ctx, const float *u, uint32_t n, uint32_t dim,
                      drmlt_splat *out);
 
@@ -244,7 +249,9 @@ int drmlt_kernel_time(drmlt_ctx *ctx, double *avg_ms, uint64_t *launches, int re
 int drmlt_render_pt(drmlt_ctx *ctx, uint32_t spp, uint64_t seed, float *out_rgb);
 
 /* Chain state dump for parity tests: lum/x/y/rgb of chain's current state and
- * the first `dim` PSS components (u is n_chains x dim, may be NULL). */
+ * the first `dim` PSS components (u is n_chains x dim, may be NULL).
+ * technique=mmlt: components are [sensor S | emitter E | direct]; n_dims = the
+ * chain's path depth, n_rays = t of the current state. */
 int drmlt_chain_state(drmlt_ctx *ctx, drmlt_splat *cur, float *u, uint32_t dim);
 
 const char *drmlt_last_error(drmlt_ctx *ctx);
