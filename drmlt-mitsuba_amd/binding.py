@@ -24,7 +24,7 @@ ABI_SYMBOLS = (
     "drmlt_create", "drmlt_seed", "drmlt_run", "drmlt_develop", "drmlt_stats_get", "drmlt_eval_paths",
     "drmlt_film_read", "drmlt_film_clear", "drmlt_film_device_ptr", "drmlt_set_luminance", "drmlt_set_stream",
     "drmlt_kernel_time", "drmlt_render_pt", "drmlt_chain_state", "drmlt_last_error", "drmlt_abi_version",
-    "drmlt_destroy",
+    "drmlt_destroy", "drmlt_set_importance_map", "drmlt_luminance_map",
 )
 
 
@@ -68,6 +68,8 @@ def load_library():
     L.drmlt_film_device_ptr.restype = C.c_void_p
     L.drmlt_film_device_ptr.argtypes = [C.c_void_p]
     L.drmlt_set_luminance.argtypes = [C.c_void_p, C.c_double]
+    L.drmlt_set_importance_map.argtypes = [C.c_void_p, C.c_void_p]
+    L.drmlt_luminance_map.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
     L.drmlt_set_stream.argtypes = [C.c_void_p, C.c_void_p]
     L.drmlt_kernel_time.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.c_int]
     L.drmlt_render_pt.argtypes = [C.c_void_p, C.c_uint32, C.c_uint64, C.c_void_p]
@@ -171,6 +173,15 @@ class Context:
     def set_luminance(self, b):
         self._chk(self.L.drmlt_set_luminance(self.h, b))
 
+    def set_importance_map(self, lum_map):
+        """Two-stage MLT: H x W luminance image of the first stage (None clears it). Call before seed()."""
+        if lum_map is None:
+            self._chk(self.L.drmlt_set_importance_map(self.h, None))
+            return
+        m = np.ascontiguousarray(lum_map, dtype=np.float32)
+        assert m.shape == (self.height, self.width)
+        self._chk(self.L.drmlt_set_importance_map(self.h, m.ctypes.data))
+
     def set_stream(self, stream_handle):
         self._chk(self.L.drmlt_set_stream(self.h, stream_handle))
 
@@ -190,3 +201,39 @@ class Context:
         u = np.empty((n, dim), dtype=np.float32)
         self._chk(self.L.drmlt_chain_state(self.h, cur, u.ctypes.data, dim))
         return np.frombuffer(cur, dtype=SPLAT_DTYPE).copy(), u
+
+
+def luminance_map(rgb_small, width, height):
+    """BidirectionalUtils::mltLuminancePass tail: first-stage image -> full-size luminance image."""
+    L = load_library()
+    src = np.ascontiguousarray(rgb_small, dtype=np.float32)
+    out = np.empty((height, width), dtype=np.float32)
+    rc = L.drmlt_luminance_map(src.ctypes.data, src.shape[1], src.shape[0], width, height, out.ctypes.data)
+    if rc != 0:
+        raise DrmltError(rc, "drmlt_luminance_map failed")
+    return out
+
+
+def render_two_stage(cfg, scene_data, seed, size_reduction=16, device=0):
+    """DRMLT::render with twoStage=true (drmlt.cpp:406-418): nested first stage on a film reduced by
+    `size_reduction` with sample_count * size_reduction mutations per pixel and the film's default (gaussian)
+    filter, then the full render weighted by its luminance image. Returns (image, importance_map, b)."""
+    import copy
+    cam = scene_data.camera
+    small = copy.deepcopy(scene_data)
+    w, h = max(1, cam.width // size_reduction), max(1, cam.height // size_reduction)
+    small.camera.width, small.camera.height = w, h
+    small.camera.filter, small.camera.filter_param = abi.FILTER_GAUSSIAN, 0.5
+    cfg1 = abi.Config.from_buffer_copy(cfg)
+    cfg1.sample_count = cfg.sample_count * size_reduction
+    cfg1.direct_samples = -1 if cfg.direct_samples < 0 else cfg.direct_samples   # nested: no direct image is rendered
+    cfg1.acceptance_map = 0
+    with Context(cfg1, small, device) as first:
+        first.seed(seed)
+        first.run(w * h * cfg1.sample_count)
+        lum = luminance_map(first.develop(), cam.width, cam.height)
+    ctx = Context(cfg, scene_data, device)
+    ctx.set_importance_map(lum)
+    b = ctx.seed(seed)
+    ctx.run(cam.width * cam.height * cfg.sample_count)
+    return ctx.develop(), lum, b

@@ -99,6 +99,7 @@ struct DParams {
     int32_t mmlt_dmax;        // findMaxDimensions of the deepest chain: draw bases 2 dmax (emitter), 4 dmax (direct)
     int32_t *chain_depth;     // [n] path depth of each chain (fixed by its seed)
     int32_t *cur_t;           // [n] sensor-subpath length t of the current state (light tracing: t == 1)
+    const float *importance;  // [H][W] two-stage MLT luminance image, or NULL (pathsampler.cpp:1001-1020)
 };
 
 // result of one PSS evaluation, SoA-friendly

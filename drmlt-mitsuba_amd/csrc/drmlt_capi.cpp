@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -27,8 +28,8 @@ void launch_init_chains_mmlt(const DParams &P, const uint32_t *seed_index, const
 void launch_mutate_mmlt(const DParams &P, uint32_t n_mut, uint32_t mut_base, hipStream_t st);
 void launch_eval_paths_mmlt(const DParams &P, const float *u, uint32_t n, uint32_t dim, float *out8, hipStream_t st);
 void launch_render_pt(const DParams &P, uint64_t n_samples, uint32_t stream, float scale, hipStream_t st);
-void launch_lum_sum(const float *film, uint32_t n_pixels, double *sum, hipStream_t st);
-void launch_develop(const float *film, const float *direct, float factor, uint32_t n, float *out, hipStream_t st);
+void launch_lum_sum(const float *film, const float *importance, uint32_t n_pixels, double *sum, hipStream_t st);
+void launch_develop(const float *film, const float *direct, const float *importance, float factor, uint32_t n, float *out, hipStream_t st);
 
 namespace {
 
@@ -67,7 +68,7 @@ struct drmlt_ctx {
     DParams P{};
     std::string error;
 
-    DevBuf d_prims, d_shade, d_bsdfs, d_emitters, d_bvh, d_lut, d_film, d_x, d_cur, d_stats, d_err, d_scratch, d_chain_i;
+    DevBuf d_prims, d_shade, d_bsdfs, d_emitters, d_bvh, d_lut, d_film, d_x, d_cur, d_stats, d_err, d_scratch, d_chain_i, d_importance;
     std::vector<DPrim> prims;
     std::vector<DShade> shade;
 
@@ -449,6 +450,7 @@ drmlt_ctx *drmlt_create(const drmlt_config *cfg, const drmlt_scene *scene, int d
     if (!ok) return bail(ctx, "device allocation of chain state / film failed");
     (void) hipMemset(ctx->d_chain_i.p, 0, (size_t) 2 * ctx->n_chains * sizeof(int32_t));
     P.chain_depth = ctx->d_chain_i.as<int32_t>(); P.cur_t = P.chain_depth + ctx->n_chains;
+    P.importance = nullptr;
     (void) hipMemset(ctx->d_film.p, 0, film_bytes);
     (void) hipMemset(ctx->d_stats.p, 0, 32 * sizeof(unsigned long long));
     (void) hipMemset(ctx->d_err.p, 0, 64);
@@ -580,6 +582,62 @@ int drmlt_seed(drmlt_ctx *ctx, uint64_t seed, uint32_t chain_offset, double *b_o
     return DRMLT_OK;
 }
 
+// Two-stage MLT (drmlt.cpp:406-418): the luminance image of the first stage weights the second stage's splats.
+// Must be set before drmlt_seed: the chains' current states are normalised with it (drmlt_proc.cpp:514).
+int drmlt_set_importance_map(drmlt_ctx *ctx, const float *lum_map_or_null) {
+    if (!ctx) return DRMLT_E_INVALID;
+    if (ctx->seeded) return ctx->fail(DRMLT_E_STATE, "the importance map must be set before drmlt_seed");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (!lum_map_or_null) { ctx->P.importance = nullptr; return DRMLT_OK; }
+    const size_t n = (size_t) ctx->P.width * ctx->P.height;
+    for (size_t i = 0; i < n; ++i)
+        if (!(lum_map_or_null[i] > 0.f) || !std::isfinite(lum_map_or_null[i]))
+            return ctx->fail(DRMLT_E_INVALID, "importance map must be positive and finite (pixel %zu)", i);
+    HIP_TRY(ctx, ctx->d_importance.alloc(n * sizeof(float)));
+    HIP_TRY(ctx, hipMemcpy(ctx->d_importance.p, lum_map_or_null, n * sizeof(float), hipMemcpyHostToDevice));
+    ctx->P.importance = ctx->d_importance.as<float>();
+    return DRMLT_OK;
+}
+
+// Tail of BidirectionalUtils::mltLuminancePass (src/libbidir/util.cpp:179-196): luminance of the developed
+// first-stage image, up-sampled with a Gaussian reconstruction filter (stddev 0.5, radius 2), clamped boundary
+// lookups, results clamped to [0, inf). Separable Resampler of include/mitsuba/core/rfilter.h:123-198,232-290:
+// horizontal pass, then vertical, as mitsuba::resample does (src/libcore/bitmap.cpp:2258-2330).
+int drmlt_luminance_map(const float *rgb, int w, int h, int W, int H, float *out) {
+    if (!rgb || !out || w <= 0 || h <= 0 || W <= 0 || H <= 0) return DRMLT_E_INVALID;
+    std::vector<float> lum((size_t) w * h);
+    for (size_t i = 0; i < lum.size(); ++i)
+        lum[i] = rgb[3 * i] * 0.212671f + rgb[3 * i + 1] * 0.715160f + rgb[3 * i + 2] * 0.072169f;
+    auto gauss = [](float x) {
+        const float stddev = 0.5f, radius = 2.0f, alpha = -1.0f / (2.0f * stddev * stddev);
+        return std::max(0.0f, std::exp(alpha * x * x) - std::exp(alpha * radius * radius));
+    };
+    // one 1-D pass: src (n_src samples, stride s_src) -> dst (n_dst samples, stride s_dst)
+    auto pass = [&](const float *src, int n_src, size_t s_src, float *dst, int n_dst, size_t s_dst) {
+        if (n_src == n_dst) { for (int i = 0; i < n_dst; ++i) dst[i * s_dst] = std::max(0.0f, src[i * s_src]); return; }
+        float radius = 2.0f, scale = 1.0f, invScale = 1.0f;
+        if (n_dst < n_src) { scale = (float) n_src / (float) n_dst; invScale = 1 / scale; radius *= scale; }
+        const int taps = (int) std::ceil(radius * 2);
+        for (int i = 0; i < n_dst; ++i) {
+            const float center = (i + 0.5f) / n_dst * n_src;
+            const int start = (int) std::floor(center - radius + 0.5f);
+            float wsum = 0.f, wts[64];
+            for (int j = 0; j < taps && j < 64; ++j) { wts[j] = gauss((start + j + 0.5f - center) * invScale); wsum += wts[j]; }
+            const float norm = 1.0f / wsum;
+            float r = 0.f;
+            for (int j = 0; j < taps && j < 64; ++j) {
+                const int k = std::min(std::max(start + j, 0), n_src - 1); // EClamp
+                r += src[k * s_src] * (wts[j] * norm);
+            }
+            dst[i * s_dst] = std::max(0.0f, r);
+        }
+    };
+    std::vector<float> tmp((size_t) W * h);
+    for (int y = 0; y < h; ++y) pass(&lum[(size_t) y * w], w, 1, &tmp[(size_t) y * W], W, 1);
+    for (int x = 0; x < W; ++x) pass(&tmp[x], h, (size_t) W, &out[x], H, (size_t) W);
+    return DRMLT_OK;
+}
+
 int drmlt_set_luminance(drmlt_ctx *ctx, double b) {
     if (!ctx) return DRMLT_E_INVALID;
     if (!(b > 0)) return ctx->fail(DRMLT_E_INVALID, "luminance must be positive");
@@ -595,10 +653,15 @@ int drmlt_run(drmlt_ctx *ctx, uint64_t total_mutations, volatile int *stop, drml
     std::vector<std::pair<hipEvent_t, hipEvent_t>> evs;
     uint64_t done = 0;
     int rc = DRMLT_OK;
+    // "timeout" (drmlt.cpp:296, drmlt_proc.cpp:519-521,868-877): equal-time mode. All chains run concurrently here,
+    // so they all stop at the first launch boundary after the deadline (the reference stops handing out work units).
+    const bool timed = ctx->cfg.timeout_s > 0;
+    const auto t_start = std::chrono::steady_clock::now();
     while (done < per_chain) {
         if (stop && *stop) { rc = DRMLT_E_CANCELLED; break; }
-        // shorter launches when somebody is watching (cancellation / progress latency ~ tens of ms)
-        const uint64_t slice = (stop || cb) ? std::min(ctx->slice, 256) : ctx->slice;
+        if (timed && std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count() >= (double) ctx->cfg.timeout_s) break;
+        // shorter launches when somebody is watching (cancellation / progress / deadline latency ~ tens of ms)
+        const uint64_t slice = (stop || cb || timed) ? std::min(ctx->slice, 256) : ctx->slice;
         uint32_t n = (uint32_t) std::min<uint64_t>(slice, per_chain - done);
         hipEvent_t a, b;
         HIP_TRY(ctx, hipEventCreate(&a));
@@ -612,7 +675,7 @@ int drmlt_run(drmlt_ctx *ctx, uint64_t total_mutations, volatile int *stop, drml
         ctx->mutation_base += n;
         done += n;
         ctx->launches++;
-        if (stop || cb) {
+        if (stop || cb || timed) {
             HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
             if (cb) cb(done * ctx->n_chains, per_chain * ctx->n_chains, user);
         }
@@ -647,7 +710,7 @@ int drmlt_develop(drmlt_ctx *ctx, const float *direct_rgb_or_null, float *out_rg
     HIP_TRY(ctx, d_sum.alloc(sizeof(double)));
     HIP_TRY(ctx, d_out.alloc((size_t) n * sizeof(float)));
     HIP_TRY(ctx, hipMemsetAsync(d_sum.p, 0, sizeof(double), ctx->stream));
-    launch_lum_sum(ctx->P.film, npix, d_sum.as<double>(), ctx->stream);
+    launch_lum_sum(ctx->P.film, ctx->P.importance, npix, d_sum.as<double>(), ctx->stream);
     double sum = 0.0;
     HIP_TRY(ctx, hipMemcpyAsync(&sum, d_sum.p, sizeof sum, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -657,7 +720,7 @@ int drmlt_develop(drmlt_ctx *ctx, const float *direct_rgb_or_null, float *out_rg
         HIP_TRY(ctx, d_direct.alloc((size_t) n * sizeof(float)));
         HIP_TRY(ctx, hipMemcpyAsync(d_direct.p, direct_rgb_or_null, (size_t) n * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
     }
-    launch_develop(ctx->P.film, d_direct.as<float>(), (float) factor, n, d_out.as<float>(), ctx->stream);
+    launch_develop(ctx->P.film, d_direct.as<float>(), ctx->P.importance, (float) factor, n, d_out.as<float>(), ctx->stream);
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipMemcpyAsync(out_rgb, d_out.p, (size_t) n * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));

@@ -36,7 +36,19 @@ DEV DSplat select_splat(bool c, const DSplat &a, const DSplat &b) {
     return r;
 }
 
-DEV void normalize_splat(DSplat &s) { // SplatList::normalize, pathsampler.cpp:1021-1027
+// SplatList::normalize, pathsampler.cpp:1001-1028. Two-stage MLT (`importance` != NULL): the splat is first divided
+// by the luminance image at its pixel and the list luminance recomputed, so chains sample f / importance.
+DEV void normalize_splat(DSplat &s, const DParams &P) {
+    if (P.importance) {
+        float lum = 0.f;
+        if (!(s.r == 0.f && s.g == 0.f && s.b == 0.f)) {
+            const int ix = min(max(0, (int) s.px), P.width - 1), iy = min(max(0, (int) s.py), P.height - 1);
+            const float lv = P.importance[ix + iy * P.width];
+            s.r /= lv; s.g /= lv; s.b /= lv;
+            lum = luminance3(mk3(s.r, s.g, s.b));
+        }
+        s.lum = lum;
+    }
     if (s.lum > 0.f) {
         float inv = 1.f / s.lum;
         s.r *= inv; s.g *= inv; s.b *= inv;

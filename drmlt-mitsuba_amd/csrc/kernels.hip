@@ -31,7 +31,7 @@ __global__ void __launch_bounds__(256) k_init_chains(DParams P, const uint32_t *
     DSplat s = eval_path(P, smp, nr, nd);
     // sanity check of drmlt_proc.cpp:509-512: same function, same inputs -> bit-equal on the device
     if (!(s.lum == seed_lum[c])) atomicExch(P.error_flag, 1);
-    normalize_splat(s);
+    normalize_splat(s, P);
     P.cur_lum[c] = s.lum; P.cur_px[c] = s.px; P.cur_py[c] = s.py;
     P.cur_r[c] = s.r; P.cur_g[c] = s.g; P.cur_b[c] = s.b;
     // replayed components + fillReplay top-up: dimension k of bootstrap sample i is U(BOOT, i, k)
@@ -79,7 +79,7 @@ __global__ void __launch_bounds__(CHAIN_BLOCK) k_mutate(DParams P, uint32_t n_mu
             uint32_t nr, nd;
             DSplat res = eval_path(P, smp, nr, nd);
             ct.rays += nr;
-            normalize_splat(res);
+            normalize_splat(res, P);
             if (stage == 0) {
                 y = res; nd1 = nd;
                 if (!(mix ? lum_invalid_mix(y.lum) : lum_invalid(y.lum))) { // Eq. 5, drmlt_proc.cpp:544-550 / :285-293
@@ -234,7 +234,7 @@ DEV int mh_decide(const DParams &P, ChainState &cs, LdsSampler &smp, PathState &
     DSplat res;
     res.px = ps.px; res.py = ps.py; res.r = ps.Li.x; res.g = ps.Li.y; res.b = ps.Li.z;
     res.lum = luminance3(ps.Li);
-    normalize_splat(res);
+    normalize_splat(res, P);
     ct.rays += ps.nrays;
     if (cs.stage == 0) {
         cs.y = res; cs.nd1 = ps.k;
@@ -637,11 +637,12 @@ __global__ void __launch_bounds__(256) k_render_pt(DParams P, uint64_t n_samples
 }
 
 // sum of pixel luminances in double (one atomic per block)
-__global__ void __launch_bounds__(256) k_lum_sum(const float *film, uint32_t n_pixels, double *sum) {
+__global__ void __launch_bounds__(256) k_lum_sum(const float *film, const float *importance, uint32_t n_pixels, double *sum) {
     __shared__ double part[256];
     double acc = 0.0;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_pixels; i += gridDim.x * blockDim.x)
-        acc += (double) film[3 * i] * 0.212671 + (double) film[3 * i + 1] * 0.715160 + (double) film[3 * i + 2] * 0.072169;
+        acc += ((double) film[3 * i] * 0.212671 + (double) film[3 * i + 1] * 0.715160 + (double) film[3 * i + 2] * 0.072169) *
+               (importance ? (double) importance[i] : 1.0); // drmlt_proc.cpp:826-832
     part[threadIdx.x] = acc;
     __syncthreads();
     for (int s = 128; s > 0; s >>= 1) {
@@ -651,9 +652,10 @@ __global__ void __launch_bounds__(256) k_lum_sum(const float *film, uint32_t n_p
     if (threadIdx.x == 0) atomicAdd(sum, part[0]);
 }
 
-__global__ void __launch_bounds__(256) k_develop(const float *film, const float *direct, float factor, uint32_t n, float *out) {
+__global__ void __launch_bounds__(256) k_develop(const float *film, const float *direct, const float *importance, float factor, uint32_t n,
+                                                 float *out) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = film[i] * factor + (direct ? direct[i] : 0.f);
+    if (i < n) out[i] = film[i] * (importance ? factor * importance[i / 3u] : factor) + (direct ? direct[i] : 0.f); // :841-847
 }
 
 // ---- host-callable launchers (C++ linkage, used by drmlt_capi.cpp) --------------------------
@@ -686,9 +688,9 @@ void launch_eval_paths(const DParams &P, const float *u, uint32_t n, uint32_t di
 void launch_render_pt(const DParams &P, uint64_t n_samples, uint32_t stream, float scale, hipStream_t st) {
     hipLaunchKernelGGL(k_render_pt, dim3(4096), dim3(256), 0, st, P, n_samples, stream, scale);
 }
-void launch_lum_sum(const float *film, uint32_t n_pixels, double *sum, hipStream_t st) {
-    hipLaunchKernelGGL(k_lum_sum, dim3(256), dim3(256), 0, st, film, n_pixels, sum);
+void launch_lum_sum(const float *film, const float *importance, uint32_t n_pixels, double *sum, hipStream_t st) {
+    hipLaunchKernelGGL(k_lum_sum, dim3(256), dim3(256), 0, st, film, importance, n_pixels, sum);
 }
-void launch_develop(const float *film, const float *direct, float factor, uint32_t n, float *out, hipStream_t st) {
-    hipLaunchKernelGGL(k_develop, dim3((n + 255) / 256), dim3(256), 0, st, film, direct, factor, n, out);
+void launch_develop(const float *film, const float *direct, const float *importance, float factor, uint32_t n, float *out, hipStream_t st) {
+    hipLaunchKernelGGL(k_develop, dim3((n + 255) / 256), dim3(256), 0, st, film, direct, importance, factor, n, out);
 }

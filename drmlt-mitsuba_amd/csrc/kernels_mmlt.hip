@@ -51,7 +51,7 @@ __global__ void __launch_bounds__(CHAIN_BLOCK) k_init_chains_mmlt(DParams P, con
     // drmlt_proc.cpp:509-512: relative tolerance Epsilon. (The replay is inlined into another kernel than the
     // bootstrap, so contraction may differ in the last bit; the reference's check is relative as well.)
     if (!(fabsf((s.lum - seed_lum[c]) / seed_lum[c]) <= EPSILON_F)) atomicExch(P.error_flag, 1);
-    normalize_splat(s);
+    normalize_splat(s, P);
     P.cur_lum[c] = s.lum; P.cur_px[c] = s.px; P.cur_py[c] = s.py;
     P.cur_r[c] = s.r; P.cur_g[c] = s.g; P.cur_b[c] = s.b;
     P.cur_t[c] = R.t;
@@ -112,7 +112,7 @@ __global__ void __launch_bounds__(CHAIN_BLOCK) k_mutate_mmlt(DParams P, uint32_t
             eval_mmlt(P, T, smp, depth, NX, R);
             ct.rays += R.nrays;
             DSplat res = R.splat;
-            normalize_splat(res);
+            normalize_splat(res, P);
             if (stage == 0) {
                 y = res; y_t = R.t; ns1 = R.n_sensor; ne1 = R.n_emitter;
                 if (!(mix ? lum_invalid_mix(y.lum) : lum_invalid(y.lum))) {

@@ -109,8 +109,11 @@ public:
         m_cfg.p_large = (float) props.getFloat("pLarge", 0.3);
         m_cfg.work_units = props.getInteger("workUnits", -1);
         m_cfg.kelemen_style_weights = props.getBoolean("kelemenStyleWeights", true);
-        if (props.getBoolean("twoStage", false)) throw std::runtime_error("twoStage is not supported by the MI355X backend yet");
-        m_timeout = props.getInteger("timeout", 0);
+        m_twoStage = props.getBoolean("twoStage", false);                             // drmlt.cpp:278
+        m_firstStageSizeReduction = props.getInteger("firstStageSizeReduction", 16);  // :292-293
+        if (m_firstStageSizeReduction <= 0) throw std::runtime_error("firstStageSizeReduction must be positive");
+        m_cfg.timeout_s = props.getInteger("timeout", 0);                             // :296
+        m_cfg.no_light_image = props.getBoolean("lightImage", true) ? 0 : 1;          // :301
         m_cfg.average_luminance = (float) props.getFloat("averageLuminance", -1.0);
         std::string type = props.getString("type");
         if (type == "green") m_cfg.type = DRMLT_TYPE_GREEN;
@@ -139,11 +142,35 @@ public:
     bool render(const SceneFile &scene, std::vector<float> &out, drmlt_stats *stats = nullptr, double *b_out = nullptr) {
         drmlt_scene sc = scene.view();
         char err[512] = {0};
+        m_stop = 0;
+        // two-stage MLT: nested first stage on a reduced film (BidirectionalUtils::mltLuminancePass, util.cpp:96-199)
+        std::vector<float> importance;
+        if (m_twoStage) {
+            drmlt_scene small = sc;
+            small.camera.width = std::max(1, sc.camera.width / m_firstStageSizeReduction);
+            small.camera.height = std::max(1, sc.camera.height / m_firstStageSizeReduction);
+            small.camera.filter = DRMLT_FILTER_GAUSSIAN; small.camera.filter_param = 0.5f; // the nested hdrfilm's default
+            drmlt_config c1 = m_cfg;
+            c1.sample_count = m_cfg.sample_count * m_firstStageSizeReduction;              // util.cpp:130-132
+            c1.acceptance_map = 0;
+            drmlt_ctx *first = drmlt_create(&c1, &small, m_device, err, sizeof err);
+            if (!first) throw std::runtime_error(err);
+            std::vector<float> img((size_t) small.camera.width * small.camera.height * 3);
+            int rc1 = drmlt_seed(first, m_seed, 0, nullptr);
+            if (rc1 == DRMLT_OK) rc1 = drmlt_run(first, (uint64_t) small.camera.width * small.camera.height * (uint64_t) c1.sample_count, &m_stop, nullptr, nullptr);
+            if (rc1 == DRMLT_OK) rc1 = drmlt_develop(first, nullptr, img.data());
+            std::string msg1 = rc1 == DRMLT_OK ? "" : drmlt_last_error(first);
+            drmlt_destroy(first);
+            if (rc1 == DRMLT_E_CANCELLED) return false;
+            if (rc1 != DRMLT_OK) throw std::runtime_error("First-stage MLT process failed! " + msg1);
+            importance.resize((size_t) sc.camera.width * sc.camera.height);
+            drmlt_luminance_map(img.data(), small.camera.width, small.camera.height, sc.camera.width, sc.camera.height, importance.data());
+        }
         drmlt_ctx *ctx = drmlt_create(&m_cfg, &sc, m_device, err, sizeof err);
         if (!ctx) throw std::runtime_error(err);
-        m_stop = 0;
         double b = 0;
-        int rc = drmlt_seed(ctx, m_seed, 0, &b);
+        int rc = importance.empty() ? DRMLT_OK : drmlt_set_importance_map(ctx, importance.data());
+        if (rc == DRMLT_OK) rc = drmlt_seed(ctx, m_seed, 0, &b);
         if (rc == DRMLT_OK) {
             uint64_t total = (uint64_t) sc.camera.width * sc.camera.height * (uint64_t) m_cfg.sample_count;
             rc = drmlt_run(ctx, total, &m_stop, nullptr, nullptr);
@@ -165,7 +192,8 @@ public:
 
 private:
     drmlt_config m_cfg;
-    int m_device = 0, m_timeout = 0;
+    int m_device = 0, m_firstStageSizeReduction = 16;
+    bool m_twoStage = false;
     uint64_t m_seed = 0x5EED;
     volatile int m_stop = 0;
 };

@@ -55,19 +55,25 @@ public:
         m_cfg.kelemen_style_weights = props.getBoolean("kelemenStyleWeights", true);
         m_cfg.kelemen_style_mutation = 1;
         m_device = props.getInteger("device", 0);
-        if (props.getBoolean("twoStage", false))
-            Log(EError, "twoStage is not supported by the MI355X backend yet");
+        m_twoStage = props.getBoolean("twoStage", false);
+        m_firstStageSizeReduction = props.getInteger("firstStageSizeReduction", 16);
+        m_cfg.timeout_s = props.getInteger("timeout", 0);
+        m_cfg.no_light_image = props.getBoolean("lightImage", true) ? 0 : 1;
     }
 
     DRMLT(Stream *stream, InstanceManager *manager) : Integrator(stream, manager), m_stop(0) {
         stream->read(&m_cfg, sizeof m_cfg);
         m_device = stream->readInt();
+        m_twoStage = stream->readBool();
+        m_firstStageSizeReduction = stream->readInt();
     }
 
     void serialize(Stream *stream, InstanceManager *manager) const {
         Integrator::serialize(stream, manager);
         stream->write(&m_cfg, sizeof m_cfg);
         stream->writeInt(m_device);
+        stream->writeBool(m_twoStage);
+        stream->writeInt(m_firstStageSizeReduction);
     }
 
     bool preprocess(const Scene *scene, RenderQueue *queue, const RenderJob *job, int sceneResID, int sensorResID,
@@ -120,8 +126,37 @@ public:
         else Log(EError, "Unsupported reconstruction filter for the MI355X drmlt backend: %s", rfName.c_str());
 
         char err[512];
+        uint64_t seed = ((uint64_t) (uintptr_t) this << 16) ^ (uint64_t) job->getID(); // any distinct value works
+
+        // two-stage MLT (drmlt.cpp:406-418): the nested first stage is a second context on a reduced film; its
+        // developed image becomes the luminance image of the full render (util.cpp:96-199)
+        std::vector<float> importance;
+        if (m_twoStage) {
+            Log(EInfo, "Executing first MLT stage");
+            drmlt_scene small = sc;
+            small.camera.width = std::max(1, crop.x / m_firstStageSizeReduction);
+            small.camera.height = std::max(1, crop.y / m_firstStageSizeReduction);
+            small.camera.filter = DRMLT_FILTER_GAUSSIAN; small.camera.filter_param = 0.5f;
+            drmlt_config c1 = m_cfg;
+            c1.sample_count = m_cfg.sample_count * m_firstStageSizeReduction;
+            c1.acceptance_map = 0;
+            drmlt_ctx *first = drmlt_create(&c1, &small, m_device, err, sizeof err);
+            if (!first) Log(EError, "%s", err);
+            std::vector<float> img((size_t) small.camera.width * small.camera.height * 3);
+            int rc1 = drmlt_seed(first, seed ^ 0x1571, 0, NULL);
+            if (rc1 == DRMLT_OK)
+                rc1 = drmlt_run(first, (uint64_t) small.camera.width * small.camera.height * (uint64_t) c1.sample_count, &m_stop, NULL, NULL);
+            if (rc1 == DRMLT_OK) rc1 = drmlt_develop(first, NULL, img.data());
+            drmlt_destroy(first);
+            if (rc1 != DRMLT_OK) { Log(EWarn, "First-stage MLT process failed!"); return false; }
+            importance.resize((size_t) crop.x * crop.y);
+            drmlt_luminance_map(img.data(), small.camera.width, small.camera.height, crop.x, crop.y, importance.data());
+        }
+
         drmlt_ctx *ctx = drmlt_create(&m_cfg, &sc, m_device, err, sizeof err);
         if (!ctx) Log(EError, "%s", err); // throws, as the reference's parameter checks do
+        if (!importance.empty() && drmlt_set_importance_map(ctx, importance.data()) != DRMLT_OK)
+            Log(EError, "%s", drmlt_last_error(ctx));
 
         // separate direct pass stays on the host integrator (util.cpp:30-92), exactly as in the reference
         ref<Bitmap> directImage;
@@ -132,7 +167,6 @@ public:
         }
 
         double b = 0;
-        uint64_t seed = ((uint64_t) (uintptr_t) this << 16) ^ (uint64_t) job->getID(); // any distinct value works
         int rc = drmlt_seed(ctx, seed, 0, &b);
         if (rc == DRMLT_OK) {
             Log(EInfo, "Normalization factor computed: %lf", b);
@@ -253,6 +287,8 @@ private:
 
     drmlt_config m_cfg;
     int m_device;
+    bool m_twoStage = false;
+    int m_firstStageSizeReduction = 16;
     volatile int m_stop;
 };
 

@@ -106,7 +106,8 @@ typedef struct drmlt_config {
     int32_t  kelemen_style_weights;  /* pssmlt: Kelemen weights (default 1)        */
     int32_t  kelemen_style_mutation; /* pssmlt: Kelemen (1) or Gaussian (0)        */
     int32_t  no_light_image;     /* 1 = "lightImage" false (mmlt; default: true)   */
-    int32_t  reserved[7];
+    int32_t  timeout_s;          /* "timeout" default 0: stop drmlt_run after this many seconds (equal-time runs) */
+    int32_t  reserved[6];
 } drmlt_config;
 
 /* ---- flat scene description -------------------------------------------- */
@@ -238,6 +239,19 @@ int drmlt_film_clear(drmlt_ctx *ctx);
  * develop once the per-rank estimates have been averaged (drmlt.cpp:544). */
 void *drmlt_film_device_ptr(drmlt_ctx *ctx);
 int drmlt_set_luminance(drmlt_ctx *ctx, double b);
+
+/* Two-stage MLT ("twoStage", drmlt.cpp:278,406-418). The adaptor renders the
+ * first stage with a second context on a film reduced by
+ * firstStageSizeReduction (sample_count multiplied by it, gaussian filter, no
+ * direct image: BidirectionalUtils::mltLuminancePass, src/libbidir/util.cpp:96-199),
+ * turns its developed image into the full-size luminance image with
+ * drmlt_luminance_map (util.cpp:179-196 + core/rfilter.h:123-290) and hands
+ * it to the second-stage context BEFORE drmlt_seed. From then on every splat
+ * list is weighted by 1 / map[pixel] (SplatList::normalize,
+ * pathsampler.cpp:1001-1020) and drmlt_develop multiplies it back
+ * (drmlt_proc.cpp:824-845). lum_map: W*H floats, positive; NULL clears it. */
+int drmlt_set_importance_map(drmlt_ctx *ctx, const float *lum_map_or_null);
+int drmlt_luminance_map(const float *rgb_small, int w, int h, int W, int H, float *out_lum);
 /* Launch all kernels of this context on a caller-owned hipStream_t. */
 int drmlt_set_stream(drmlt_ctx *ctx, void *hip_stream);
 /* Timing of the dominant kernel for bench.py's roofline (HIP events on the

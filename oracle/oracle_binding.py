@@ -61,6 +61,8 @@ def lib(native=False):
         L.oracle_film_put.argtypes = [C.c_int, C.c_int, C.c_int, C.c_double, C.c_uint32, C.c_void_p, C.c_void_p,
                                       C.c_void_p]
         L.oracle_find_max_dim.argtypes = [C.c_int, C.c_int]
+        L.oracle_set_importance_map.argtypes = [C.c_void_p, C.c_void_p]
+        L.oracle_luminance_map.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
         L.oracle_find_max_dim_mmlt.argtypes = [C.c_int]
         L.oracle_roughconductor.argtypes = [C.c_int, C.c_double] + [C.c_void_p] * 3 + [C.c_uint32] + [C.c_void_p] * 7
         _libs[native] = L
@@ -161,6 +163,14 @@ class Oracle:
                                           ud.ctypes.data, n, dim, out, st.ctypes.data))
         return np.frombuffer(out, dtype=SPLAT_DTYPE).copy(), st
 
+    def set_importance_map(self, lum_map):
+        if lum_map is None:
+            self._chk(self.L.oracle_set_importance_map(self.h, None))
+            return
+        self._imp = np.ascontiguousarray(lum_map, dtype=np.float32)
+        assert self._imp.shape == (self.height, self.width)
+        self._chk(self.L.oracle_set_importance_map(self.h, self._imp.ctypes.data))
+
     def bootstrap_lum(self, seed, stream, n):
         out = np.empty(n, dtype=np.float32)
         self._chk(self.L.oracle_bootstrap_lum(self.h, seed, stream, n, out.ctypes.data))
@@ -247,3 +257,10 @@ def roughconductor(ggx, alpha, eta, k, wi, wo=None, sxy=None):
                                 wo_.ctypes.data if wo_ is not None else None, sxy_.ctypes.data if sxy_ is not None else None,
                                 ev.ctypes.data, pdf.ctypes.data, swo.ctypes.data, sw.ctypes.data, spdf.ctypes.data)
     return dict(eval=ev, pdf=pdf, wo=swo, weight=sw, spdf=spdf)
+
+
+def luminance_map(rgb_small, width, height):
+    src = np.ascontiguousarray(rgb_small, dtype=np.float32)
+    out = np.empty((height, width), dtype=np.float32)
+    lib().oracle_luminance_map(src.ctypes.data, src.shape[1], src.shape[0], width, height, out.ctypes.data)
+    return out

@@ -35,6 +35,7 @@ struct CtxBase {
     virtual int chainState(drmlt_splat *cur, float *u, uint32_t dim) = 0;
     virtual int renderPT(uint32_t spp, uint64_t seed, int nthreads, float *out) = 0;
     virtual int bootstrapLum(uint64_t seed, uint32_t stream, uint32_t n, float *out) = 0;
+    virtual int setImportance(const float *map) = 0;
     virtual int mmltRender(int depth, uint64_t n, uint64_t seed, int lightImage, int nthreads, float *out, double *strat) = 0;
     virtual int mmltEval(int depth, int lightImage, const float *uSensor, const float *uEmitter, const float *uDirect,
                          uint32_t n, uint32_t dim, drmlt_splat *out, int *st) = 0;
@@ -172,12 +173,20 @@ template <typename F> struct Ctx : CtxBase {
         return 0;
     }
 
+    std::vector<float> importance;
+    int setImportance(const float *map) override {
+        if (seeded) { error = "the importance map must be set before seed"; return DRMLT_E_STATE; }
+        if (!map) { importance.clear(); c.importance = nullptr; return 0; }
+        importance.assign(map, map + (size_t) scene.width * scene.height);
+        c.importance = importance.data(); c.impW = scene.width; c.impH = scene.height;
+        return 0;
+    }
     int filmRead(float *out) override {
         for (size_t i = 0; i < accum.size(); ++i) out[i] = (float) accum[i];
         return 0;
     }
     int developImage(const float *direct, float *out) override {
-        develop(accum, scene.width, scene.height, b, cfg.acceptance_map != 0, direct, out);
+        develop(accum, scene.width, scene.height, b, cfg.acceptance_map != 0, direct, out, c.importance);
         return 0;
     }
     int stats(drmlt_stats *o) override {
@@ -487,6 +496,8 @@ void oracle_roughconductor(int ggx, double alpha, const double *eta, const doubl
     }
 }
 
+int oracle_set_importance_map(void *p, const float *map) { GUARD(static_cast<CtxBase *>(p)->setImportance(map)) }
+void oracle_luminance_map(const float *rgb, int w, int h, int W, int H, float *out) { luminanceMap(rgb, w, h, W, H, out); }
 int oracle_find_max_dim(int maxDepth, int rrDepth) { return findMaxDimensionsPath(maxDepth, rrDepth); }
 int oracle_find_max_dim_mmlt(int depth) { return findMaxDimensionsMMLT(depth); }
 

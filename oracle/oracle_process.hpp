@@ -111,6 +111,8 @@ template <typename F> struct Config {
     F luminance = 1; // b (pssmlt Kelemen weights)
     int maxDim;
     bool fixEmitterPath = false, lightImage = true; // technique=mmlt
+    const float *importance = nullptr;              // two-stage MLT luminance image (W x H), drmlt.cpp:406-418
+    int impW = 0, impH = 0;
 };
 
 // Evaluator over a scene: PathSampler::sampleSplats(EUnidirectional)
@@ -228,7 +230,7 @@ public:
         m_sampler.fillReplay(); // tops up from the same addressed stream (dims >= consumed)
         m_sampler.setRandom(&m_random);
         bool ok = std::abs((m_current.luminance - (F) seed.luminance) / (F) seed.luminance) <= Consts<F>::Epsilon;
-        m_current.normalize();
+        m_current.normalize(m_cfg.importance, m_cfg.impW, m_cfg.impH);
         return ok;
     }
 
@@ -268,7 +270,7 @@ private:
             m_sampler.setLargeStep(largeStep);
 
             m_eval(m_sampler, first, &st);
-            first.normalize();
+            first.normalize(m_cfg.importance, m_cfg.impW, m_cfg.impH);
             st.mutations++;
             if (!isInvalid(first.luminance)) {
                 a1 = clamp1(first.luminance / m_current.luminance);
@@ -281,12 +283,12 @@ private:
                 // fixEmitterPath: the emitter sampler moves in the second stage only for pure light tracing (:566-573)
                 m_sampler.nextStage(m_cfg.fixEmitterPath && m_current.t == 1);
                 m_eval(m_sampler, second, &st);
-                second.normalize();
+                second.normalize(m_cfg.importance, m_cfg.impW, m_cfg.impH);
                 if (!isInvalid(second.luminance)) {
                     if (m_cfg.type == EGreen) {
                         m_sampler.setReverse(true);
                         m_eval(m_sampler, reverse, &st);
-                        reverse.normalize();
+                        reverse.normalize(m_cfg.importance, m_cfg.impW, m_cfg.impH);
                         F aReverse = isInvalid(reverse.luminance) ? F(0) : clamp1(reverse.luminance / second.luminance);
                         if (aReverse != 1) {
                             F lumRatio = second.luminance / m_current.luminance;
@@ -368,7 +370,7 @@ private:
             bool largeStep = (F) m_random.nextFloat() < m_cfg.pLarge;
             m_sampler.setLargeStep(largeStep);
             m_eval(m_sampler, proposed, &st);
-            proposed.normalize();
+            proposed.normalize(m_cfg.importance, m_cfg.impW, m_cfg.impH);
             st.mutations++;
             if (!isInvalid(proposed.luminance)) {
                 a = clamp1(proposed.luminance / m_current.luminance);
@@ -379,7 +381,7 @@ private:
             if (doSecond) {
                 m_sampler.nextStage(m_cfg.fixEmitterPath && m_current.t == 1); // :306-312
                 m_eval(m_sampler, proposed, &st);
-                proposed.normalize();
+                proposed.normalize(m_cfg.importance, m_cfg.impW, m_cfg.impH);
                 if (isInvalid(proposed.luminance)) { a = 0; accept = false; }
                 else {
                     a = clamp1(proposed.luminance / m_current.luminance);
@@ -430,7 +432,7 @@ public:
         m_sampler.accept();
         m_sampler.setRandom(&m_random);
         bool ok = std::abs((m_current.luminance - (F) seed.luminance) / (F) seed.luminance) <= Consts<F>::Epsilon;
-        m_current.normalize();
+        m_current.normalize(m_cfg.importance, m_cfg.impW, m_cfg.impH);
         return ok;
     }
     void run(uint64_t nMutations, Film<F> &film, Stats &st) {
@@ -444,7 +446,7 @@ public:
             bool largeStep = (F) m_random.nextFloat() < pLarge;
             m_sampler.setLargeStep(largeStep);
             m_eval(m_sampler, proposed, &st);
-            proposed.normalize();
+            proposed.normalize(m_cfg.importance, m_cfg.impW, m_cfg.impH);
             st.mutations++;
             F a = std::min(F(1), proposed.luminance / m_current.luminance);
             if (std::isnan(proposed.luminance) || proposed.luminance < 0) a = 0;
@@ -499,14 +501,50 @@ private:
 
 // develop(): out = accum * (b / mean_lum(accum)) + direct   (drmlt_proc.cpp:824-849)
 inline void develop(const std::vector<double> &accum, int w, int h, double b, bool acceptanceMap, const float *direct,
-                    float *out) {
+                    float *out, const float *importance = nullptr) {
     size_t n = (size_t) w * h;
     double avg = 0;
     for (size_t i = 0; i < n; ++i)
-        avg += accum[i * 3] * 0.212671 + accum[i * 3 + 1] * 0.715160 + accum[i * 3 + 2] * 0.072169;
+        avg += (accum[i * 3] * 0.212671 + accum[i * 3 + 1] * 0.715160 + accum[i * 3 + 2] * 0.072169) *
+               (importance ? (double) importance[i] : 1.0);
     avg /= (double) n;
     double factor = acceptanceMap ? 1.0 : b / avg;
-    for (size_t i = 0; i < n * 3; ++i) out[i] = (float) (accum[i] * factor + (direct ? (double) direct[i] : 0.0));
+    for (size_t i = 0; i < n * 3; ++i)
+        out[i] = (float) (accum[i] * factor * (importance ? (double) importance[i / 3] : 1.0) + (direct ? (double) direct[i] : 0.0));
+}
+
+// Tail of BidirectionalUtils::mltLuminancePass (src/libbidir/util.cpp:179-196): luminance of the first-stage image,
+// up-sampled by Bitmap::resample (bitmap.cpp:2230-2330: X pass, then Y pass) through Resampler
+// (core/rfilter.h:123-198,232-290) with the gaussian filter (gaussian.cpp: stddev 0.5, radius 2), EClamp lookups,
+// values clamped to [0, inf).
+inline void luminanceMap(const float *rgb, int w, int h, int W, int H, float *out) {
+    std::vector<double> lum((size_t) w * h);
+    for (size_t i = 0; i < lum.size(); ++i)
+        lum[i] = (double) rgb[3 * i] * 0.212671 + (double) rgb[3 * i + 1] * 0.715160 + (double) rgb[3 * i + 2] * 0.072169;
+    const double stddev = 0.5, fradius = 4 * stddev, alpha = -1.0 / (2 * stddev * stddev), bias = std::exp(alpha * fradius * fradius);
+    auto rf = [&](double x) { return std::max(0.0, std::exp(alpha * x * x) - bias); };
+    auto resample1d = [&](const std::vector<double> &src, int nSrc, size_t strideSrc, size_t offSrc, std::vector<double> &dst, int nDst,
+                          size_t strideDst, size_t offDst) {
+        double radius = fradius, invScale = 1;
+        if (nDst < nSrc) { double scale = (double) nSrc / nDst; invScale = 1 / scale; radius *= scale; }
+        int taps = (int) std::ceil(radius * 2);
+        std::vector<double> wts(taps);
+        for (int i = 0; i < nDst; ++i) {
+            double center = (i + 0.5) / nDst * nSrc;
+            int start = (int) std::floor(center - radius + 0.5);
+            double sum = 0;
+            for (int j = 0; j < taps; ++j) { wts[j] = rf((start + j + 0.5 - center) * invScale); sum += wts[j]; }
+            double r = 0;
+            for (int j = 0; j < taps; ++j) r += src[offSrc + (size_t) std::min(std::max(start + j, 0), nSrc - 1) * strideSrc] * (wts[j] / sum);
+            dst[offDst + (size_t) i * strideDst] = std::max(0.0, r);
+        }
+    };
+    std::vector<double> tmp((size_t) W * h), res((size_t) W * H);
+    if (w != W) { for (int y = 0; y < h; ++y) resample1d(lum, w, 1, (size_t) y * w, tmp, W, 1, (size_t) y * W); }
+    else tmp = lum;
+    if (h != H) { for (int x = 0; x < W; ++x) resample1d(tmp, h, (size_t) W, (size_t) x, res, H, (size_t) W, (size_t) x); }
+    else res = tmp;
+    for (size_t i = 0; i < res.size(); ++i) out[i] = (float) res[i];
 }
 
 } // namespace oracle

@@ -554,7 +554,16 @@ template <typename F> struct SplatList {
     F luminance = 0;
     int nDims = 0, nRays = 0;
     int s = 0, t = 0; // technique=mmlt: SplatList::setStrategy (pathsampler.cpp:129)
-    void normalize() { // pathsampler.cpp:1001-1028 (no importance map)
+    // pathsampler.cpp:1001-1028. `importance` (two-stage MLT): W x H luminance image, row-major, or null
+    void normalize(const float *importance = nullptr, int w = 0, int h = 0) {
+        if (importance) {
+            luminance = 0;
+            if (!value.isZero()) {
+                int ix = std::min(std::max(0, (int) px), w - 1), iy = std::min(std::max(0, (int) py), h - 1);
+                value /= (F) importance[ix + iy * w];
+                luminance = oracle::luminance(value);
+            }
+        }
         if (luminance > 0) value *= F(1) / luminance;
     }
 };

@@ -1,0 +1,91 @@
+"""GPU parity for two-stage MLT (`twoStage`) and the equal-time mode (`timeout`), through the C-ABI."""
+import time
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+LUMW = np.array([0.212671, 0.715160, 0.072169])
+
+
+def test_luminance_map_matches_oracle(pkg, ob, native_lib):
+    rng = np.random.default_rng(5)
+    small = rng.random((8, 8, 3)).astype(np.float32) * 3
+    a, b = pkg.binding.luminance_map(small, 128, 128), ob.luminance_map(small, 128, 128)
+    np.testing.assert_allclose(a, b, rtol=2e-5, atol=1e-6)          # fp32 host statement vs fp64 oracle
+    a, b = pkg.binding.luminance_map(small, 20, 50), ob.luminance_map(small, 20, 50)
+    np.testing.assert_allclose(a, b, rtol=2e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("tech", ["path", "mmlt"])
+def test_weighted_chains_track_the_oracle(pkg, ob, tech, native_lib):
+    sd = pkg.scenes.cornell_c2(32)
+    abi = pkg.abi
+    ref = pkg.Context(abi.make_config(max_depth=6, rr_depth=100, direct_samples=-1, work_units=64), sd).render_pt(256, seed=3)
+    imp = np.maximum(pkg.binding.luminance_map(ref.reshape(4, 8, 4, 8, 3).mean((1, 3)), 32, 32), 1e-3)
+    n_chains, n_mut = 2048, 40
+    cfg = abi.make_config(technique=tech, type="orbital", max_depth=6, direct_samples=-1, work_units=n_chains,
+                          sample_count=1, luminance_samples=20000)
+    ctx, orc = pkg.Context(cfg, sd), ob.Oracle(abi, cfg, sd, 64)
+    ctx.set_importance_map(imp); orc.set_importance_map(imp)
+    bg, bo = ctx.seed(0xABCD), orc.seed(0xABCD)
+    assert bg == pytest.approx(bo, rel=1e-3)
+    dim = 34 if tech == "path" else 27
+    (c0g, u0g), (c0o, u0o) = ctx.chain_state(dim), orc.chain_state(dim)
+    same0 = np.abs(c0g["luminance"] - c0o["luminance"]) <= 1e-3 * c0o["luminance"]   # same seed, same weighted f
+    assert same0.mean() > 0.5
+    ctx.run(n_chains * n_mut); orc.run(n_chains * n_mut, 8)
+    (cg, ug), (co, uo) = ctx.chain_state(dim), orc.chain_state(dim)
+    tracked = same0 & (np.abs(cg["luminance"] - co["luminance"]) <= 2e-3 * co["luminance"]) & \
+        (np.abs(cg["x"] - co["x"]) < 1e-2) & (np.abs(cg["y"] - co["y"]) < 1e-2)
+    assert tracked.sum() / same0.sum() > 0.95, tracked.sum() / same0.sum()
+    sg, so = ctx.stats(), orc.stats()
+    for k in ("first", "second", "overall"):
+        bg_, bo_ = getattr(sg, k + "_base"), getattr(so, k + "_base")
+        pg, po = getattr(sg, k + "_acc") / bg_, getattr(so, k + "_acc") / bo_
+        assert abs(pg - po) < 4 * np.sqrt(po * (1 - po) / bo_) + 0.015, (k, pg, po)
+    ig, io = ctx.develop(), orc.develop()
+    assert (ig @ LUMW).mean() == pytest.approx((io @ LUMW).mean(), rel=5e-3)
+    blk = lambda a: (a @ LUMW).reshape(8, 4, 8, 4).mean((1, 3))
+    assert np.abs(blk(ig) - blk(io)).sum() / blk(io).sum() < 0.1
+    with pytest.raises(pkg.DrmltError, match="before drmlt_seed"):
+        ctx.set_importance_map(imp)
+
+
+def test_two_stage_render_is_unbiased_and_flatter(pkg, native_lib):
+    sd = pkg.scenes.glass_sphere(64)
+    abi = pkg.abi
+    ref = pkg.Context(abi.make_config(max_depth=6, rr_depth=100, direct_samples=-1, work_units=64), sd).render_pt(4096, seed=3)
+    # Seeds are drawn in proportion to the UNWEIGHTED luminance (pathsampler.cpp:901-903) while the chains' target is
+    # f / importance: a start-up bias the reference shares, negligible for its long chains -> long chains here too
+    cfg = abi.make_config(technique="path", type="orbital", max_depth=6, direct_samples=-1, work_units=2048,
+                          sample_count=2048, luminance_samples=200000)
+    img, imp, b = pkg.binding.render_two_stage(cfg, sd, 0x5EED, size_reduction=16)
+    assert imp.shape == (64, 64) and imp.min() > 0
+    assert b == pytest.approx((ref @ LUMW).mean(), rel=0.02)
+    blk = lambda a: a.reshape(8, 8, 8, 8, 3).mean((1, 3))
+    assert np.abs(blk(img) - blk(ref)).mean() / ref.mean() < 0.03
+    plain = pkg.Context(cfg, sd)
+    plain.seed(0x5EED); plain.run(64 * 64 * 2048)
+    ip = plain.develop()
+    # relative error in the darkest quarter of the image drops (what two-stage MLT is for, drmlt.cpp:270-277)
+    lr = ref @ LUMW
+    dark = (lr > 0) & (lr < np.quantile(lr[lr > 0], 0.25))      # directly visible emitter pixels are 0 in this estimator
+    err = lambda a: np.mean(((a @ LUMW) - lr)[dark] ** 2 / lr[dark] ** 2)
+    assert err(img) < err(ip)
+
+
+def test_timeout_stops_the_run(pkg, native_lib):
+    sd = pkg.scenes.cornell_c2(64)
+    cfg = pkg.abi.make_config(technique="path", type="orbital", max_depth=8, direct_samples=-1, work_units=65536,
+                              sample_count=1, luminance_samples=1000, timeout_s=1)
+    ctx = pkg.Context(cfg, sd)
+    ctx.seed(1)
+    t0 = time.time()
+    ctx.run(65536 * 200000)                      # minutes of work without the deadline
+    dt = time.time() - t0
+    st = ctx.stats()
+    assert 0.9 < dt < 3.0
+    assert 0 < st.mutations < 65536 * 200000 and st.mutations % 65536 == 0
+    img = ctx.develop()
+    assert np.isfinite(img).all() and img.mean() > 0
