@@ -24,7 +24,8 @@ class Config(C.Structure):
         ("average_luminance", C.c_float),
         ("acceptance_map", C.c_int32), ("timid_after_large", C.c_int32), ("fix_emitter_path", C.c_int32),
         ("use_mixture", C.c_int32), ("kelemen_style_weights", C.c_int32), ("kelemen_style_mutation", C.c_int32),
-        ("no_light_image", C.c_int32), ("timeout_s", C.c_int32), ("reserved", C.c_int32 * 6),
+        ("no_light_image", C.c_int32), ("timeout_s", C.c_int32), ("no_direct_sampling", C.c_int32),
+        ("reserved", C.c_int32 * 5),
     ]
 
 

@@ -107,7 +107,8 @@ typedef struct drmlt_config {
     int32_t  kelemen_style_mutation; /* pssmlt: Kelemen (1) or Gaussian (0)        */
     int32_t  no_light_image;     /* 1 = "lightImage" false (mmlt; default: true)   */
     int32_t  timeout_s;          /* "timeout" default 0: stop drmlt_run after this many seconds (equal-time runs) */
-    int32_t  reserved[6];
+    int32_t  no_direct_sampling; /* 1 = "directSampling" false (default true; bdpt only, forced false for mmlt) */
+    int32_t  reserved[5];
 } drmlt_config;
 
 /* ---- flat scene description -------------------------------------------- */

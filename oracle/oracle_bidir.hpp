@@ -30,6 +30,7 @@ template <typename F> struct PVertex {
     int shape = -1, bsdf = -1, emitter = -1;
     V3<F> weight[2];
     F pdf[2] = {0, 0};
+    F rrWeight = 1; // russian roulette compensation of the random walk (vertex.cpp:46,314-321)
     int measure = MInvalid;
     bool degenerate = false;
     bool isConnectable() const { return !degenerate && measure != MDiscrete; }
@@ -86,9 +87,10 @@ public:
 
     // ---- vertex sampling (PathVertex::sampleNext + PathEdge::sampleNext) ---------------------
     bool sampleNext(PVertex<F> &cur, const PVertex<F> *pred, const PEdge<F> *predEdge, PEdge<F> &succEdge, PVertex<F> &succ,
-                    int mode, Sampler<F> &sampler, uint64_t *rays) const {
+                    int mode, Sampler<F> &sampler, uint64_t *rays, bool russianRoulette = false, V3<F> *throughput = nullptr) const {
         succ = PVertex<F>();
         succEdge = PEdge<F>();
+        cur.rrWeight = 1;
         Ray<F> ray;
         switch (cur.type) {
             case VEmitterSupernode: {
@@ -161,7 +163,7 @@ public:
                 bool delta;
                 V3<F> w = scene.bsdfSample(bsdf, wi, sx, sy, woL, pdf, eta, delta, mode);
                 if (w.isZero()) return false;
-                (void) eta;
+
                 cur.weight[mode] = w;
                 cur.pdf[mode] = pdf;
                 cur.measure = delta ? MDiscrete : MSolidAngle;
@@ -178,11 +180,22 @@ public:
                 } else { // ENonSymmetric: eval in the reverse direction / pdf
                     cur.weight[1 - mode] = scene.bsdfEvalDelta(bsdf, woL, wi, 1 - mode) / pdfRev;
                 }
+                // "For BDPT & russian roulette, track radiance * eta^2" (vertex.cpp:263-265)
+                if (throughput && mode == ERadiance && eta != 1) *throughput *= eta * eta;
                 // adjoint BSDF for shading normals (adjointComp = true); 1 up to rounding for flat shading
                 if (mode == EImportance) cur.weight[EImportance] *= std::abs((wi.z * woDotGeoN) / (woL.z * wiDotGeoN));
                 else cur.weight[EImportance] *= std::abs((woL.z * wiDotGeoN) / (wi.z * woDotGeoN));
                 ray = Ray<F>{cur.p, wo, Consts<F>::Epsilon, std::numeric_limits<F>::infinity()};
                 break;
+            }
+        }
+        if (throughput) { // vertex.cpp:310-324: the random walk's russian roulette
+            *throughput *= cur.weight[mode];
+            if (russianRoulette) {
+                F q = std::min(throughput->max(), F(0.95));
+                if (sampler.next1D() > q) { cur.measure = MInvalid; return false; }
+                cur.rrWeight = F(1) / q;
+                *throughput *= cur.rrWeight;
             }
         }
         // PathEdge::sampleNext: next surface along the ray
@@ -210,7 +223,8 @@ public:
         return true;
     }
 
-    int randomWalk(SubPath<F> &path, Sampler<F> &sampler, int nSteps, int mode, uint64_t *rays) const {
+    int randomWalk(SubPath<F> &path, Sampler<F> &sampler, int nSteps, int mode, uint64_t *rays, int rrStart = -1) const {
+        V3<F> throughput(1);
         for (int i = 0; i < nSteps; ++i) {
             size_t last = path.v.size() - 1;
             PVertex<F> succ;
@@ -218,7 +232,7 @@ public:
             const PVertex<F> *pred = last >= 1 ? &path.v[last - 1] : nullptr;
             const PEdge<F> *predEdge = path.e.empty() ? nullptr : &path.e.back();
             PVertex<F> cur = path.v[last];
-            if (!sampleNext(cur, pred, predEdge, succEdge, succ, mode, sampler, rays)) return i;
+            if (!sampleNext(cur, pred, predEdge, succEdge, succ, mode, sampler, rays, rrStart != -1 && i >= rrStart, &throughput)) return i;
             path.v[last] = cur;
             path.v.push_back(succ);
             path.e.push_back(succEdge);
@@ -446,6 +460,75 @@ public:
         list.luminance = oracle::luminance(value);
     }
 
+    // ---- PathSampler::sampleSplats, EBidirectional branch (pathsampler.cpp:321-527), directSampling = false ----------
+    void sampleSplatsBDPT(Sampler<F> &emitterSampler, Sampler<F> &sensorSampler, int maxDepth, int rrDepth, bool excludeDirect,
+                          bool lightImage, SplatList<F> &list) const {
+        list.px = list.py = 0; list.value = V3<F>(0); list.luminance = 0; list.nDims = 0; list.nRays = 0;
+        list.more.clear(); list.hasMain = false; list.s = list.t = 0;
+        uint64_t rays = 0;
+        SubPath<F> em, se;
+        em.v.emplace_back(); em.v[0].type = VEmitterSupernode; em.v[0].degenerate = false;
+        se.v.emplace_back(); se.v[0].type = VSensorSupernode; se.v[0].degenerate = true;
+        // m_emitterDepth = maxDepth (pinhole: degenerate sensor), m_sensorDepth = maxDepth + 1 (area emitters), :53-71
+        randomWalk(em, emitterSampler, maxDepth, EImportance, &rays, rrDepth);
+        randomWalk(se, sensorSampler, maxDepth + 1, ERadiance, &rays, rrDepth);
+        std::vector<V3<F>> impW(em.v.size()), radW(se.v.size());
+        impW[0] = radW[0] = V3<F>(1);
+        for (size_t i = 1; i < em.v.size(); ++i) impW[i] = impW[i - 1] * em.v[i - 1].weight[EImportance] * em.v[i - 1].rrWeight;
+        for (size_t i = 1; i < se.v.size(); ++i) radW[i] = radW[i - 1] * se.v[i - 1].weight[ERadiance] * se.v[i - 1].rrWeight;
+        if (se.v.size() > 2) {
+            F sx = 0, sy = 0;
+            samplePositionOf(se.v[2].p - se.v[1].p, sx, sy);
+            list.hasMain = true; list.px = sx; list.py = sy; list.value = V3<F>(0);
+        }
+        for (int s = (int) em.v.size() - 1; s >= 0; --s) {
+            int minT = std::max(2 - s, lightImage ? 0 : 2), maxT = (int) se.v.size() - 1;
+            if (maxDepth != -1) maxT = std::min(maxT, maxDepth + 1 - s);
+            for (int t = maxT; t >= minT; --t) {
+                PVertex<F> &vs = em.v[s], &vt = se.v[t];
+                const PVertex<F> *vsPred = s >= 1 ? &em.v[s - 1] : nullptr, *vtPred = t >= 1 ? &se.v[t - 1] : nullptr;
+                struct Restore { PVertex<F> &v; int m; ~Restore() { v.measure = m; } } r0{vs, vs.measure}, r1{vt, vt.measure};
+                int depth = s + t - 1;
+                V3<F> value;
+                F geo = 1;
+                F sx = 0, sy = 0;
+                if (vs.type == VEmitterSupernode) {
+                    if (vt.type != VSurface || vt.emitter < 0) continue;       // cast(EEmitterSample)
+                    vt.type = VEmitterSample; vt.n = vt.shFrame.n; vt.measure = MArea; vt.degenerate = false;
+                    r1.m = MArea; // the cast is permanent (vertex.cpp:1397-1403)
+                    value = radW[t] * eval(vs, vsPred, &vt, EImportance) * eval(vt, vtPred, &vs, ERadiance);
+                    if (value.isZero()) continue;
+                } else if (vt.type == VSensorSupernode) {
+                    continue; // cast(ESensorSample) needs a sensor shape: a pinhole has none
+                } else {
+                    if (vs.degenerate || vt.degenerate) continue;
+                    value = impW[s] * radW[t] * eval(vs, vsPred, &vt, EImportance) * eval(vt, vtPred, &vs, ERadiance);
+                    vs.measure = vt.measure = MArea;
+                    if (value.isZero()) continue;
+                    V3<F> d = vs.p - vt.p;
+                    F length = d.length();
+                    if (length == 0) continue;
+                    d /= length;
+                    Ray<F> ray{vt.p, d, vt.isOnSurface() ? Consts<F>::Epsilon : F(0), length * (vs.isOnSurface() ? (1 - Consts<F>::ShadowEpsilon) : F(1))};
+                    Intersection<F> its;
+                    ++rays;
+                    if (scene.rayIntersect(ray, its)) continue;
+                    geo = F(1) / (length * length);
+                    if (vs.isOnSurface() && vs.isConnectable()) geo *= absDot(vsShadingNormal(vs), d);
+                    if (vt.isOnSurface() && vt.isConnectable()) geo *= absDot(vsShadingNormal(vt), d);
+                }
+                if (excludeDirect && depth <= 2) continue;
+                value *= geo;
+                value *= miWeight(em, se, s, t, lightImage);
+                if (vt.type == VSensorSample && !samplePositionOf(vs.p - vt.p, sx, sy)) continue;
+                if (t < 2) { list.more.push_back({sx, sy, value}); }
+                else { list.value += value; }
+                list.luminance += oracle::luminance(value);
+            }
+        }
+        list.nRays = (int) rays;
+    }
+
 private:
     static V3<F> vsShadingNormal(const PVertex<F> &v) { return v.type == VSurface ? v.shFrame.n : v.n; }
 };
@@ -457,6 +540,13 @@ inline int findMaxDimensionsMMLT(int depth) {
     return maxDim;
 }
 
+// pssmlt_utils.h:69-75: sensor = emitter = (maxDepth + 2) * (2 + RR) rounded up to even; direct = 0 without direct sampling
+inline int findMaxDimensionsBDPT(int maxDepth, int rrDepth) {
+    int maxDim = (maxDepth + 2) * (2 + (rrDepth < maxDepth ? 1 : 0));
+    if (maxDim % 2 == 1) ++maxDim;
+    return maxDim;
+}
+
 // The sensor / emitter / direct samplers of one chain (drmlt_proc.cpp:84-141). They share the chain's
 // Random; here each gets its own draw-index range inside a (tag, mutation) stream:
 // sensor [0, 2D), emitter [2D, 4D), direct [4D, ...), D = findMaxDimensionsMMLT(maxDepth) for every chain.
@@ -464,17 +554,21 @@ template <typename F> struct MMLTSamplers {
     DRMLTSampler<F> sensor, emitter, direct;
     int depth = -1;
     uint32_t dmax;
+    bool bdpt; // technique=bdpt: same triple, dimensions independent of the seed, direct sampler unused (directSampling=false)
     template <typename Cfg>
     MMLTSamplers(const Cfg &cfg, Random *r)
-        : sensor(cfg, r), emitter(cfg, r), direct(cfg, r), dmax((uint32_t) findMaxDimensionsMMLT(cfg.maxDepth)) {
-        direct.setStagesToIdentity();                      // the strategy stays fixed in small steps (:133-135)
-        if (cfg.fixEmitterPath) emitter.handleLightTracing(); // :136-140
+        : sensor(cfg, r), emitter(cfg, r), direct(cfg, r), bdpt(cfg.technique == DRMLT_TECH_BDPT) {
+        dmax = (uint32_t) (bdpt ? findMaxDimensionsBDPT(cfg.maxDepth, cfg.rrDepth) : findMaxDimensionsMMLT(cfg.maxDepth));
+        if (!bdpt) {
+            direct.setStagesToIdentity();                      // the strategy stays fixed in small steps (:133-135)
+            if (cfg.fixEmitterPath) emitter.handleLightTracing(); // :136-140
+        }
     }
     void setMaxDim(size_t) {}
     void configureForSeed(int d) { // :452-464
         depth = d;
-        size_t D = (size_t) findMaxDimensionsMMLT(d);
-        sensor.setMaxDim(D); emitter.setMaxDim(D); direct.setMaxDim(1);
+        size_t D = bdpt ? (size_t) dmax : (size_t) findMaxDimensionsMMLT(d);
+        sensor.setMaxDim(D); emitter.setMaxDim(D); direct.setMaxDim(bdpt ? 0 : 1);
         sensor.setDrawBase(0); emitter.setDrawBase(2 * dmax); direct.setDrawBase(4 * dmax);
     }
     void reset() { emitter.reset(); sensor.reset(); direct.reset(); }
@@ -513,6 +607,26 @@ template <typename F> struct MMLTEvaluator {
         auto consumed = [&]() { return shared ? sensor.sampleIndex : emitter.sampleIndex + sensor.sampleIndex + direct.sampleIndex; };
         size_t before = consumed();
         bd.sampleSplatsMMLT(emitter, sensor, direct, depth, maxDepth, excludeDirect, lightImage, list, s_, t_);
+        list.nDims = (int) (consumed() - before);
+        if (st) { st->path_evals++; st->rays += (uint64_t) list.nRays; }
+    }
+    int width() const { return scene->width; }
+    int height() const { return scene->height; }
+};
+
+// Evaluator over a scene: PathSampler::sampleSplats(EBidirectional), directSampling = false
+template <typename F> struct BDPTEvaluator {
+    const Scene<F> *scene;
+    int maxDepth, rrDepth;
+    bool excludeDirect, lightImage;
+    void operator()(MMLTSamplers<F> &set, SplatList<F> &list, Stats *st) const { run(set.emitter, set.sensor, list, st); }
+    void operator()(ReplayableSampler<F> &s, SplatList<F> &list, Stats *st) const { run(s, s, list, st); }
+    void run(Sampler<F> &emitter, Sampler<F> &sensor, SplatList<F> &list, Stats *st) const {
+        Bidir<F> bd(*scene);
+        const bool shared = &emitter == &sensor;
+        auto consumed = [&]() { return shared ? sensor.sampleIndex : emitter.sampleIndex + sensor.sampleIndex; };
+        size_t before = consumed();
+        bd.sampleSplatsBDPT(emitter, sensor, maxDepth, rrDepth, excludeDirect, lightImage, list);
         list.nDims = (int) (consumed() - before);
         if (st) { st->path_evals++; st->rays += (uint64_t) list.nRays; }
     }

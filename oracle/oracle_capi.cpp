@@ -36,6 +36,8 @@ struct CtxBase {
     virtual int renderPT(uint32_t spp, uint64_t seed, int nthreads, float *out) = 0;
     virtual int bootstrapLum(uint64_t seed, uint32_t stream, uint32_t n, float *out) = 0;
     virtual int setImportance(const float *map) = 0;
+    virtual int bdptRender(uint64_t n, uint64_t seed, int nthreads, float *out) = 0;
+    virtual int bdptEval(const float *uSensor, const float *uEmitter, uint32_t n, uint32_t dim, float *out, uint32_t stride) = 0;
     virtual int mmltRender(int depth, uint64_t n, uint64_t seed, int lightImage, int nthreads, float *out, double *strat) = 0;
     virtual int mmltEval(int depth, int lightImage, const float *uSensor, const float *uEmitter, const float *uDirect,
                          uint32_t n, uint32_t dim, drmlt_splat *out, int *st) = 0;
@@ -50,9 +52,12 @@ template <typename F> struct Ctx : CtxBase {
     std::vector<std::unique_ptr<DRChain<F, SceneEvaluator<F>>>> chains;
     std::vector<std::unique_ptr<PSSMLTChain<F, SceneEvaluator<F>>>> pchains;
     using MChain = DRChain<F, MMLTEvaluator<F>, MMLTSamplers<F>>;
+    using BChain = DRChain<F, BDPTEvaluator<F>, MMLTSamplers<F>>;
     MMLTEvaluator<F> meval;
+    BDPTEvaluator<F> beval;
     std::vector<std::unique_ptr<MChain>> mchains;
-    bool mmlt = false;
+    std::vector<std::unique_ptr<BChain>> bchains;
+    bool mmlt = false, bdpt = false;
     std::vector<double> accum;
     Stats st;
     double b = 0;
@@ -60,8 +65,14 @@ template <typename F> struct Ctx : CtxBase {
 
     std::string init(const drmlt_config &in, const drmlt_scene &s) {
         cfg = in;
-        if (in.technique != DRMLT_TECH_PATH && in.technique != DRMLT_TECH_MMLT) return "oracle: technique=bdpt is not restated";
         mmlt = in.technique == DRMLT_TECH_MMLT;
+        bdpt = in.technique == DRMLT_TECH_BDPT;
+        // With directSampling=true (the reference's default) its bdpt chains overrun the direct sampler: it gets
+        // maxDepth components (pssmlt_utils.h:75) but every s = 1 / t = 1 connection draws two (pathsampler.cpp:424-452),
+        // and primarySample raises "Exceeded maximum dimension" (drmlt_sampler.cpp:256-258). Only the variant that runs is restated.
+        if (bdpt && !in.no_direct_sampling) return "technique=bdpt needs directSampling=false (no_direct_sampling=1)";
+        if (bdpt && in.algo == DRMLT_ALGO_PSSMLT) return "oracle: pssmlt over technique=bdpt is not restated";
+        if (bdpt && in.timid_after_large) return "timidAfterLarge is not restated for technique=bdpt";
         if (mmlt && in.max_depth <= 0) return "Impossible to use MMLT with no max depth"; // drmlt.cpp:213-215
         if (mmlt && in.algo == DRMLT_ALGO_PSSMLT) return "oracle: pssmlt over technique=mmlt is not restated";
         // A rejected large step re-draws the strategy; its second stage (and Green's reverse path) then reads an
@@ -81,7 +92,8 @@ template <typename F> struct Ctx : CtxBase {
         c.kelemenMutation = in.kelemen_style_mutation != 0;
         c.pLarge = in.p_large; c.sigma = in.sigma; c.scaleSecond = in.scale_second;
         c.maxDim = findMaxDimensionsPath(in.max_depth, in.rr_depth);
-        c.fixEmitterPath = in.fix_emitter_path != 0; c.lightImage = in.no_light_image == 0;
+        c.fixEmitterPath = in.fix_emitter_path != 0; c.lightImage = in.no_light_image == 0; c.technique = in.technique;
+        beval = BDPTEvaluator<F>{&scene, c.maxDepth, c.rrDepth, c.separateDirect, c.lightImage};
         meval = MMLTEvaluator<F>{&scene, c.maxDepth, c.separateDirect, c.lightImage};
         if (c.acceptanceMap && scene.filterType != DRMLT_FILTER_BOX) return "Box filter required for acceptance map!";
         eval = SceneEvaluator<F>{&scene, c.maxDepth, c.rrDepth, c.separateDirect};
@@ -109,6 +121,7 @@ template <typename F> struct Ctx : CtxBase {
         for (uint32_t i = 0; i < n; ++i) {
             s.setSampleIndex(i);
             if (mmlt) { s.depth = (int) (i % (uint32_t) cfg.max_depth) + 1; meval(s, l, nullptr); out[i] = (float) l.luminance; continue; }
+            if (bdpt) { beval(s, l, nullptr); out[i] = (float) l.luminance; continue; }
             eval(s, l, nullptr);
             out[i] = (float) l.luminance;
         }
@@ -122,15 +135,19 @@ template <typename F> struct Ctx : CtxBase {
         size_t lumSamples = (size_t) std::max(cfg.luminance_samples, cfg.work_units * (mmlt ? 50 : 10));
         if (mmlt) lumSamples *= (size_t) cfg.max_depth;
         b = mmlt ? generateSeeds<F>(meval, boot, lumSamples, (size_t) cfg.work_units, seeds, nullptr, cfg.max_depth)
-                 : generateSeeds<F>(eval, boot, lumSamples, (size_t) cfg.work_units, seeds);
+            : bdpt ? generateSeeds<F>(beval, boot, lumSamples, (size_t) cfg.work_units, seeds)
+                   : generateSeeds<F>(eval, boot, lumSamples, (size_t) cfg.work_units, seeds);
         if (b == 0) { error = "The average image luminance appears to be zero!"; return DRMLT_E_ZERO_LUM; }
         if (cfg.acceptance_map) b = 1.0;                               // drmlt.cpp:550-552
         else if (cfg.average_luminance != -1.0f) b = cfg.average_luminance; // :555-558
         c.luminance = (F) b;
-        chains.clear(); pchains.clear(); mchains.clear();
+        chains.clear(); pchains.clear(); mchains.clear(); bchains.clear();
         for (int i = 0; i < cfg.work_units; ++i) {
             bool ok;
-            if (mmlt) {
+            if (bdpt) {
+                bchains.emplace_back(new BChain(c, beval, seedv, chainOffset + i, chainOffset));
+                ok = bchains.back()->init(seeds[i]);
+            } else if (mmlt) {
                 mchains.emplace_back(new MChain(c, meval, seedv, chainOffset + i, chainOffset));
                 ok = mchains.back()->init(seeds[i]);
             } else if (cfg.algo == DRMLT_ALGO_PSSMLT) {
@@ -160,7 +177,8 @@ template <typename F> struct Ctx : CtxBase {
             for (;;) {
                 int i = next.fetch_add(1);
                 if (i >= cfg.work_units) break;
-                if (mmlt) mchains[i]->run(perChain, *films[t], tstats[t]);
+                if (bdpt) bchains[i]->run(perChain, *films[t], tstats[t]);
+                else if (mmlt) mchains[i]->run(perChain, *films[t], tstats[t]);
                 else if (cfg.algo == DRMLT_ALGO_PSSMLT) pchains[i]->run(perChain, *films[t], tstats[t]);
                 else chains[i]->run(perChain, *films[t], tstats[t]);
             }
@@ -214,6 +232,28 @@ template <typename F> struct Ctx : CtxBase {
                     for (uint32_t k = 0; k < S && k < ms.sensor.uCurrent.size(); ++k) row[k] = (float) ms.sensor.uCurrent[k];
                     for (uint32_t k = 0; k < E && k < ms.emitter.uCurrent.size(); ++k) row[S + k] = (float) ms.emitter.uCurrent[k];
                     if (!ms.direct.uCurrent.empty()) row[S + E] = (float) ms.direct.uCurrent[0];
+                }
+            }
+            return 0;
+        }
+        if (bdpt) { // [sensor S | emitter E]: the components the walks can consume (see drmlt_abi.h)
+            const uint32_t rr = (uint32_t) std::max(0, cfg.max_depth + 1 - std::max(cfg.rr_depth, 0));
+            uint32_t S = 2u * (uint32_t) (cfg.max_depth + 1) + rr, E = 2u * (uint32_t) cfg.max_depth + (rr > 0 ? rr - 1 : 0);
+            S += S & 1u; E += E & 1u;
+            if (u && dim < S + E) throw std::runtime_error("chain_state: need S + E dims for technique=bdpt");
+            for (int i = 0; i < cfg.work_units; ++i) {
+                const SplatList<F> &l = bchains[i]->current();
+                const MMLTSamplers<F> &ms = bchains[i]->sampler();
+                if (cur) {
+                    cur[i].luminance = (float) l.luminance; cur[i].x = (float) l.px; cur[i].y = (float) l.py;
+                    cur[i].rgb[0] = (float) l.value.x; cur[i].rgb[1] = (float) l.value.y; cur[i].rgb[2] = (float) l.value.z;
+                    cur[i].n_dims = l.hasMain ? 1 : 0; cur[i].n_rays = (int) l.more.size(); // as drmlt_chain_state
+                }
+                if (u) {
+                    float *row = u + (size_t) i * dim;
+                    for (uint32_t k = 0; k < dim; ++k) row[k] = 0.f;
+                    for (uint32_t k = 0; k < S && k < ms.sensor.uCurrent.size(); ++k) row[k] = (float) ms.sensor.uCurrent[k];
+                    for (uint32_t k = 0; k < E && k < ms.emitter.uCurrent.size(); ++k) row[S + k] = (float) ms.emitter.uCurrent[k];
                 }
             }
             return 0;
@@ -301,6 +341,55 @@ template <typename F> struct Ctx : CtxBase {
             double v = 0;
             for (int t = 0; t < nthreads; ++t) v += ss[t][s_];
             strat[s_] = v / (double) n;
+        }
+        return 0;
+    }
+
+    // independent-sample rendering with the bidirectional estimator (all its splats), radiance units
+    int bdptRender(uint64_t n, uint64_t seedv, int nthreads, float *out) override {
+        nthreads = std::max(1, nthreads);
+        std::vector<std::unique_ptr<Film<F>>> films;
+        for (int t = 0; t < nthreads; ++t) films.emplace_back(new Film<F>(scene.width, scene.height, scene.filterType, scene.filterParam));
+        auto work = [&](int t) {
+            Random rs(seedv, (uint32_t) (2 * t)), re(seedv, (uint32_t) (2 * t + 1));
+            ReplayableSampler<F> sensor(&rs), emitter(&re);
+            SplatList<F> l;
+            Bidir<F> bd(scene);
+            for (uint64_t i = (uint64_t) t; i < n; i += (uint64_t) nthreads) {
+                uint32_t major = (uint32_t) (i / (uint64_t) nthreads);
+                rs.seek(TAG_PT, major, 0); re.seek(TAG_PT, major, 0);
+                bd.sampleSplatsBDPT(emitter, sensor, cfg.max_depth, cfg.rr_depth, cfg.direct_samples >= 0, cfg.no_light_image == 0, l);
+                if (l.hasMain && spectrumValid(l.value)) films[t]->put(l.px, l.py, l.value);
+                for (const auto &sp : l.more) if (spectrumValid(sp.value)) films[t]->put(sp.px, sp.py, sp.value);
+            }
+        };
+        std::vector<std::thread> th;
+        for (int t = 1; t < nthreads; ++t) th.emplace_back(work, t);
+        work(0);
+        for (auto &x : th) x.join();
+        std::vector<double> acc((size_t) scene.width * scene.height * 3, 0.0);
+        for (auto &f : films) f->accumulateInto(acc);
+        double scale = (double) scene.width * scene.height / (double) n;
+        for (size_t i = 0; i < acc.size(); ++i) out[i] = (float) (acc[i] * scale);
+        return 0;
+    }
+    // out row: [lum, hasMain, px, py, r, g, b, nMore, nDims, nRays, then nMore x (px, py, r, g, b)] (stride floats)
+    int bdptEval(const float *uSensor, const float *uEmitter, uint32_t n, uint32_t dim, float *out, uint32_t stride) override {
+        Bidir<F> bd(scene);
+        for (uint32_t i = 0; i < n; ++i) {
+            ArraySampler<F> sensor(uSensor + (size_t) i * dim, dim), emitter(uEmitter + (size_t) i * dim, dim);
+            SplatList<F> l;
+            bd.sampleSplatsBDPT(emitter, sensor, cfg.max_depth, cfg.rr_depth, cfg.direct_samples >= 0, cfg.no_light_image == 0, l);
+            float *o = out + (size_t) i * stride;
+            for (uint32_t k = 0; k < stride; ++k) o[k] = 0.f;
+            o[0] = (float) l.luminance; o[1] = l.hasMain ? 1.f : 0.f; o[2] = (float) l.px; o[3] = (float) l.py;
+            o[4] = (float) l.value.x; o[5] = (float) l.value.y; o[6] = (float) l.value.z;
+            o[7] = (float) l.more.size(); o[8] = (float) (sensor.sampleIndex + emitter.sampleIndex); o[9] = (float) l.nRays;
+            for (size_t k = 0; k < l.more.size() && 10 + 5 * (k + 1) <= stride; ++k) {
+                float *q = o + 10 + 5 * k;
+                q[0] = (float) l.more[k].px; q[1] = (float) l.more[k].py;
+                q[2] = (float) l.more[k].value.x; q[3] = (float) l.more[k].value.y; q[4] = (float) l.more[k].value.z;
+            }
         }
         return 0;
     }
@@ -496,6 +585,8 @@ void oracle_roughconductor(int ggx, double alpha, const double *eta, const doubl
     }
 }
 
+int oracle_bdpt_render(void *p, uint64_t n, uint64_t seed, int nthreads, float *out) { GUARD(static_cast<CtxBase *>(p)->bdptRender(n, seed, nthreads, out)) }
+int oracle_bdpt_eval(void *p, const float *uSensor, const float *uEmitter, uint32_t n, uint32_t dim, float *out, uint32_t stride) { GUARD(static_cast<CtxBase *>(p)->bdptEval(uSensor, uEmitter, n, dim, out, stride)) }
 int oracle_set_importance_map(void *p, const float *map) { GUARD(static_cast<CtxBase *>(p)->setImportance(map)) }
 void oracle_luminance_map(const float *rgb, int w, int h, int W, int H, float *out) { luminanceMap(rgb, w, h, W, H, out); }
 int oracle_find_max_dim(int maxDepth, int rrDepth) { return findMaxDimensionsPath(maxDepth, rrDepth); }

@@ -110,6 +110,7 @@ template <typename F> struct Config {
     F pLarge, sigma, scaleSecond;
     F luminance = 1; // b (pssmlt Kelemen weights)
     int maxDim;
+    int technique = 0;                              // DRMLT_TECH_*
     bool fixEmitterPath = false, lightImage = true; // technique=mmlt
     const float *importance = nullptr;              // two-stage MLT luminance image (W x H), drmlt.cpp:406-418
     int impW = 0, impH = 0;
@@ -247,14 +248,23 @@ public:
 private:
     static F clamp1(F x) { return std::min(F(1), x); }
 
+    // drmlt_proc.cpp:432-450: every splat of the list
     void splat(Film<F> &film, const SplatList<F> &l, F weight) {
         if (!m_cfg.acceptanceMap && weight > 0) {
-            V3<F> v = l.value * weight;
-            if (spectrumValid(v)) film.put(l.px, l.py, v);
+            if (l.hasMain) { V3<F> v = l.value * weight; if (spectrumValid(v)) film.put(l.px, l.py, v); }
+            for (const auto &sp : l.more) { V3<F> v = sp.value * weight; if (spectrumValid(v)) film.put(sp.px, sp.py, v); }
         }
     }
+    void splatAlways(Film<F> &film, const SplatList<F> &l, F weight) {
+        if (!(weight > 0)) return;
+        if (l.hasMain) { V3<F> v = l.value * weight; if (spectrumValid(v)) film.put(l.px, l.py, v); }
+        for (const auto &sp : l.more) { V3<F> v = sp.value * weight; if (spectrumValid(v)) film.put(sp.px, sp.py, v); }
+    }
     void splatAcceptance(Film<F> &film, const SplatList<F> &l, int stage) {
-        if (m_cfg.acceptanceMap) film.put(l.px, l.py, stage == 0 ? V3<F>(1, 0, 0) : V3<F>(0, 1, 0));
+        if (!m_cfg.acceptanceMap) return;
+        const V3<F> c = stage == 0 ? V3<F>(1, 0, 0) : V3<F>(0, 1, 0);
+        if (l.hasMain) film.put(l.px, l.py, c);
+        for (const auto &sp : l.more) film.put(sp.px, sp.py, c);
     }
 
     void runDR(uint64_t nMutations, Film<F> &film, Stats &st) {
@@ -388,8 +398,8 @@ private:
                     accept = flipCoin(a, m_random, m, 2);
                 }
             }
-            if (1 - a > 0) { V3<F> v = m_current.value * (1 - a); if (spectrumValid(v)) film.put(m_current.px, m_current.py, v); }
-            if (a > 0) { V3<F> v = proposed.value * a; if (spectrumValid(v)) film.put(proposed.px, proposed.py, v); }
+            splatAlways(film, m_current, 1 - a); // the mixture loop splats whatever acceptanceMap says (:183-194)
+            splatAlways(film, proposed, a);
             st.overall_base++;
             if (!doSecond) { st.first_base++; if (largeStep) st.large_base++; else st.bold_base++; }
             else st.second_base++;

@@ -547,10 +547,15 @@ private:
     }
 };
 
-// One evaluated PSS point: SplatList with exactly one splat (pathsampler.cpp:565)
+// One evaluated PSS point: a SplatList (include/mitsuba/bidir/pathsampler.h:317-360). technique=path and mmlt
+// produce exactly one splat (px, py, value); technique=bdpt adds the light-image splats of the t = 1 strategies
+// in `more` (pathsampler.cpp:514-519), `hasMain` tells whether the main splat exists (:357-361).
 template <typename F> struct SplatList {
+    struct Splat { F px, py; V3<F> value; };
     F px = 0, py = 0;
     V3<F> value;
+    std::vector<Splat> more;
+    bool hasMain = true;
     F luminance = 0;
     int nDims = 0, nRays = 0;
     int s = 0, t = 0; // technique=mmlt: SplatList::setStrategy (pathsampler.cpp:129)
@@ -558,13 +563,20 @@ template <typename F> struct SplatList {
     void normalize(const float *importance = nullptr, int w = 0, int h = 0) {
         if (importance) {
             luminance = 0;
-            if (!value.isZero()) {
-                int ix = std::min(std::max(0, (int) px), w - 1), iy = std::min(std::max(0, (int) py), h - 1);
-                value /= (F) importance[ix + iy * w];
-                luminance = oracle::luminance(value);
-            }
+            auto weigh = [&](F x, F y, V3<F> &v) {
+                if (v.isZero()) return;
+                int ix = std::min(std::max(0, (int) x), w - 1), iy = std::min(std::max(0, (int) y), h - 1);
+                v /= (F) importance[ix + iy * w];
+                luminance += oracle::luminance(v);
+            };
+            if (hasMain) weigh(px, py, value);
+            for (Splat &sp : more) weigh(sp.px, sp.py, sp.value);
         }
-        if (luminance > 0) value *= F(1) / luminance;
+        if (luminance > 0) {
+            F inv = F(1) / luminance;
+            value *= inv;
+            for (Splat &sp : more) sp.value *= inv;
+        }
     }
 };
 

@@ -139,3 +139,60 @@ def test_seed_depths_and_replay(pkg, abi, ob):
     cur, u = o.chain_state(64)
     assert (cur["luminance"] > 0).all()                 # replay succeeded (seed() would have failed otherwise)
     assert ((u >= 0) & (u <= 1)).all()
+
+
+# ---------------------------------------------------------------- technique=bdpt (pathsampler.cpp:321-527)
+
+@pytest.mark.parametrize("name,maxd,rr", [("cornell_c2", 3, 100), ("cornell_c2", 5, 2), ("glass_sphere", 5, 100)])
+def test_bdpt_estimate_matches_unidirectional(pkg, abi, ob, name, maxd, rr):
+    """All (s, t) connections with Path::miWeight, random walks with russian roulette from rrDepth, light-image splats.
+    With the direct component excluded (depth <= 2, :407-408) both estimators cover the same paths."""
+    sd = pkg.scenes.SCENES[name](16)
+    ref = ob.Oracle(abi, abi.make_config(max_depth=maxd, rr_depth=100, work_units=4, direct_samples=16), sd, 64) \
+        .render_pt(6000, seed=7, nthreads=8)
+    cfg = abi.make_config(technique="bdpt", max_depth=maxd, rr_depth=rr, work_units=4, direct_samples=16, no_direct_sampling=1)
+    img = ob.Oracle(abi, cfg, sd, 64).bdpt_render(16 * 16 * 6000, seed=3, nthreads=8)
+    assert lum(img).mean() == pytest.approx(lum(ref).mean(), rel=0.02)
+    assert np.abs(blocks(img) - blocks(ref)).mean() / ref.mean() < 0.03
+
+
+def test_bdpt_splat_lists(pkg, abi, ob):
+    """One main splat when the camera ray hits something (:357-361) + one light-image splat per t = 1 connection
+    (:514-519); luminance = sum over all splats; without the light image no t < 2 strategy (:372)."""
+    sd = pkg.scenes.cornell_c2(16)
+    rng = np.random.default_rng(2)
+    us, ue = rng.random((3000, 30), dtype=np.float32), rng.random((3000, 30), dtype=np.float32)
+    cfg = abi.make_config(technique="bdpt", max_depth=5, rr_depth=3, work_units=4, direct_samples=-1, no_direct_sampling=1)
+    rows = ob.Oracle(abi, cfg, sd, 64).bdpt_eval(us, ue)
+    n_more = rows[:, 7].astype(int)
+    assert rows[:, 1].mean() > 0.9 and n_more.max() <= 5 and n_more.max() >= 3    # edge rays miss the open box
+    more = rows[:, 10:].reshape(len(rows), -1, 5)
+    total = rows[:, 4:7] @ np.array([0.212671, 0.715160, 0.072169]) + (more[:, :, 2:] @ np.array([0.212671, 0.715160, 0.072169])).sum(1)
+    np.testing.assert_allclose(total, rows[:, 0], rtol=1e-5, atol=1e-7)
+    assert ((more[:, :, 0] >= 0) & (more[:, :, 0] <= 16) & (more[:, :, 1] >= 0) & (more[:, :, 1] <= 16)).all()
+    cfg2 = abi.make_config(technique="bdpt", max_depth=5, rr_depth=3, work_units=4, direct_samples=-1, no_direct_sampling=1,
+                           no_light_image=1)
+    rows2 = ob.Oracle(abi, cfg2, sd, 64).bdpt_eval(us, ue)
+    assert rows2[:, 7].max() == 0
+    assert rows2[:, 8].max() <= 2 * 6 + 3 + 2 * 5 + 2            # dims: 2 per step + 1 per roulette test
+
+
+@pytest.mark.parametrize("kw", [dict(type="orbital"), dict(type="green"), dict(type="mira"), dict(type="orbital", use_mixture=1)],
+                         ids=lambda kw: "-".join("%s=%s" % kv for kv in kw.items()))
+def test_bdpt_chains_converge(pkg, abi, ob, kw):
+    sd = pkg.scenes.glass_sphere(16)
+    cfg = abi.make_config(technique="bdpt", max_depth=6, rr_depth=5, work_units=2048, direct_samples=-1, no_direct_sampling=1,
+                          luminance_samples=100000, **kw)
+    o = ob.Oracle(abi, cfg, sd, 64)
+    ref = o.bdpt_render(16 * 16 * 4000, seed=9, nthreads=8)
+    b = o.seed(1234)
+    o.run(16 * 16 * 3000, nthreads=8)
+    img = o.develop()
+    assert b == pytest.approx(lum(ref).mean(), rel=0.02)
+    assert np.abs(blocks(img) - blocks(ref)).mean() / ref.mean() < 0.03
+
+
+def test_bdpt_refusals(pkg, abi, ob):
+    sd = pkg.scenes.cornell_c2(16)
+    with pytest.raises(ob.OracleError, match="directSampling=false"):
+        ob.Oracle(abi, abi.make_config(technique="bdpt", max_depth=5, work_units=4), sd, 64)
