@@ -24,7 +24,7 @@ ABI_SYMBOLS = (
     "drmlt_create", "drmlt_seed", "drmlt_run", "drmlt_develop", "drmlt_stats_get", "drmlt_eval_paths",
     "drmlt_film_read", "drmlt_film_clear", "drmlt_film_device_ptr", "drmlt_set_luminance", "drmlt_set_stream",
     "drmlt_kernel_time", "drmlt_render_pt", "drmlt_chain_state", "drmlt_last_error", "drmlt_abi_version",
-    "drmlt_destroy", "drmlt_set_importance_map", "drmlt_luminance_map",
+    "drmlt_destroy", "drmlt_set_importance_map", "drmlt_luminance_map", "drmlt_eval_lists",
 )
 
 
@@ -63,6 +63,7 @@ def load_library():
     L.drmlt_develop.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     L.drmlt_stats_get.argtypes = [C.c_void_p, C.c_void_p]
     L.drmlt_eval_paths.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
+    L.drmlt_eval_lists.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32]
     L.drmlt_film_read.argtypes = [C.c_void_p, C.c_void_p]
     L.drmlt_film_clear.argtypes = [C.c_void_p]
     L.drmlt_film_device_ptr.restype = C.c_void_p
@@ -143,6 +144,23 @@ class Context:
         out = (abi.Splat * n)()
         self._chk(self.L.drmlt_eval_paths(self.h, u.ctypes.data, n, dim, out))
         return np.frombuffer(out, dtype=SPLAT_DTYPE).copy()
+
+    def eval_lists_bdpt(self, u_sensor, u_emitter):
+        """technique=bdpt: rows [lum, hasMain, px, py, r, g, b, nMore, nDims, nRays, nMore x (px, py, r, g, b)]."""
+        st = self.stats()
+        S = E = None
+        rr = self.cfg.max_depth + 1 - max(self.cfg.rr_depth, 0)
+        S = 2 * (self.cfg.max_depth + 1) + max(rr, 0); S += S & 1
+        E = 2 * self.cfg.max_depth + max(rr - 1, 0); E += E & 1
+        us, ue = np.asarray(u_sensor, dtype=np.float32), np.asarray(u_emitter, dtype=np.float32)
+        n = us.shape[0]
+        u = np.zeros((n, S + E), dtype=np.float32)
+        u[:, :min(S, us.shape[1])] = us[:, :S]
+        u[:, S:S + min(E, ue.shape[1])] = ue[:, :E]
+        stride = 10 + 5 * (self.cfg.max_depth + 1)
+        out = np.zeros((n, stride), dtype=np.float32)
+        self._chk(self.L.drmlt_eval_lists(self.h, u.ctypes.data, n, S + E, out.ctypes.data, stride))
+        return out
 
     def eval_paths_mmlt(self, depth, u_sensor, u_emitter, u_direct):
         """technique=mmlt: points are [sensor S | emitter E | direct | depth]; returns (splats, (s, t))."""

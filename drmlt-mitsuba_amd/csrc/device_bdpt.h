@@ -1,0 +1,388 @@
+// technique=bdpt on the device: PathSampler::sampleSplats, EBidirectional branch, with directSampling = false
+// (src/libbidir/pathsampler.cpp:321-527). Both random walks (with russian roulette from rrDepth) are stored, then
+// every (s, t) pair is connected and weighted with Path::miWeight; the result is a splat LIST: the sensor-side pixel
+// accumulates all t >= 2 strategies, every t = 1 strategy adds a light-image splat.
+//
+// Storage per chain:
+//   global workspace `bd_verts`  [BV_FIELDS][NVS][n]   geometry of every stored vertex (SoA, coalesced per field)
+//   LDS rows from `mis_row`      4 x NVS rows           fwd / rev densities (area measure), edge factor len^2/|cos cos|,
+//                                                       flags -- what the MIS sweep reads for every pair
+//   global lists `bd_lists`      [slot][BL_ROWS][n]     splat lists of the current state and the two proposals
+// NVS = ME + MS vertex slots: emitter vertices 1..ME (ME = maxDepth), sensor vertices 1..MS (MS = maxDepth + 1);
+// the supernodes are implicit.
+#pragma once
+#include "device_bidir.h"
+
+enum { BV_P = 0, BV_N = 3, BV_S = 6, BV_WI = 9, BV_LEN2 = 12, BV_COS = 13, BV_THR = 14, BV_IDS = 17, BV_EMIT = 18, BV_SHADE = 19, BV_FIELDS = 20 };
+enum { BL_LUM = 0, BL_META = 1, BL_MAIN = 2, BL_MORE = 7 }; // rows of a splat list; 5 rows (px, py, r, g, b) per splat
+enum { MF_FWD = 0, MF_REV = 1, MF_GINV = 2, MF_FLAGS = 3 }; // LDS row groups
+#define BF_CONN 1u
+#define BF_DEGEN 2u
+
+__host__ __device__ inline int bdpt_list_rows(int max_depth) { return BL_MORE + 5 * max_depth; }
+__host__ __device__ inline int bdpt_dims_sensor(int max_depth, int rr_depth) {
+    int rr = max_depth + 1 - (rr_depth > 0 ? rr_depth : 0);
+    int d = 2 * (max_depth + 1) + (rr > 0 ? rr : 0);
+    return d + (d & 1);
+}
+__host__ __device__ inline int bdpt_dims_emitter(int max_depth, int rr_depth) {
+    int rr = max_depth + 1 - (rr_depth > 0 ? rr_depth : 0);
+    int d = 2 * max_depth + (rr > 1 ? rr - 1 : 0);
+    return d + (d & 1);
+}
+__host__ __device__ inline int bdpt_max_dim(int max_depth, int rr_depth) { // pssmlt_utils.h:69-75
+    int d = (max_depth + 2) * (2 + (rr_depth < max_depth ? 1 : 0));
+    return d + (d & 1);
+}
+
+struct BdptResult {
+    float lum;
+    uint32_t nrays, n_sensor, n_emitter;
+    int n_more;
+    bool has_main;
+};
+
+struct BdptStore {
+    float *verts;     // P.bd_verts
+    uint32_t n, chain, NVS;
+    DEV float &f(int field, int slot) const { return verts[((size_t) field * NVS + (uint32_t) slot) * n + chain]; }
+    DEV void put(int slot, const BVert &v, f3 thr) const {
+        f(BV_P, slot) = v.p.x; f(BV_P + 1, slot) = v.p.y; f(BV_P + 2, slot) = v.p.z;
+        f(BV_N, slot) = v.n.x; f(BV_N + 1, slot) = v.n.y; f(BV_N + 2, slot) = v.n.z;
+        f(BV_S, slot) = v.s.x; f(BV_S + 1, slot) = v.s.y; f(BV_S + 2, slot) = v.s.z;
+        f(BV_WI, slot) = v.wi.x; f(BV_WI + 1, slot) = v.wi.y; f(BV_WI + 2, slot) = v.wi.z;
+        f(BV_LEN2, slot) = v.e_len2; f(BV_COS, slot) = v.e_cos;
+        f(BV_THR, slot) = thr.x; f(BV_THR + 1, slot) = thr.y; f(BV_THR + 2, slot) = thr.z;
+        f(BV_IDS, slot) = __int_as_float(v.kind | (v.bsdf << 4));
+        f(BV_EMIT, slot) = __int_as_float(v.emitter);
+        f(BV_SHADE, slot) = __int_as_float(v.shade);
+    }
+    DEV void get(int slot, BVert &v, f3 &thr) const {
+        v.p = mk3(f(BV_P, slot), f(BV_P + 1, slot), f(BV_P + 2, slot));
+        v.n = mk3(f(BV_N, slot), f(BV_N + 1, slot), f(BV_N + 2, slot));
+        v.s = mk3(f(BV_S, slot), f(BV_S + 1, slot), f(BV_S + 2, slot));
+        v.wi = mk3(f(BV_WI, slot), f(BV_WI + 1, slot), f(BV_WI + 2, slot));
+        v.e_len2 = f(BV_LEN2, slot); v.e_cos = f(BV_COS, slot);
+        thr = mk3(f(BV_THR, slot), f(BV_THR + 1, slot), f(BV_THR + 2, slot));
+        const int ids = __float_as_int(f(BV_IDS, slot));
+        v.kind = ids & 15; v.bsdf = ids >> 4;
+        v.emitter = __float_as_int(f(BV_EMIT, slot));
+        v.shade = __float_as_int(f(BV_SHADE, slot));
+    }
+};
+
+// `list`: this lane's column of the target splat list (row r at list[r * n])
+template <class TablesT>
+DEV void eval_bdpt(const DParams &P, const TablesT &T, MSampler &smp, uint32_t chain, uint32_t mis_row, float *list, BdptResult &R) {
+    const uint32_t lane = smp.lane, n = P.n_chains_alloc;
+    const int ME = P.max_depth, MS = P.max_depth + 1;
+    const uint32_t NVS = (uint32_t) (ME + MS);
+    const BdptStore W{P.bd_verts, n, chain, NVS};
+    auto mis = [&](int group, int slot) -> float & { return lds_x[(mis_row + (uint32_t) group * NVS + (uint32_t) slot) * 64u + lane]; };
+    auto lrow = [&](int r) -> float & { return list[(size_t) r * n]; };
+
+    R.lum = 0.f; R.nrays = 0u; R.n_sensor = R.n_emitter = 0u; R.n_more = 0; R.has_main = false;
+    smp.reset_caches();
+
+    // ------------------------------------------------------------ the two random walks (emitter first, :331-340)
+    int nE = 1, nS = 1;            // vertices of each subpath, supernode included
+    float em0_fwd = 0.f;           // density of the emitter sample (area x emitter choice)
+    float film_x = 0.f, film_y = 0.f;
+    {
+        BVert cur;
+        cur.kind = BK_SUPER_E; cur.p = cur.n = cur.s = cur.wi = mk3(0.f, 0.f, 0.f);
+        cur.e_len2 = cur.e_cos = 0.f; cur.bsdf = 0; cur.emitter = -1; cur.shade = 0; cur.degenerate = false;
+        f3 thr = mk3(1.f, 1.f, 1.f);   // cumulative weight[mode] * rrWeight: importanceWeights / radianceWeights
+        f3 thr_rr = thr;               // the walk's roulette throughput (tracks eta^2 as well, vertex.cpp:263-265)
+        uint32_t kdim = 0u;
+        smp.select(SEG_EMITTER);
+#pragma nounroll
+        for (int step = 0; step < ME + MS; ++step) {
+            const bool emitter = step < ME;
+            if (step == ME) {
+                cur.kind = BK_SUPER_S; cur.degenerate = true; cur.e_len2 = 0.f;
+                thr = thr_rr = mk3(1.f, 1.f, 1.f);
+                kdim = 0u;
+                smp.select(SEG_SENSOR);
+            }
+            const int i = emitter ? step : step - ME;          // this step samples from vertex i of its walk
+            const int base = emitter ? 0 : ME;                 // slot of vertex v (>= 1) is base + v - 1
+#define WALK_FAIL { if (emitter) { step = ME - 1; continue; } break; }
+            const float u0 = smp.next(kdim), u1 = smp.next(kdim + 1u);
+            kdim += 2u;
+            if (emitter) R.n_emitter = kdim; else R.n_sensor = kdim;
+
+            if (cur.kind == BK_SUPER_S) {
+                cur.kind = BK_END_S; cur.p = cam_pos(P); cur.n = cam_dir(P); cur.degenerate = false; cur.e_len2 = 0.f; cur.e_cos = 0.f;
+                cur.s = cur.wi = mk3(0.f, 0.f, 0.f);
+                W.put(base, cur, thr);
+                mis(MF_GINV, base) = 0.f; mis(MF_FLAGS, base) = 0.f;
+                nS = 2;
+                continue;
+            }
+            if (cur.kind == BK_SUPER_E) {
+                float sx = u0;
+                int ei = 0;
+                for (int q = 1; q < P.n_emitters; ++q)
+                    if (T.emitter_cdf_lo(q) < sx) ei = q;
+                const DEmitter E = T.emitter(ei);
+                const float emPdf = E.cdf_hi - E.cdf_lo;
+                sx = (sx - E.cdf_lo) / emPdf;
+                const DShade L = T.shade(E.prim);
+                f3 lp;
+                if ((L.bsdf >> 24) == PRIM_RECTANGLE) lp = fma3(ld3(L.eu), sx, fma3(ld3(L.ev), u1, ld3(L.origin)));
+                else { float a = sqrtf(fmaxf(0.f, 1.f - sx)); lp = fma3(ld3(L.eu), 1.f - a, fma3(ld3(L.ev), a * u1, ld3(L.origin))); }
+                em0_fwd = L.inv_area * emPdf;
+                thr = thr * (ld3(E.radiance) * (PI_F / (L.inv_area * emPdf)));
+                // the roulette throughput starts at the emitter sample: sampleNext returns before updating it (vertex.cpp:50-72)
+                cur.kind = BK_END_E; cur.p = lp; cur.n = ld3(L.n); cur.emitter = ei; cur.shade = E.prim; cur.degenerate = false;
+                cur.e_len2 = 0.f; cur.e_cos = 0.f; cur.s = cur.wi = mk3(0.f, 0.f, 0.f);
+                W.put(base, cur, thr);
+                mis(MF_GINV, base) = 0.f; mis(MF_FLAGS, base) = 0.f;
+                nE = 2;
+                continue;
+            }
+
+            // ---- sample a direction at `cur` (vertex i >= 1)
+            f3 d;
+            f3 w = mk3(1.f, 1.f, 1.f);
+            float pdf_fwd, pdf_rev = 1.f, eta2 = 1.f;
+            bool delta = false;
+            if (cur.kind == BK_END_E) {
+                f3 fs, ft;
+                frame_from_normal(cur.n, fs, ft);
+                f3 l = square_to_cosine_hemisphere(u0, u1);
+                d = fma3(fs, l.x, fma3(ft, l.y, cur.n * l.z));
+                pdf_fwd = INV_PI_F * l.z;
+            } else if (cur.kind == BK_END_S) {
+                f3 nearP = mk3((1.f - 2.f * u0) * P.tan_half_fov * P.near_clip, (1.f - 2.f * u1) * P.tan_half_fov * P.inv_aspect * P.near_clip,
+                               P.near_clip);
+                f3 dl = normalize3(nearP);
+                d = cam_to_world(P, dl);
+                pdf_fwd = cam_normalization(P) / (dl.z * dl.z * dl.z);
+                film_x = u0 * (float) P.width; film_y = u1 * (float) P.height;
+            } else {
+                const DBsdf B = T.bsdf(cur.bsdf);
+                f3 wo;
+                if (B.type == 0) {
+                    if (!(cur.wi.z > 0.f)) WALK_FAIL;
+                    wo = square_to_cosine_hemisphere(u0, u1);
+                    pdf_fwd = INV_PI_F * wo.z;
+                    w = ld3(B.rgb);
+                } else if (B.type == 1) {
+                    float cosThetaT;
+                    float F = fresnel_dielectric_ext(cur.wi.z, cosThetaT, B.p[0]);
+                    delta = true;
+                    if (u0 <= F) {
+                        wo = mk3(-cur.wi.x, -cur.wi.y, cur.wi.z);
+                        pdf_fwd = F;
+                    } else {
+                        float scale = -(cosThetaT < 0.f ? B.p[1] : B.p[0]);
+                        wo = mk3(scale * cur.wi.x, scale * cur.wi.y, cosThetaT);
+                        pdf_fwd = 1.f - F;
+                        float factor = emitter ? 1.f : (cosThetaT < 0.f ? B.p[1] : B.p[0]);
+                        w = mk3(factor * factor, factor * factor, factor * factor);
+                        const float e = cosThetaT < 0.f ? B.p[0] : B.p[1]; // bRec.eta
+                        if (!emitter) eta2 = e * e;
+                    }
+                } else {
+                    pdf_fwd = 0.f;
+                    w = make_rc(B).sample(cur.wi, u0, u1, wo, pdf_fwd);
+                }
+                if (is_zero3(w)) WALK_FAIL;
+                if (cur.wi.z == 0.f || wo.z == 0.f) WALK_FAIL;
+                pdf_rev = delta ? dielectric_pdf_delta(B, wo, cur.wi) : bsdf_pdf_sa(B, wo, cur.wi);
+                if (!(pdf_rev > 2.93873587705571876e-39f)) WALK_FAIL;
+                d = fma3(cur.s, wo.x, fma3(cross3(cur.n, cur.s), wo.y, cur.n * wo.z));
+            }
+            // russian roulette of the random walk (path.cpp:515-518, vertex.cpp:310-324)
+            thr_rr = thr_rr * (w * eta2);
+            float rrw = 1.f;
+            if (P.rr_depth != -1 && i >= P.rr_depth) {
+                const float q = fminf(max3(thr_rr), 0.95f);
+                const float ur = smp.next(kdim);
+                kdim += 1u;
+                if (emitter) R.n_emitter = kdim; else R.n_sensor = kdim;
+                if (ur > q) WALK_FAIL;
+                rrw = 1.f / q;
+                thr_rr = thr_rr * rrw;
+            }
+
+            const Hit h = trace(P, cur.p, d, ray_eps_closest(cur.p), INFINITY, false);
+            R.nrays++;
+            if (h.prim < 0) WALK_FAIL;
+            const DShade Sh = T.shade(h.prim);
+            BVert nv;
+            if ((Sh.bsdf >> 24) != PRIM_SPHERE) {
+                nv.p = fma3(ld3(Sh.eu), h.u, fma3(ld3(Sh.ev), h.v, ld3(Sh.origin)));
+                nv.n = ld3(Sh.n);
+                nv.s = ld3(Sh.eu) * Sh.inv_len_eu;
+            } else {
+                f3 c = ld3(Sh.origin);
+                f3 local = normalize3(fma3(d, h.t, cur.p) - c);
+                nv.p = fma3(local, Sh.eu[0], c);
+                nv.n = local;
+                float zrad2 = local.x * local.x + local.y * local.y;
+                float inv = rsqrtf(zrad2);
+                nv.s = zrad2 > 0.f ? mk3(-local.y * inv, local.x * inv, 0.f) : mk3(1.f, 0.f, 0.f);
+            }
+            if (h.t == 0.f) WALK_FAIL;
+            const float len2 = h.t * h.t;
+            const float cosNew = fabsf(dot3(d, nv.n)), cosCur = fabsf(dot3(d, cur.n));
+            float fwd = pdf_fwd, rev = pdf_rev;
+            if (!delta) {
+                fwd = pdf_fwd * cosNew / len2;
+                if (cur.e_len2 != 0.f) rev = pdf_rev * cur.e_cos / cur.e_len2;
+            }
+            // vertex i is now complete: densities and connectability
+            const int cslot = base + i - 1;
+            mis(MF_FWD, cslot) = fwd;
+            mis(MF_REV, cslot) = rev;
+            mis(MF_FLAGS, cslot) = __uint_as_float(((!cur.degenerate && !delta) ? BF_CONN : 0u) | (cur.degenerate ? BF_DEGEN : 0u));
+            thr = thr * (w * rrw);
+
+            nv.kind = BK_SURF;
+            nv.bsdf = Sh.bsdf & 0xffffff;
+            nv.emitter = Sh.emitter;
+            nv.shade = h.prim;
+            {
+                const int bt = T.bsdf(nv.bsdf).type;
+                nv.degenerate = !(bt == 0 || bt == 2 || Sh.emitter >= 0);
+            }
+            nv.wi = to_local(nv, -d);
+            nv.e_len2 = len2;
+            nv.e_cos = cosCur;
+            W.put(base + i, nv, thr);                            // vertex i + 1
+            mis(MF_GINV, base + i) = len2 / (cosNew * cosCur);   // edge (i, i + 1), kept with vertex i + 1
+            mis(MF_FLAGS, base + i) = __uint_as_float(nv.degenerate ? BF_DEGEN : 0u);
+            if (emitter) nE = i + 2; else nS = i + 2;
+            cur = nv;
+        }
+#undef WALK_FAIL
+    }
+
+    // ------------------------------------------------------------ the splat list
+    float total_lum = 0.f;
+    f3 main_v = mk3(0.f, 0.f, 0.f);
+    R.has_main = nS > 2; // "if (m_sensorSubpath.vertexCount() > 2)", :357-361
+    int n_more = 0;
+
+    auto flags = [&](int slot) { return __float_as_uint(mis(MF_FLAGS, slot)); };
+#pragma nounroll
+    for (int s = nE - 1; s >= 0; --s) {
+        BVert vs;
+        f3 thr_s = mk3(1.f, 1.f, 1.f);
+        if (s >= 1) W.get(s - 1, vs, thr_s);
+        vs.degenerate = s >= 1 ? (flags(s - 1) & BF_DEGEN) != 0u : false;
+        int minT = max(2 - s, P.light_image ? 0 : 2), maxT = min(nS - 1, P.max_depth + 1 - s);
+        if (minT < 1) minT = 1; // t = 0 needs a sensor that can be hit: a pinhole cannot (vertex.cpp:1405-1413)
+#pragma nounroll
+        for (int t = maxT; t >= minT; --t) {
+            BVert vt;
+            f3 thr_t;
+            W.get(ME + t - 1, vt, thr_t);
+            vt.degenerate = (flags(ME + t - 1) & BF_DEGEN) != 0u;
+            const int k = s + t + 1, depth = s + t - 1;
+            f3 value;
+            float geo = 1.f;
+            float pc_i1, pc_i2, pc_r0 = 0.f, pc_r1 = 0.f;
+            if (s == 0) {
+                if (vt.kind != BK_SURF || vt.emitter < 0) continue;
+                const DEmitter E = T.emitter(vt.emitter);
+                const f3 wo = to_world(vt, vt.wi);
+                const float dp = dot3(wo, vt.n);
+                float r = dp < 0.f ? 0.f : INV_PI_F * dp;
+                if (dp != 0.f) r /= fabsf(dp);
+                value = thr_t * (ld3(E.radiance) * (PI_F * r));
+                if (is_zero3(value)) continue;
+                pc_i1 = T.shade(vt.shade).inv_area * (E.cdf_hi - E.cdf_lo);
+                pc_i2 = (dp < 0.f ? 0.f : INV_PI_F * dp) * vt.e_cos / vt.e_len2;
+            } else {
+                if (vs.degenerate || vt.degenerate) continue;
+                f3 dc = vt.p - vs.p;
+                const float len2 = dot3(dc, dc);
+                const float len = sqrtf(len2);
+                if (len == 0.f) continue;
+                dc = dc * (1.f / len);
+                const DBsdf Bs = T.bsdf(vs.bsdf), Bt = T.bsdf(vt.bsdf);
+                value = thr_s * thr_t * vert_eval(P, Bs, vs, dc, true) * vert_eval(P, Bt, vt, -dc, false);
+                if (is_zero3(value)) continue;
+                const Hit h = trace(P, vt.p, -dc, ray_eps_closest(vt.p), len * (1.f - SHADOW_EPSILON_F), true);
+                R.nrays++;
+                if (h.prim >= 0) continue;
+                const float cs = fabsf(dot3(vs.n, dc)), ct = fabsf(dot3(vt.n, dc));
+                geo = cs * ct / len2;
+                const f3 wos = to_local(vs, dc), wot = to_local(vt, -dc);
+                pc_i1 = vert_pdf_sa(P, Bs, vs, vs.wi, wos, dc) * ct / len2;
+                pc_r0 = vert_pdf_sa(P, Bt, vt, vt.wi, wot, -dc) * cs / len2;
+                if (vt.kind == BK_END_S) pc_i2 = 1.f;
+                else pc_i2 = bsdf_pdf_sa(Bt, wot, vt.wi) * ((wot.z == 0.f || vt.wi.z == 0.f) ? 0.f : 1.f) * vt.e_cos / vt.e_len2;
+                if (vs.kind == BK_END_E) pc_r1 = 1.f;
+                else pc_r1 = bsdf_pdf_sa(Bs, wos, vs.wi) * ((wos.z == 0.f || vs.wi.z == 0.f) ? 0.f : 1.f) * vs.e_cos / vs.e_len2;
+            }
+            if (P.exclude_direct && depth <= 2) continue;
+
+            // ---- Path::miWeight over positions 0..k (emitter vertex j at j, sensor vertex j at k - j)
+            auto conn = [&](int j) -> bool {
+                if (j == 0 || j == s || j == s + 1) return true;
+                if (j >= k) return false;
+                return (flags(j < s ? j - 1 : ME + (k - j) - 1) & BF_CONN) != 0u;
+            };
+            auto ginv = [&](int e) -> float { return e < s ? mis(MF_GINV, e) : mis(MF_GINV, ME + (k - e) - 1); }; // edge (e, e + 1)
+            auto pImp = [&](int j) -> float {
+                float v;
+                if (j == 0) v = 1.f;
+                else if (j <= s) v = j == 1 ? em0_fwd : mis(MF_FWD, j - 2);
+                else if (j == s + 1) v = pc_i1;
+                else if (j == s + 2) v = pc_i2;
+                else v = mis(MF_REV, ME + (k - j + 1) - 1);
+                const int i = j - 1; // area -> projected solid angle next to a specular vertex (path.cpp:868-882)
+                if (i >= 1 && i <= k - 3 && i != s && conn(i) && !conn(i + 1)) v *= ginv(i);
+                return v;
+            };
+            auto pRad = [&](int j) -> float {
+                float v;
+                if (j == k) v = 1.f;
+                else if (j >= s + 1) { const int a = k - j - 1; v = a == 0 ? 1.f : mis(MF_FWD, ME + a - 1); }
+                else if (j == s) v = pc_r0;
+                else if (j == s - 1) v = pc_r1;
+                else v = mis(MF_REV, j);                       // emitter vertex j + 1, slot j
+                const int i = j + 1; // (path.cpp:884-898)
+                if (i <= k - 1 && i >= 3 && j != s && conn(i) && !conn(j)) v *= ginv(j);
+                return v;
+            };
+            double weight = 1.0, pdf = 1.0;
+            for (int i = s + 1; i < k; ++i) {
+                double next = pdf * (double) pImp(i) / (double) pRad(i);
+                if (conn(i) && conn(i + 1) && (P.light_image || k - i - 1 > 1)) weight += next * next;
+                pdf = next;
+            }
+            pdf = 1.0;
+            for (int i = s - 1; i >= 0; --i) {
+                double next = pdf * (double) pRad(i + 1) / (double) pImp(i + 1);
+                if (conn(i) && conn(i + 1) && (P.light_image || k - i - 1 > 1)) weight += next * next;
+                pdf = next;
+            }
+            value = value * (geo * (float) (1.0 / weight));
+
+            if (t == 1) { // light image: its own splat (:514-516)
+                float sx, sy;
+                if (!cam_sample_position(P, vs.p - vt.p, sx, sy)) continue;
+                if (n_more < P.max_depth) {
+                    const int r0 = BL_MORE + 5 * n_more;
+                    lrow(r0) = sx; lrow(r0 + 1) = sy; lrow(r0 + 2) = value.x; lrow(r0 + 3) = value.y; lrow(r0 + 4) = value.z;
+                    ++n_more;
+                }
+            } else {
+                main_v = main_v + value;
+            }
+            total_lum += luminance3(value);
+        }
+    }
+    lrow(BL_LUM) = total_lum;
+    lrow(BL_META) = __int_as_float((R.has_main ? 1 : 0) | (n_more << 1));
+    lrow(BL_MAIN) = R.has_main ? film_x : 0.f; lrow(BL_MAIN + 1) = R.has_main ? film_y : 0.f;
+    lrow(BL_MAIN + 2) = main_v.x; lrow(BL_MAIN + 3) = main_v.y; lrow(BL_MAIN + 4) = main_v.z;
+    R.lum = total_lum;
+    R.n_more = n_more;
+}

@@ -100,6 +100,10 @@ struct DParams {
     int32_t *chain_depth;     // [n] path depth of each chain (fixed by its seed)
     int32_t *cur_t;           // [n] sensor-subpath length t of the current state (light tracing: t == 1)
     const float *importance;  // [H][W] two-stage MLT luminance image, or NULL (pathsampler.cpp:1001-1020)
+    // technique=bdpt (device_bdpt.h)
+    float *bd_verts;          // [BV_FIELDS][2 maxDepth + 1][n_chains_alloc] stored subpath vertices
+    float *bd_lists;          // [3][BL rows][n_chains_alloc] splat lists: 0 current, 1 first-stage, 2 second-stage proposal
+    uint32_t n_chains_alloc;  // column stride of the two buffers above
 };
 
 // result of one PSS evaluation, SoA-friendly

@@ -27,6 +27,11 @@ void launch_bootstrap_mmlt(const DParams &P, uint32_t n, float *lum_out, hipStre
 void launch_init_chains_mmlt(const DParams &P, const uint32_t *seed_index, const float *seed_lum, hipStream_t st);
 void launch_mutate_mmlt(const DParams &P, uint32_t n_mut, uint32_t mut_base, hipStream_t st);
 void launch_eval_paths_mmlt(const DParams &P, const float *u, uint32_t n, uint32_t dim, float *out8, hipStream_t st);
+// technique=bdpt (kernels_bdpt.hip)
+void launch_bootstrap_bdpt(const DParams &P, uint32_t n, float *lum_out, hipStream_t st);
+void launch_init_chains_bdpt(const DParams &P, const uint32_t *seed_index, const float *seed_lum, hipStream_t st);
+void launch_mutate_bdpt(const DParams &P, uint32_t n_mut, uint32_t mut_base, hipStream_t st);
+void launch_eval_lists_bdpt(const DParams &P, const float *u, uint32_t n, uint32_t dim, float *out, uint32_t stride, hipStream_t st);
 void launch_render_pt(const DParams &P, uint64_t n_samples, uint32_t stream, float scale, hipStream_t st);
 void launch_lum_sum(const float *film, const float *importance, uint32_t n_pixels, double *sum, hipStream_t st);
 void launch_develop(const float *film, const float *direct, const float *importance, float factor, uint32_t n, float *out, hipStream_t st);
@@ -68,7 +73,7 @@ struct drmlt_ctx {
     DParams P{};
     std::string error;
 
-    DevBuf d_prims, d_shade, d_bsdfs, d_emitters, d_bvh, d_lut, d_film, d_x, d_cur, d_stats, d_err, d_scratch, d_chain_i, d_importance;
+    DevBuf d_prims, d_shade, d_bsdfs, d_emitters, d_bvh, d_lut, d_film, d_x, d_cur, d_stats, d_err, d_scratch, d_chain_i, d_importance, d_bd_verts, d_bd_lists;
     std::vector<DPrim> prims;
     std::vector<DShade> shade;
 
@@ -343,8 +348,13 @@ drmlt_ctx *drmlt_create(const drmlt_config *cfg, const drmlt_scene *scene, int d
     if (cfg->technique == DRMLT_TECH_MMLT && cfg->max_depth == -1) return bail(nullptr, "Impossible to use MMLT with no max depth");
     if (cfg->fix_emitter_path && cfg->technique != DRMLT_TECH_MMLT) return bail(nullptr, "Impossible to use fixEmitterPath without MMLT");
     if (cfg->scale_second > 1.0f) return bail(nullptr, "scaleSecond is bigger than the first stage");
-    if (cfg->technique == DRMLT_TECH_BDPT) return bail(nullptr, "technique=bdpt has no device implementation yet (SURVEY 8f)");
-    const bool mmlt = cfg->technique == DRMLT_TECH_MMLT;
+    const bool mmlt = cfg->technique == DRMLT_TECH_MMLT, bdpt = cfg->technique == DRMLT_TECH_BDPT;
+    // With directSampling=true (the reference's default) its bdpt chains overrun the direct sampler: it is given maxDepth
+    // components (pssmlt_utils.h:75) while every s = 1 / t = 1 connection draws two (pathsampler.cpp:424-452), and
+    // primarySample raises "Exceeded maximum dimension" (drmlt_sampler.cpp:256-258). Only the variant that runs is built.
+    if (bdpt && !cfg->no_direct_sampling) return bail(nullptr, "technique=bdpt needs directSampling=false (no_direct_sampling=1)");
+    if (bdpt && cfg->timid_after_large) return bail(nullptr, "timidAfterLarge is not supported for technique=bdpt");
+    if (bdpt && cfg->max_depth > 16) return bail(nullptr, "technique=bdpt: maxDepth above 16 is not supported on the device");
     if (cfg->max_depth <= 0) return bail(nullptr, "technique=path needs a finite maxDepth (pssmlt_utils.h:63)");
     if (mmlt && cfg->max_depth > 24) return bail(nullptr, "technique=mmlt: maxDepth above 24 is not supported on the device");
     // a rejected large step re-draws the strategy; its second stage would read an emitter state that may be
@@ -408,7 +418,7 @@ drmlt_ctx *drmlt_create(const drmlt_config *cfg, const drmlt_scene *scene, int d
     // ---- derived quantities of DRMLT::render (drmlt.cpp:434-476)
     const uint64_t budget = (uint64_t) cam.width * cam.height * (uint64_t) cfg->sample_count;
     int work_units = cfg->work_units;
-    const uint64_t per_unit = mmlt ? 100000 : 200000; // desiredMutationsPerWorkUnit, drmlt.cpp:434-444
+    const uint64_t per_unit = (mmlt || bdpt) ? 100000 : 200000; // desiredMutationsPerWorkUnit, drmlt.cpp:434-444
     if (work_units <= 0) work_units = (int) std::max<uint64_t>(1, (budget + per_unit - 1) / per_unit);
     ctx->cfg.work_units = work_units;
     ctx->n_chains = (uint32_t) work_units;
@@ -442,6 +452,14 @@ drmlt_ctx *drmlt_create(const drmlt_config *cfg, const drmlt_scene *scene, int d
         P.max_dim = 2 * P.mmlt_dmax + 1;
         P.eff_dim = P.mmlt_S + P.mmlt_E + 1;
     }
+    if (bdpt) { // [sensor S | emitter E]: what the two walks can consume (device_bdpt.h); draw bases as for mmlt
+        const int rr = cfg->max_depth + 1 - (cfg->rr_depth > 0 ? cfg->rr_depth : 0);
+        P.mmlt_S = 2 * (cfg->max_depth + 1) + (rr > 0 ? rr : 0); P.mmlt_S += P.mmlt_S & 1;
+        P.mmlt_E = 2 * cfg->max_depth + (rr > 1 ? rr - 1 : 0); P.mmlt_E += P.mmlt_E & 1;
+        P.mmlt_dmax = (cfg->max_depth + 2) * (2 + (cfg->rr_depth < cfg->max_depth ? 1 : 0)); P.mmlt_dmax += P.mmlt_dmax & 1; // pssmlt_utils.h:69-75
+        P.max_dim = 2 * P.mmlt_dmax;
+        P.eff_dim = P.mmlt_S + P.mmlt_E;
+    }
 
     const size_t film_bytes = (size_t) cam.width * cam.height * 3 * sizeof(float);
     ok = ctx->d_film.alloc(film_bytes) == hipSuccess && ctx->d_x.alloc((size_t) P.eff_dim * ctx->n_chains * sizeof(float)) == hipSuccess &&
@@ -451,6 +469,15 @@ drmlt_ctx *drmlt_create(const drmlt_config *cfg, const drmlt_scene *scene, int d
     (void) hipMemset(ctx->d_chain_i.p, 0, (size_t) 2 * ctx->n_chains * sizeof(int32_t));
     P.chain_depth = ctx->d_chain_i.as<int32_t>(); P.cur_t = P.chain_depth + ctx->n_chains;
     P.importance = nullptr;
+    P.bd_verts = nullptr; P.bd_lists = nullptr; P.n_chains_alloc = ctx->n_chains;
+    if (bdpt) {
+        const size_t nvs = (size_t) 2 * cfg->max_depth + 1, rows = (size_t) 7 + 5 * cfg->max_depth;
+        if (ctx->d_bd_verts.alloc((size_t) 20 * nvs * ctx->n_chains * sizeof(float)) != hipSuccess ||
+            ctx->d_bd_lists.alloc((size_t) 3 * rows * ctx->n_chains * sizeof(float)) != hipSuccess)
+            return bail(ctx, "device allocation of the bdpt workspace failed");
+        (void) hipMemset(ctx->d_bd_lists.p, 0, (size_t) 3 * rows * ctx->n_chains * sizeof(float));
+        P.bd_verts = ctx->d_bd_verts.as<float>(); P.bd_lists = ctx->d_bd_lists.as<float>();
+    }
     (void) hipMemset(ctx->d_film.p, 0, film_bytes);
     (void) hipMemset(ctx->d_stats.p, 0, 32 * sizeof(unsigned long long));
     (void) hipMemset(ctx->d_err.p, 0, 64);
@@ -513,7 +540,9 @@ int drmlt_seed(drmlt_ctx *ctx, uint64_t seed, uint32_t chain_offset, double *b_o
     uint32_t n = (uint32_t) n64;
     DevBuf d_lum;
     HIP_TRY(ctx, d_lum.alloc((size_t) n * sizeof(float)));
+    const bool bdpt = ctx->cfg.technique == DRMLT_TECH_BDPT;
     if (mmlt) launch_bootstrap_mmlt(P, n, d_lum.as<float>(), ctx->stream);
+    else if (bdpt) launch_bootstrap_bdpt(P, n, d_lum.as<float>(), ctx->stream);
     else launch_bootstrap(P, n, d_lum.as<float>(), ctx->stream);
     HIP_TRY(ctx, hipGetLastError());
     std::vector<float> lum(n);
@@ -561,6 +590,7 @@ int drmlt_seed(drmlt_ctx *ctx, uint64_t seed, uint32_t chain_offset, double *b_o
     HIP_TRY(ctx, hipMemcpyAsync(d_sl.p, seed_lum.data(), seed_lum.size() * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(ctx, hipMemsetAsync(ctx->d_err.p, 0, 64, ctx->stream));
     if (mmlt) launch_init_chains_mmlt(P, d_si.as<uint32_t>(), d_sl.as<float>(), ctx->stream);
+    else if (bdpt) launch_init_chains_bdpt(P, d_si.as<uint32_t>(), d_sl.as<float>(), ctx->stream);
     else launch_init_chains(P, d_si.as<uint32_t>(), d_sl.as<float>(), ctx->stream);
     HIP_TRY(ctx, hipGetLastError());
     int32_t flag = 0;
@@ -668,6 +698,7 @@ int drmlt_run(drmlt_ctx *ctx, uint64_t total_mutations, volatile int *stop, drml
         HIP_TRY(ctx, hipEventCreate(&b));
         HIP_TRY(ctx, hipEventRecord(a, ctx->stream));
         if (ctx->cfg.technique == DRMLT_TECH_MMLT) launch_mutate_mmlt(ctx->P, n, ctx->mutation_base, ctx->stream);
+        else if (ctx->cfg.technique == DRMLT_TECH_BDPT) launch_mutate_bdpt(ctx->P, n, ctx->mutation_base, ctx->stream);
         else launch_mutate(ctx->P, n, ctx->mutation_base, ctx->stream);
         HIP_TRY(ctx, hipGetLastError());
         HIP_TRY(ctx, hipEventRecord(b, ctx->stream));
@@ -771,6 +802,7 @@ int drmlt_stats_get(drmlt_ctx *ctx, drmlt_stats *o) {
 int drmlt_eval_paths(drmlt_ctx *ctx, const float *u, uint32_t n, uint32_t dim, drmlt_splat *out) {
     if (!ctx || !u || !out) return DRMLT_E_INVALID;
     const bool mmlt = ctx->cfg.technique == DRMLT_TECH_MMLT;
+    if (ctx->cfg.technique == DRMLT_TECH_BDPT) return ctx->fail(DRMLT_E_INVALID, "technique=bdpt evaluates to splat lists: use drmlt_eval_lists");
     const int need = ctx->P.eff_dim + (mmlt ? 1 : 0); // mmlt: [sensor S | emitter E | direct | depth]
     if ((int) dim < need) return ctx->fail(DRMLT_E_INVALID, "eval_paths: need at least %d PSS dimensions per point", need);
     if (n == 0) return DRMLT_OK;
@@ -831,11 +863,44 @@ int drmlt_render_pt(drmlt_ctx *ctx, uint32_t spp, uint64_t seed, float *out_rgb)
     return DRMLT_OK;
 }
 
+int drmlt_eval_lists(drmlt_ctx *ctx, const float *u, uint32_t n, uint32_t dim, float *out, uint32_t stride) {
+    if (!ctx || !u || !out) return DRMLT_E_INVALID;
+    if (ctx->cfg.technique != DRMLT_TECH_BDPT) return ctx->fail(DRMLT_E_INVALID, "drmlt_eval_lists is for technique=bdpt");
+    if ((int) dim < ctx->P.eff_dim) return ctx->fail(DRMLT_E_INVALID, "eval_lists: need at least %d PSS dimensions per point", ctx->P.eff_dim);
+    if (stride < 10) return ctx->fail(DRMLT_E_INVALID, "eval_lists: stride must be at least 10 floats");
+    if (n == 0) return DRMLT_OK;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    DevBuf d_u, d_o;
+    HIP_TRY(ctx, d_u.alloc((size_t) n * dim * sizeof(float)));
+    HIP_TRY(ctx, d_o.alloc((size_t) n * stride * sizeof(float)));
+    HIP_TRY(ctx, hipMemcpyAsync(d_u.p, u, (size_t) n * dim * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    launch_eval_lists_bdpt(ctx->P, d_u.as<float>(), n, dim, d_o.as<float>(), stride, ctx->stream);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipMemcpyAsync(out, d_o.p, (size_t) n * stride * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return DRMLT_OK;
+}
+
 int drmlt_chain_state(drmlt_ctx *ctx, drmlt_splat *cur, float *u, uint32_t dim) {
     if (!ctx) return DRMLT_E_INVALID;
     if (!ctx->seeded) return ctx->fail(DRMLT_E_STATE, "chain_state before seed");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const uint32_t n = ctx->n_chains;
+    if (cur && ctx->cfg.technique == DRMLT_TECH_BDPT) {
+        // current splat list (slot 0, unnormalised): luminance, main splat; n_dims = has main splat, n_rays = light-image splats
+        std::vector<float> h((size_t) 7 * n), l(n);
+        HIP_TRY(ctx, hipMemcpyAsync(h.data(), ctx->d_bd_lists.p, h.size() * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(l.data(), ctx->d_cur.p, l.size() * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        for (uint32_t i = 0; i < n; ++i) {
+            int32_t meta; memcpy(&meta, &h[(size_t) n + i], 4);
+            const float inv = l[i] > 0.f ? 1.f / l[i] : 0.f;
+            cur[i].luminance = l[i]; cur[i].x = h[2 * (size_t) n + i]; cur[i].y = h[3 * (size_t) n + i];
+            cur[i].rgb[0] = h[4 * (size_t) n + i] * inv; cur[i].rgb[1] = h[5 * (size_t) n + i] * inv; cur[i].rgb[2] = h[6 * (size_t) n + i] * inv;
+            cur[i].n_dims = meta & 1; cur[i].n_rays = meta >> 1;
+        }
+        cur = nullptr;
+    }
     if (cur) {
         std::vector<float> h((size_t) 6 * n);
         HIP_TRY(ctx, hipMemcpyAsync(h.data(), ctx->d_cur.p, h.size() * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));

@@ -1,0 +1,322 @@
+// HIP kernels of the DRMLT hot path for technique=bdpt (gfx950). One Markov chain per lane, one wave per workgroup.
+//
+//   k_bootstrap_bdpt    luminance samples of generateSeeds (pathsampler.cpp:879-920)
+//   k_init_chains_bdpt  seed replay + fillReplay of the sensor / emitter samplers (drmlt_proc.cpp:467-514)
+//   k_mutate_bdpt       DRMLTRenderer::process / processMixture over sampleSplats(EBidirectional) (drmlt_proc.cpp:161-380,518-770)
+//   k_eval_lists_bdpt   sampleSplats(EBidirectional) on caller-supplied PSS points, full splat lists
+//
+// LDS rows ([row][lane]): chain state [0, NX), NX = S + E (bdpt_dims_sensor / bdpt_dims_emitter), then the four row
+// groups of eval_bdpt. Splat lists live in HBM (`bd_lists`, slot 0 = current state), unnormalised next to their luminance.
+#include "device_bdpt.h"
+#include "kernel_common.h"
+
+DEV uint32_t bdpt_nx(const DParams &P) { return (uint32_t) (P.mmlt_S + P.mmlt_E); }
+
+DEV void bsampler_setup(MSampler &smp, const DParams &P, uint32_t lane) {
+    smp.key0 = P.key0; smp.key1 = P.key1;
+    smp.type = P.type; smp.sigma2 = P.sigma2; smp.large = false;
+    smp.lane = lane; smp.arr = nullptr;
+    smp.S = (uint32_t) P.mmlt_S; smp.E = (uint32_t) P.mmlt_E;
+    smp.base_e = 2u * (uint32_t) P.mmlt_dmax; smp.base_d = 4u * (uint32_t) P.mmlt_dmax;
+    smp.emitter_ident2 = false;
+    smp.reset_caches();
+    smp.select(SEG_SENSOR);
+}
+
+DEV float *list_col(const DParams &P, int slot, uint32_t chain) {
+    return P.bd_lists + (size_t) slot * (size_t) bdpt_list_rows(P.max_depth) * P.n_chains_alloc + chain;
+}
+
+// SplatList::normalize with a two-stage importance map (pathsampler.cpp:1001-1020): weigh every splat, recompute the
+// list luminance. Lists stay unnormalised otherwise; the 1 / luminance factor is applied when splatting.
+DEV float list_finalize(const DParams &P, float *list, float lum) {
+    if (!P.importance) return lum;
+    const size_t n = P.n_chains_alloc;
+    const int meta = __float_as_int(list[(size_t) BL_META * n]);
+    const int cnt = meta >> 1;
+    float total = 0.f;
+    for (int k = -1; k < cnt; ++k) {
+        if (k < 0 && !(meta & 1)) continue;
+        const int r0 = k < 0 ? BL_MAIN : BL_MORE + 5 * k;
+        float r = list[(size_t) (r0 + 2) * n], g = list[(size_t) (r0 + 3) * n], b = list[(size_t) (r0 + 4) * n];
+        if (r == 0.f && g == 0.f && b == 0.f) continue;
+        const int ix = min(max(0, (int) list[(size_t) r0 * n]), P.width - 1), iy = min(max(0, (int) list[(size_t) (r0 + 1) * n]), P.height - 1);
+        const float lv = P.importance[ix + iy * P.width];
+        r /= lv; g /= lv; b /= lv;
+        list[(size_t) (r0 + 2) * n] = r; list[(size_t) (r0 + 3) * n] = g; list[(size_t) (r0 + 4) * n] = b;
+        total += luminance3(mk3(r, g, b));
+    }
+    list[(size_t) BL_LUM * n] = total;
+    return total;
+}
+
+// splat every entry of a list with weight w / luminance (the list is stored unnormalised)
+DEV void list_splat(const DParams &P, const float *list, float lum, float w) {
+    if (!(w > 0.f) || !(lum > 0.f)) return;
+    const size_t n = P.n_chains_alloc;
+    const float sc = w / lum;
+    const int meta = __float_as_int(list[(size_t) BL_META * n]);
+    if (meta & 1)
+        film_put(P, list[(size_t) BL_MAIN * n], list[(size_t) (BL_MAIN + 1) * n],
+                 mk3(list[(size_t) (BL_MAIN + 2) * n] * sc, list[(size_t) (BL_MAIN + 3) * n] * sc, list[(size_t) (BL_MAIN + 4) * n] * sc));
+    const int cnt = meta >> 1;
+    for (int k = 0; k < cnt; ++k) {
+        const int r0 = BL_MORE + 5 * k;
+        film_put(P, list[(size_t) r0 * n], list[(size_t) (r0 + 1) * n],
+                 mk3(list[(size_t) (r0 + 2) * n] * sc, list[(size_t) (r0 + 3) * n] * sc, list[(size_t) (r0 + 4) * n] * sc));
+    }
+}
+DEV void list_splat_const(const DParams &P, const float *list, f3 c) { // acceptance map: every splat position (:443-450)
+    const size_t n = P.n_chains_alloc;
+    const int meta = __float_as_int(list[(size_t) BL_META * n]);
+    if (meta & 1) film_put(P, list[(size_t) BL_MAIN * n], list[(size_t) (BL_MAIN + 1) * n], c);
+    for (int k = 0; k < (meta >> 1); ++k) film_put(P, list[(size_t) (BL_MORE + 5 * k) * n], list[(size_t) (BL_MORE + 5 * k + 1) * n], c);
+}
+DEV void list_copy(const DParams &P, float *dst, const float *src) {
+    const size_t n = P.n_chains_alloc;
+    const int rows = BL_MORE + 5 * (__float_as_int(src[(size_t) BL_META * n]) >> 1);
+    for (int r = 0; r < rows; ++r) dst[(size_t) r * n] = src[(size_t) r * n];
+}
+
+__global__ void __launch_bounds__(CHAIN_BLOCK) k_bootstrap_bdpt(DParams P, uint32_t n, float *lum_out) {
+    const uint32_t lane = threadIdx.x;
+    const uint32_t c = blockIdx.x * CHAIN_BLOCK + lane; // workspace column
+    if (c >= P.n_chains_alloc) return;
+    MSampler smp;
+    bsampler_setup(smp, P, lane);
+    smp.chain = P.boot_stream; smp.mode = SM_BOOT;
+    const GlobalTables T{P.shade, P.bsdfs, P.emitters};
+    for (uint32_t i = c; i < n; i += P.n_chains_alloc) {
+        smp.major = i;
+        BdptResult R;
+        eval_bdpt(P, T, smp, c, bdpt_nx(P), list_col(P, 1, c), R);
+        lum_out[i] = R.lum;
+    }
+}
+
+__global__ void __launch_bounds__(CHAIN_BLOCK) k_init_chains_bdpt(DParams P, const uint32_t *seed_index, const float *seed_lum) {
+    const uint32_t lane = threadIdx.x;
+    const uint32_t c = blockIdx.x * CHAIN_BLOCK + lane;
+    if (c >= P.n_chains) return;
+    MSampler smp;
+    bsampler_setup(smp, P, lane);
+    smp.chain = P.boot_stream; smp.major = seed_index[c]; smp.mode = SM_BOOT;
+    const GlobalTables T{P.shade, P.bsdfs, P.emitters};
+    BdptResult R;
+    float *cur = list_col(P, 0, c);
+    eval_bdpt(P, T, smp, c, bdpt_nx(P), cur, R);
+    if (!(fabsf((R.lum - seed_lum[c]) / seed_lum[c]) <= EPSILON_F)) atomicExch(P.error_flag, 1); // drmlt_proc.cpp:509-512
+    const float lum = list_finalize(P, cur, R.lum);
+    P.cur_lum[c] = lum;
+    // replayed stream, in call order: emitter (n_e), sensor (n_s); fillReplay tops up sensor then emitter to D
+    const uint32_t D = (uint32_t) P.mmlt_dmax, ne = R.n_emitter;
+    const uint32_t S = (uint32_t) P.mmlt_S, E = (uint32_t) P.mmlt_E;
+    smp.b1_idx = 0xffffffffu;
+    for (uint32_t k = 0; k < S; ++k) P.x[(size_t) k * P.n_chains + c] = smp.u_boot(ne + k); // k < ns: replayed; else top-up
+    for (uint32_t k = 0; k < E; ++k) P.x[(size_t) (S + k) * P.n_chains + c] = smp.u_boot(k < ne ? k : D + k);
+}
+
+__global__ void __launch_bounds__(CHAIN_BLOCK) k_mutate_bdpt(DParams P, uint32_t n_mut, uint32_t mut_base) {
+    const uint32_t lane = threadIdx.x;
+    const uint32_t c = blockIdx.x * CHAIN_BLOCK + lane;
+    const bool live = c < P.n_chains;
+    const uint32_t cc = live ? c : P.n_chains - 1;
+    const uint32_t NX = bdpt_nx(P);
+    for (uint32_t k = 0; k < NX; ++k) lds_x[k * 64u + lane] = P.x[(size_t) k * P.n_chains + cc];
+    float cur_lum = P.cur_lum[cc];
+    float *L0 = list_col(P, 0, cc), *L1 = list_col(P, 1, cc), *L2 = list_col(P, 2, cc);
+
+    MSampler smp;
+    bsampler_setup(smp, P, lane);
+    smp.chain = P.chain_offset + cc;
+    const GlobalTables T{P.shade, P.bsdfs, P.emitters};
+    Counters ct = {0u, 0u, 0u, 0u, 0u};
+    const bool amap = P.acceptance_map != 0;
+    const bool mix = P.use_mixture != 0;
+
+    if (live) for (uint32_t it = 0; it < n_mut; ++it) {
+        const uint32_t m = mut_base + it;
+        const u4 coins = philox4x32_10(P.key0, P.key1, 0u, m, smp.chain, TAG_COIN);
+        const bool large = u32_to_unit(coins.x) < P.p_large;
+        smp.major = m;
+        smp.large = large;
+        float y_lum = 0.f, z_lum = 0.f;
+        uint32_t ns1 = 0, ne1 = 0, ns2 = 0, ne2 = 0;
+        float a1 = 0.f, a2 = 0.f;
+        bool acc1 = false, acc2 = false, doSecond = false;
+
+#pragma nounroll
+        for (int stage = 0; stage < 3; ++stage) {
+            smp.mode = stage == 0 ? SM_STAGE1 : (stage == 1 ? SM_STAGE2 : SM_REVERSE);
+            BdptResult R;
+            // Green's reverse path only needs its luminance; it is written over the first-stage list, which is rejected
+            // for good by then (acc1 = false) and has already been splatted (see below)
+            float *target = stage == 1 ? L2 : L1;
+            eval_bdpt(P, T, smp, cc, NX, target, R);
+            ct.rays += R.nrays;
+            const float lum = list_finalize(P, target, R.lum);
+            if (stage == 0) {
+                y_lum = lum; ns1 = R.n_sensor; ne1 = R.n_emitter;
+                if (!(mix ? lum_invalid_mix(y_lum) : lum_invalid(y_lum))) {
+                    a1 = fminf(1.f, y_lum / cur_lum);
+                    acc1 = a1 >= 1.f || u32_to_unit(coins.y) < a1;
+                }
+                if (!mix) doSecond = !acc1 && !large;
+                else doSecond = !large && u32_to_unit(coins.w) < 0.5f;
+                if (!doSecond) break;
+            } else if (stage == 1) {
+                z_lum = lum; ns2 = R.n_sensor; ne2 = R.n_emitter;
+                if (mix) {
+                    acc1 = false;
+                    a1 = 0.f;
+                    if (!lum_invalid_mix(z_lum)) {
+                        a2 = fminf(1.f, z_lum / cur_lum);
+                        acc2 = a2 >= 1.f || u32_to_unit(coins.z) < a2;
+                    }
+                    break;
+                }
+                if (lum_invalid(z_lum)) break;
+                if (P.type == 0) {
+                    // Green: the first-stage splats must reach the film before the reverse move reuses their list
+                    if (!amap && a1 > 0.f) list_splat(P, L1, y_lum, a1);
+                    continue;
+                }
+                if (P.type == 1) {
+                    float aRev = fminf(1.f, y_lum / z_lum);
+                    if (!(aRev >= 1.f)) {
+                        float num = 0.f, den = 0.f;
+                        for (int sg = 0; sg < 2; ++sg) {
+                            const uint32_t nmax = sg == 0 ? max(ns1, ns2) : max(ne1, ne2);
+                            const uint32_t dimStage = nmax > 0u ? nmax - 1u : 0u;
+                            smp.select(sg);
+                            for (uint32_t i = 0; i < dimStage; ++i) {
+                                float yi = smp.y_raw(i);
+                                num += kelemen_logpdf(smp.z_raw(i) - yi);
+                                den += kelemen_logpdf(smp.x(i) - yi);
+                            }
+                        }
+                        float ratio = __expf(num - den);
+                        if (!lum_invalid(ratio)) {
+                            a2 = fminf(1.f, (z_lum / cur_lum) * ratio * (1.f - aRev) / (1.f - a1));
+                            acc2 = a2 >= 1.f || u32_to_unit(coins.z) < a2;
+                        }
+                    }
+                } else {
+                    if (z_lum < y_lum) { a2 = 0.f; }
+                    else if (z_lum >= cur_lum) { a2 = 1.f; acc2 = true; }
+                    else {
+                        a2 = (z_lum - y_lum) / (cur_lum - y_lum);
+                        acc2 = a2 >= 1.f || u32_to_unit(coins.z) < a2;
+                    }
+                }
+                break;
+            } else {
+                ct.acc2b_rev += 1u << 16;
+                float aRev = lum_invalid(lum) ? 0.f : fminf(1.f, lum / z_lum);
+                if (aRev != 1.f) {
+                    a2 = fminf(1.f, (z_lum / cur_lum) * (1.f - aRev) / (1.f - a1));
+                    acc2 = a2 >= 1.f || u32_to_unit(coins.z) < a2;
+                }
+            }
+        }
+        const bool y_splatted = !mix && P.type == 0 && doSecond && !lum_invalid(z_lum); // Green went on to the reverse move
+
+        if (!mix) {
+            float w1 = a1, w2 = (1.f - a1) * a2, w0 = 1.f - w1 - w2;
+            if (!amap) {
+                list_splat(P, L0, cur_lum, w0);
+                if (!y_splatted) list_splat(P, L1, y_lum, w1);
+                if (doSecond) list_splat(P, L2, z_lum, w2);
+            }
+        } else {
+            const float a = doSecond ? a2 : a1;
+            list_splat(P, L0, cur_lum, 1.f - a);
+            if (doSecond) list_splat(P, L2, z_lum, a); else list_splat(P, L1, y_lum, a);
+        }
+
+        if (large) {
+            ct.large_acc1l += 1u + (acc1 ? 1u << 16 : 0u);
+            if (doSecond) ct.acc1b_secl += 1u << 16;
+            if (acc2) ct.secb_acc2l += 1u << 16;
+        } else {
+            if (acc1) ct.acc1b_secl += 1u;
+            if (doSecond) ct.secb_acc2l += 1u;
+            if (acc2) ct.acc2b_rev += 1u;
+        }
+
+        if (acc1 || acc2) {
+            for (int sg = 0; sg < 2; ++sg) {
+                smp.select(sg);
+                const uint32_t nk = sg == 0 ? smp.S : smp.E;
+                for (uint32_t k = 0; k < nk; ++k) {
+                    const float v = wrap01(acc1 ? smp.y_raw(k) : smp.z_raw(k));
+                    lds_x[(smp.x_off + k) * 64u + lane] = v;
+                    if (smp.type == 2 && (k & 1u)) smp.pair_base = 0xffffffffu;
+                }
+            }
+            list_copy(P, L0, acc1 ? L1 : L2);
+            cur_lum = acc1 ? y_lum : z_lum;
+            if (amap) {
+                if (acc1) { if (!large && !mix) list_splat_const(P, L0, mk3(1.f, 0.f, 0.f)); }
+                else if (!mix) list_splat_const(P, L0, mk3(0.f, 1.f, 0.f));
+            }
+        }
+    }
+
+    if (live) {
+        for (uint32_t k = 0; k < NX; ++k) P.x[(size_t) k * P.n_chains + c] = lds_x[k * 64u + lane];
+        P.cur_lum[c] = cur_lum;
+    }
+    unsigned long long v[9];
+    v[0] = wave_sum(ct.large_acc1l & 0xffffu); v[1] = wave_sum(ct.large_acc1l >> 16);
+    v[2] = wave_sum(ct.acc1b_secl & 0xffffu);  v[3] = wave_sum(ct.acc1b_secl >> 16);
+    v[4] = wave_sum(ct.secb_acc2l & 0xffffu);  v[5] = wave_sum(ct.secb_acc2l >> 16);
+    v[6] = wave_sum(ct.acc2b_rev & 0xffffu);   v[7] = wave_sum(ct.acc2b_rev >> 16);
+    v[8] = wave_sum(ct.rays);
+    if (lane == 0)
+        for (int i = 0; i < 9; ++i) atomicAdd(P.stats + i, v[i]);
+}
+
+// u: [sensor S | emitter E] per point (dim >= S + E); out: rows of `stride` floats:
+// [lum, hasMain, px, py, r, g, b, nMore, nDims, nRays, nMore x (px, py, r, g, b)]
+__global__ void __launch_bounds__(CHAIN_BLOCK) k_eval_lists_bdpt(DParams P, const float *u, uint32_t n, uint32_t dim, float *out, uint32_t stride) {
+    const uint32_t lane = threadIdx.x;
+    const uint32_t c = blockIdx.x * CHAIN_BLOCK + lane;
+    if (c >= P.n_chains_alloc) return;
+    MSampler smp;
+    bsampler_setup(smp, P, lane);
+    smp.chain = 0u; smp.major = 0u; smp.mode = SM_ARRAY;
+    const GlobalTables T{P.shade, P.bsdfs, P.emitters};
+    const size_t na = P.n_chains_alloc;
+    for (uint32_t i = c; i < n; i += P.n_chains_alloc) {
+        smp.arr = u + (size_t) i * dim;
+        BdptResult R;
+        float *L = list_col(P, 1, c);
+        eval_bdpt(P, T, smp, c, bdpt_nx(P), L, R);
+        float *o = out + (size_t) i * stride;
+        for (uint32_t k = 0; k < stride; ++k) o[k] = 0.f;
+        o[0] = R.lum; o[1] = R.has_main ? 1.f : 0.f;
+        for (int k = 0; k < 5; ++k) o[2 + k] = L[(size_t) (BL_MAIN + k) * na];
+        o[7] = (float) R.n_more; o[8] = (float) (R.n_sensor + R.n_emitter); o[9] = (float) R.nrays;
+        for (int k = 0; k < R.n_more && 10 + 5 * (k + 1) <= (int) stride; ++k)
+            for (int q = 0; q < 5; ++q) o[10 + 5 * k + q] = L[(size_t) (BL_MORE + 5 * k + q) * na];
+    }
+}
+
+static size_t bdpt_lds_bytes(const DParams &P) {
+    return ((size_t) P.mmlt_S + P.mmlt_E + 4 * ((size_t) 2 * P.max_depth + 1)) * 64 * sizeof(float);
+}
+void launch_bootstrap_bdpt(const DParams &P, uint32_t n, float *lum_out, hipStream_t st) {
+    hipLaunchKernelGGL(k_bootstrap_bdpt, dim3((P.n_chains_alloc + CHAIN_BLOCK - 1) / CHAIN_BLOCK), dim3(CHAIN_BLOCK), bdpt_lds_bytes(P), st, P, n, lum_out);
+}
+void launch_init_chains_bdpt(const DParams &P, const uint32_t *seed_index, const float *seed_lum, hipStream_t st) {
+    hipLaunchKernelGGL(k_init_chains_bdpt, dim3((P.n_chains + CHAIN_BLOCK - 1) / CHAIN_BLOCK), dim3(CHAIN_BLOCK), bdpt_lds_bytes(P), st, P, seed_index,
+                       seed_lum);
+}
+void launch_mutate_bdpt(const DParams &P, uint32_t n_mut, uint32_t mut_base, hipStream_t st) {
+    hipLaunchKernelGGL(k_mutate_bdpt, dim3((P.n_chains + CHAIN_BLOCK - 1) / CHAIN_BLOCK), dim3(CHAIN_BLOCK), bdpt_lds_bytes(P), st, P, n_mut, mut_base);
+}
+void launch_eval_lists_bdpt(const DParams &P, const float *u, uint32_t n, uint32_t dim, float *out, uint32_t stride, hipStream_t st) {
+    hipLaunchKernelGGL(k_eval_lists_bdpt, dim3((P.n_chains_alloc + CHAIN_BLOCK - 1) / CHAIN_BLOCK), dim3(CHAIN_BLOCK), bdpt_lds_bytes(P), st, P, u, n, dim, out,
+                       stride);
+}

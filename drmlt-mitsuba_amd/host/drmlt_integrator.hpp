@@ -114,6 +114,8 @@ public:
         if (m_firstStageSizeReduction <= 0) throw std::runtime_error("firstStageSizeReduction must be positive");
         m_cfg.timeout_s = props.getInteger("timeout", 0);                             // :296
         m_cfg.no_light_image = props.getBoolean("lightImage", true) ? 0 : 1;          // :301
+        // :228-231 (forced off for mmlt). bdpt: the device builds the directSampling=false variant only (see drmlt_create)
+        m_cfg.no_direct_sampling = (props.getBoolean("directSampling", true) && m_cfg.technique != DRMLT_TECH_MMLT) ? 0 : 1;
         m_cfg.average_luminance = (float) props.getFloat("averageLuminance", -1.0);
         std::string type = props.getString("type");
         if (type == "green") m_cfg.type = DRMLT_TYPE_GREEN;

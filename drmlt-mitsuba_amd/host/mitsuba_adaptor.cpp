@@ -59,6 +59,7 @@ public:
         m_firstStageSizeReduction = props.getInteger("firstStageSizeReduction", 16);
         m_cfg.timeout_s = props.getInteger("timeout", 0);
         m_cfg.no_light_image = props.getBoolean("lightImage", true) ? 0 : 1;
+        m_cfg.no_direct_sampling = (props.getBoolean("directSampling", true) && m_cfg.technique != DRMLT_TECH_MMLT) ? 0 : 1;
     }
 
     DRMLT(Stream *stream, InstanceManager *manager) : Integrator(stream, manager), m_stop(0) {

@@ -263,10 +263,20 @@ int drmlt_kernel_time(drmlt_ctx *ctx, double *avg_ms, uint64_t *launches, int re
  * (test utility: equal-expectation reference for the MLT image). */
 int drmlt_render_pt(drmlt_ctx *ctx, uint32_t spp, uint64_t seed, float *out_rgb);
 
+/* technique=bdpt: f(u) is a splat LIST (one sensor-side splat accumulating all
+ * t >= 2 strategies + one light-image splat per t = 1 strategy,
+ * pathsampler.cpp:357-361,514-519). A point is [sensor S | emitter E]
+ * (drmlt_stats.max_dim / 2 each at most); a result row is `stride` floats:
+ * [lum, hasMain, px, py, r, g, b, nMore, nDims, nRays, nMore x (px, py, r, g, b)]. */
+int drmlt_eval_lists(drmlt_ctx *ctx, const float *u, uint32_t n, uint32_t dim,
+                     float *out, uint32_t stride);
+
 /* Chain state dump for parity tests: lum/x/y/rgb of chain's current state and
  * the first `dim` PSS components (u is n_chains x dim, may be NULL).
  * technique=mmlt: components are [sensor S | emitter E | direct]; n_dims = the
- * chain's path depth, n_rays = t of the current state. */
+ * chain's path depth, n_rays = t of the current state. technique=bdpt:
+ * components are [sensor S | emitter E]; cur = main splat of the current list
+ * (normalised), n_dims = 1 if it exists, n_rays = number of light-image splats. */
 int drmlt_chain_state(drmlt_ctx *ctx, drmlt_splat *cur, float *u, uint32_t dim);
 
 const char *drmlt_last_error(drmlt_ctx *ctx);

@@ -1,0 +1,110 @@
+"""GPU parity for technique=bdpt, directSampling=false: through the C-ABI, against the oracle's
+restatement of PathSampler::sampleSplats(EBidirectional) and of the chain loop over multi-splat lists."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+LUMW = np.array([0.212671, 0.715160, 0.072169])
+
+
+def lum(img):
+    return img @ LUMW
+
+
+def make(pkg, ob, sd, **kw):
+    abi = pkg.abi
+    base = dict(technique="bdpt", max_depth=6, rr_depth=4, direct_samples=-1, no_direct_sampling=1, luminance_samples=20000)
+    base.update(kw)
+    cfg = abi.make_config(**base)
+    return cfg, pkg.Context(cfg, sd), ob.Oracle(abi, cfg, sd, 64)
+
+
+@pytest.mark.parametrize("name", ["cornell_c2", "glass_sphere", "door_c3"])
+def test_lists_match_oracle(pkg, ob, name, native_lib):
+    """f(u) = a splat list: same number of light-image splats, same dims / rays, luminance and every splat within 2e-3."""
+    sd = pkg.scenes.SCENES[name](res=64)
+    cfg, ctx, orc = make(pkg, ob, sd, type="orbital", work_units=1024)
+    rng = np.random.default_rng(11)
+    n = 6000
+    us, ue = rng.random((n, 24), dtype=np.float32), rng.random((n, 24), dtype=np.float32)
+    g, o = ctx.eval_lists_bdpt(us, ue), orc.bdpt_eval(us, ue)
+    same = (g[:, 1] == o[:, 1]) & (g[:, 7] == o[:, 7]) & (g[:, 8] == o[:, 8]) & (g[:, 9] == o[:, 9])
+    assert same.mean() > 0.99, same.mean()
+    rel = np.abs(g[:, 0] - o[:, 0])[same] / np.maximum(o[:, 0][same], 1e-3)
+    assert np.quantile(rel, 0.99) < 2e-3, np.quantile(rel, 0.99)
+    assert g[:, 0].sum() == pytest.approx(o[:, 0].sum(), rel=2e-3)
+    ok = same & (rel_full(g, o) < 1e-2)
+    assert ok.mean() > 0.985
+    np.testing.assert_allclose(g[ok][:, 2:4], o[ok][:, 2:4], atol=1e-3)                 # main splat position
+    np.testing.assert_allclose(g[ok][:, 4:7], o[ok][:, 4:7], rtol=2e-2, atol=2e-4)      # main splat value
+    mg, mo = g[ok][:, 10:].reshape(ok.sum(), -1, 5), o[ok][:, 10:].reshape(ok.sum(), -1, 5)
+    np.testing.assert_allclose(mg[:, :, :2], mo[:, :, :2], atol=3e-2)                   # light-image positions (fp32 light paths)
+    np.testing.assert_allclose(mg[:, :, 2:], mo[:, :, 2:], rtol=3e-2, atol=3e-4)
+
+
+def rel_full(g, o):
+    return np.abs(g[:, 0] - o[:, 0]) / np.maximum(o[:, 0], 1e-3)
+
+
+VARIANTS = [dict(type="orbital"), dict(type="green"), dict(type="mira"), dict(type="orbital", use_mixture=1),
+            dict(type="orbital", no_light_image=1), dict(type="green", direct_samples=16)]
+
+
+@pytest.mark.parametrize("kw", VARIANTS, ids=lambda k: "-".join("%s=%s" % i for i in k.items()))
+def test_chains_track_the_oracle(pkg, ob, kw, native_lib):
+    sd = pkg.scenes.glass_sphere(32)
+    n_chains, n_mut = 2048, 32
+    cfg, ctx, orc = make(pkg, ob, sd, work_units=n_chains, sample_count=1, **kw)
+    bg, bo = ctx.seed(0xABCD), orc.seed(0xABCD)
+    assert bg == pytest.approx(bo, rel=1e-3)
+    dim = ctx.stats().max_dim
+    (c0g, u0g), (c0o, u0o) = ctx.chain_state(dim), orc.chain_state(dim)
+    same0 = np.abs(c0g["luminance"] - c0o["luminance"]) <= 1e-3 * c0o["luminance"]
+    assert same0.mean() > 0.5
+    ctx.run(n_chains * n_mut); orc.run(n_chains * n_mut, 8)
+    (cg, ug), (co, uo) = ctx.chain_state(dim), orc.chain_state(dim)
+    tracked = same0 & (np.abs(cg["luminance"] - co["luminance"]) <= 3e-3 * co["luminance"]) & (cg["n_rays"] == co["n_rays"])
+    assert tracked.sum() / same0.sum() > 0.93, tracked.sum() / same0.sum()
+    sg, so = ctx.stats(), orc.stats()
+    assert sg.mutations == so.mutations == n_chains * n_mut
+    for k in ("first", "large", "bold", "second", "overall"):
+        bg_, bo_ = getattr(sg, k + "_base"), getattr(so, k + "_base")
+        assert abs(bg_ - bo_) <= 0.02 * max(bo_, 1) + 20, (k, bg_, bo_)
+        if bo_ > 200:
+            pg, po = getattr(sg, k + "_acc") / bg_, getattr(so, k + "_acc") / bo_
+            assert abs(pg - po) < 4 * np.sqrt(po * (1 - po) / bo_) + 0.015, (k, pg, po)
+    assert abs(sg.rays - so.rays) <= 0.03 * so.rays
+    fg, fo = ctx.film(), orc.film()
+    assert lum(fg).sum() == pytest.approx(lum(fo).sum(), rel=5e-3)
+    bgk, bok = (lum(f).reshape(8, 4, 8, 4).sum(axis=(1, 3)) for f in (fg, fo))
+    assert np.abs(bgk - bok).sum() / bok.sum() < 0.1
+
+
+def test_bdpt_image_and_acceptance_map(pkg, ob, native_lib):
+    sd = pkg.scenes.glass_sphere(32)
+    cfg, ctx, orc = make(pkg, ob, sd, type="orbital", work_units=8192, sample_count=512, luminance_samples=200000)
+    ref = orc.bdpt_render(32 * 32 * 3000, seed=9, nthreads=8)
+    b = ctx.seed(0x5EED)
+    ctx.run(32 * 32 * 512)
+    img = ctx.develop()
+    assert b == pytest.approx(lum(ref).mean(), rel=0.02)
+    blk = lambda a: a.reshape(8, 4, 8, 4, 3).mean((1, 3))
+    assert np.abs(blk(img) - blk(ref)).mean() / ref.mean() < 0.04
+    # README's acceptance-map example uses technique=bdpt: every splat of an accepted list marks its pixel
+    cfg2, ctx2, orc2 = make(pkg, ob, sd, type="orbital", work_units=4096, sample_count=1, acceptance_map=1)
+    assert ctx2.seed(3) == 1.0
+    orc2.seed(3)
+    ctx2.run(4096 * 32); orc2.run(4096 * 32, 8)
+    fg, fo = ctx2.film().astype(np.float64), orc2.film().astype(np.float64)
+    assert fg[..., 2].max() == 0 and fg[..., 0].sum() > 0 and fg[..., 1].sum() > 0
+    assert fg[..., 0].sum() == pytest.approx(fo[..., 0].sum(), rel=0.03)
+    assert fg[..., 1].sum() == pytest.approx(fo[..., 1].sum(), rel=0.05)
+
+
+def test_refusals(pkg, native_lib):
+    sd = pkg.scenes.cornell_c2(16)
+    with pytest.raises(pkg.DrmltError, match="directSampling=false"):
+        pkg.Context(pkg.abi.make_config(technique="bdpt", max_depth=5, work_units=64), sd)
+    ctx = pkg.Context(pkg.abi.make_config(technique="bdpt", max_depth=5, work_units=64, no_direct_sampling=1), sd)
+    with pytest.raises(pkg.DrmltError, match="drmlt_eval_lists"):
+        ctx.eval_paths(np.zeros((4, 64), dtype=np.float32))
