@@ -386,8 +386,77 @@ DEV Hit trace_bvh(const DParams &P, f3 o, f3 d, float tmin, float tmax, bool any
     return h;
 }
 
+// Brute-force loop for scenes of flat primitives only (rectangles, triangles, merged pairs). Same tests as
+// intersect_prim, restructured around the scalar unit, which was issuing almost as many instructions as the VALU:
+//   * DPrimFlat: the (u, v) rows arrive as aligned SGPR pairs -> packed FMAs without scalar shuffles;
+//   * two sentinel records end the array, so the software pipeline reads ahead without clamping its index and the
+//     loads take immediate offsets from one running pointer;
+//   * the sub-triangle of a merged pair is resolved once, for the final hit, not per record.
+typedef float float2v __attribute__((ext_vector_type(2)));
+typedef const DPrimFlat __attribute__((address_space(4))) *ScalarFlatPtr;
+
+struct FlatRec {
+    float2v cx, cy, cz, cw;
+    float z0, z1, z2, z3;
+    int ks;
+};
+
+template <bool TRI> DEV void test_flat(const FlatRec &G, f3 o, f3 d, float tmin, float &best_t, float2v &best_uv, int &best_ks) {
+    const float ldz = fmaf(G.z0, d.x, fmaf(G.z1, d.y, G.z2 * d.z));
+    const float loz = fmaf(G.z0, o.x, fmaf(G.z1, o.y, fmaf(G.z2, o.z, G.z3)));
+    const float t = -loz * fast_rcp(ldz);
+    const float2v lo = G.cx * o.x + (G.cy * o.y + (G.cz * o.z + G.cw));
+    const float2v ld = G.cx * d.x + (G.cy * d.y + G.cz * d.z);
+    const float2v uv = ld * t + lo;
+    float w;
+    if (TRI && (G.ks & 0xff) == PRIM_TRIANGLE) w = 1.f - (uv.x + uv.y);
+    else { const float2v om = 1.f - uv; w = fminf(om.x, om.y); }
+    const bool hit = fminf(fminf(uv.x, uv.y), w) >= 0.f && t >= tmin && t <= best_t;
+    best_t = hit ? t : best_t;
+    best_uv.x = hit ? uv.x : best_uv.x;
+    best_uv.y = hit ? uv.y : best_uv.y;
+    best_ks = hit ? G.ks : best_ks;
+}
+
+template <bool TRI> DEV Hit trace_flat(const DParams &P, f3 o, f3 d, float tmin, float tmax) {
+    ScalarFlatPtr p = (ScalarFlatPtr) (uintptr_t) P.prims_flat;
+    auto load = [](ScalarFlatPtr q, FlatRec &G) {
+        G.cx = float2v{q->c[0], q->c[1]}; G.cy = float2v{q->c[2], q->c[3]}; G.cz = float2v{q->c[4], q->c[5]}; G.cw = float2v{q->c[6], q->c[7]};
+        G.z0 = q->rz[0]; G.z1 = q->rz[1]; G.z2 = q->rz[2]; G.z3 = q->rz[3];
+        G.ks = q->kind_shade;
+    };
+#define PINF(G) asm volatile("" ::"s"(G.cx.x), "s"(G.cz.x), "s"(G.z0), "s"(G.ks))
+    float best_t = tmax;
+    float2v best_uv = {0.f, 0.f};
+    int best_ks = -1;
+    const int n = P.n_prims;
+    FlatRec A, B;
+    load(p, A);
+    for (int i = 0; i < n; i += 2, p += 2) { // records n and n + 1 are sentinels
+        PINF(A);
+        load(p + 1, B);
+        test_flat<TRI>(A, o, d, tmin, best_t, best_uv, best_ks);
+        PINF(B);
+        load(p + 2, A);
+        test_flat<TRI>(B, o, d, tmin, best_t, best_uv, best_ks);
+    }
+#undef PINF
+    Hit h{-1, best_t, best_uv.x, best_uv.y};
+    if (best_ks >= 0) {
+        h.prim = best_ks >> 8;
+        if ((best_ks & 0xff) == PRIM_QUAD2) { // sub-triangle (a,b,c) for v <= u, (a,c,d) otherwise; its own barycentrics
+            const bool second = h.v > h.u;
+            const float uu = second ? h.u : h.u - h.v, vv = second ? h.v - h.u : h.v;
+            h.prim += second ? 1 : 0;
+            h.u = uu; h.v = vv;
+        }
+    }
+    return h;
+}
+
 template <int FEAT = 15> DEV Hit trace(const DParams &P, f3 o, f3 d, float tmin, float tmax, bool any_hit) {
     if ((FEAT & 8) && P.use_bvh) return trace_bvh(P, o, d, tmin, tmax, any_hit);
+    if (!(FEAT & 4) && P.prims_flat) return P.has_plain_tri ? trace_flat<true>(P, o, d, tmin, tmax) : trace_flat<false>(P, o, d, tmin, tmax);
     return trace_brute<FEAT>(P, o, d, tmin, tmax);
 }
 

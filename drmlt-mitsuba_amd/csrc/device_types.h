@@ -28,6 +28,16 @@ struct DPrim {
     int32_t pad;
 };
 
+// The same intersection record laid out for the brute-force loop of flat-primitive scenes: rows 0 and 1 of the
+// affine map interleaved column by column, so that each (u, v) column is one aligned SGPR pair feeding a packed
+// fp32 FMA directly (the row-major record needs six scalar moves per primitive to build those pairs).
+struct DPrimFlat {
+    float c[8];        // (m0, m4), (m1, m5), (m2, m6), (m3, m7)
+    float rz[4];       // row 2: m8 .. m11
+    int32_t kind_shade;
+    int32_t pad[3];
+};
+
 struct DShade {
     float origin[3]; // tri: p0; rect: centre; sphere: centre
     float eu[3];     // tri: p1-p0; rect: objectToWorld column 0; sphere: eu[0] = radius
@@ -104,6 +114,9 @@ struct DParams {
     float *bd_verts;          // [BV_FIELDS][2 maxDepth + 1][n_chains_alloc] stored subpath vertices
     float *bd_lists;          // [3][BL rows][n_chains_alloc] splat lists: 0 current, 1 first-stage, 2 second-stage proposal
     uint32_t n_chains_alloc;  // column stride of the two buffers above
+    // flat-primitive fast path of the brute-force ray loop (device_path.h: trace_flat)
+    const DPrimFlat *prims_flat; // n_prims records + 2 sentinels that no ray can hit, or NULL (scene has spheres / uses the BVH)
+    int32_t has_plain_tri;       // any PRIM_TRIANGLE record (needs the u + v <= 1 test)
 };
 
 // result of one PSS evaluation, SoA-friendly

@@ -73,7 +73,7 @@ struct drmlt_ctx {
     DParams P{};
     std::string error;
 
-    DevBuf d_prims, d_shade, d_bsdfs, d_emitters, d_bvh, d_lut, d_film, d_x, d_cur, d_stats, d_err, d_scratch, d_chain_i, d_importance, d_bd_verts, d_bd_lists;
+    DevBuf d_prims, d_shade, d_bsdfs, d_emitters, d_bvh, d_lut, d_film, d_x, d_cur, d_stats, d_err, d_scratch, d_chain_i, d_importance, d_bd_verts, d_bd_lists, d_prims_flat;
     std::vector<DPrim> prims;
     std::vector<DShade> shade;
 
@@ -413,6 +413,23 @@ drmlt_ctx *drmlt_create(const drmlt_config *cfg, const drmlt_scene *scene, int d
               up(ctx->d_emitters, emitters.data(), emitters.size() * sizeof(DEmitter)) &&
               up(ctx->d_lut, lut, sizeof lut);
     if (ok && P.use_bvh) ok = up(ctx->d_bvh, nodes.data(), nodes.size() * sizeof(DBvhNode));
+    // flat-primitive fast path of the brute-force loop: interleaved records + two sentinels no ray can hit
+    // (ld.z = 0, lo.z = 1: t = -inf fails t >= tmin)
+    P.prims_flat = nullptr; P.has_plain_tri = 0;
+    bool flat_only = !P.use_bvh && !getenv("DRMLT_NO_FLAT_LOOP");
+    for (const DPrim &g : ctx->prims) { if (g.type == PRIM_SPHERE) flat_only = false; if (g.type == PRIM_TRIANGLE) P.has_plain_tri = 1; }
+    if (ok && flat_only) {
+        std::vector<DPrimFlat> flat(ctx->prims.size() + 2);
+        for (size_t i = 0; i < ctx->prims.size(); ++i) {
+            const DPrim &g = ctx->prims[i];
+            DPrimFlat &f = flat[i];
+            for (int c = 0; c < 4; ++c) { f.c[2 * c] = g.m[c]; f.c[2 * c + 1] = g.m[4 + c]; f.rz[c] = g.m[8 + c]; }
+            f.kind_shade = g.kind_shade; f.pad[0] = f.pad[1] = f.pad[2] = 0;
+        }
+        for (size_t i = ctx->prims.size(); i < flat.size(); ++i) { memset(&flat[i], 0, sizeof(DPrimFlat)); flat[i].rz[3] = 1.f; flat[i].kind_shade = PRIM_RECTANGLE; }
+        ok = up(ctx->d_prims_flat, flat.data(), flat.size() * sizeof(DPrimFlat));
+        if (ok) P.prims_flat = ctx->d_prims_flat.as<DPrimFlat>();
+    }
     if (!ok) return bail(ctx, "device allocation/upload of the scene failed");
 
     // ---- derived quantities of DRMLT::render (drmlt.cpp:434-476)
