@@ -456,7 +456,7 @@ template <bool TRI> DEV Hit trace_flat(const DParams &P, f3 o, f3 d, float tmin,
 
 template <int FEAT = 15> DEV Hit trace(const DParams &P, f3 o, f3 d, float tmin, float tmax, bool any_hit) {
     if ((FEAT & 8) && P.use_bvh) return trace_bvh(P, o, d, tmin, tmax, any_hit);
-    if (!(FEAT & 4) && P.prims_flat) return P.has_plain_tri ? trace_flat<true>(P, o, d, tmin, tmax) : trace_flat<false>(P, o, d, tmin, tmax);
+    if (P.prims_flat) return P.has_plain_tri ? trace_flat<true>(P, o, d, tmin, tmax) : trace_flat<false>(P, o, d, tmin, tmax);
     return trace_brute<FEAT>(P, o, d, tmin, tmax);
 }
 

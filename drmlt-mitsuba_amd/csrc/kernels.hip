@@ -673,7 +673,10 @@ void launch_mutate(const DParams &P, uint32_t n_mut, uint32_t mut_base, hipStrea
     } else if (P.kernel_variant == 3) { // 32 chains per wave, rows of 32 floats
         size_t lds = (D + 2 * D4) * 32 * sizeof(float);
         if (P.tables_in_lds) lds += (size_t) P.n_shade * 64 + (size_t) P.n_bsdfs * 48 + (size_t) P.n_emitters * 32;
+        // specialisations: 0 = diffuse polygons (Cornell configs); 3 = + rough conductor / dielectric, still flat primitives
+        // under the brute-force loop (door config); 15 = everything (spheres, BVH traversal)
         if (P.features == 0) hipLaunchKernelGGL(k_mutate_v3<0>, dim3((P.n_chains + 31) / 32), block, lds, st, P, n_mut, mut_base);
+        else if ((P.features & ~3) == 0) hipLaunchKernelGGL(k_mutate_v3<3>, dim3((P.n_chains + 31) / 32), block, lds, st, P, n_mut, mut_base);
         else hipLaunchKernelGGL(k_mutate_v3<15>, dim3((P.n_chains + 31) / 32), block, lds, st, P, n_mut, mut_base);
     } else { // x + first-stage uniforms + second-stage values, one 256 B row per dimension
         size_t lds = (D + 2 * D4) * 64 * sizeof(float);
