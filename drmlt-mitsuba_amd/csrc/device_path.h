@@ -429,7 +429,7 @@ template <bool TRI> DEV Hit trace_flat(const DParams &P, f3 o, f3 d, float tmin,
     float best_t = tmax;
     float2v best_uv = {0.f, 0.f};
     int best_ks = -1;
-    const int n = P.n_prims;
+    const int n = P.n_flat;
     FlatRec A, B;
     load(p, A);
     for (int i = 0; i < n; i += 2, p += 2) { // records n and n + 1 are sentinels
@@ -456,7 +456,20 @@ template <bool TRI> DEV Hit trace_flat(const DParams &P, f3 o, f3 d, float tmin,
 
 template <int FEAT = 15> DEV Hit trace(const DParams &P, f3 o, f3 d, float tmin, float tmax, bool any_hit) {
     if ((FEAT & 8) && P.use_bvh) return trace_bvh(P, o, d, tmin, tmax, any_hit);
-    if (P.prims_flat) return P.has_plain_tri ? trace_flat<true>(P, o, d, tmin, tmax) : trace_flat<false>(P, o, d, tmin, tmax);
+    if (P.prims_flat) {
+        Hit h = P.has_plain_tri ? trace_flat<true>(P, o, d, tmin, tmax) : trace_flat<false>(P, o, d, tmin, tmax);
+        if (FEAT & 4) // the spheres of the scene follow the flat records; same wave-uniform scalar loads, one at a time
+            for (int i = P.n_flat; i < P.n_prims; ++i) {
+                ScalarPrimPtr sp = (ScalarPrimPtr) (uintptr_t) P.prims;
+                DPrim G;
+#pragma unroll
+                for (int k = 0; k < 12; ++k) G.m[k] = sp[i].m[k];
+                const int ks = sp[i].kind_shade;
+                G.type = PRIM_SPHERE; G.shade = ks >> 8;
+                intersect_prim<4>(G, G.shade, o, d, tmin, h);
+            }
+        return h;
+    }
     return trace_brute<FEAT>(P, o, d, tmin, tmax);
 }
 

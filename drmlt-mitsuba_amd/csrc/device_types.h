@@ -115,8 +115,9 @@ struct DParams {
     float *bd_lists;          // [3][BL rows][n_chains_alloc] splat lists: 0 current, 1 first-stage, 2 second-stage proposal
     uint32_t n_chains_alloc;  // column stride of the two buffers above
     // flat-primitive fast path of the brute-force ray loop (device_path.h: trace_flat)
-    const DPrimFlat *prims_flat; // n_prims records + 2 sentinels that no ray can hit, or NULL (scene has spheres / uses the BVH)
+    const DPrimFlat *prims_flat; // n_flat records + 2 sentinels that no ray can hit, or NULL (BVH scenes)
     int32_t has_plain_tri;       // any PRIM_TRIANGLE record (needs the u + v <= 1 test)
+    int32_t n_flat;              // records [0, n_flat) of `prims` are flat (and mirrored in prims_flat), [n_flat, n_prims) are spheres
 };
 
 // result of one PSS evaluation, SoA-friendly

@@ -400,6 +400,8 @@ drmlt_ctx *drmlt_create(const drmlt_config *cfg, const drmlt_scene *scene, int d
         ctx->prims.swap(np);
     }
 
+    if (!P.use_bvh) // brute-force order: flat records first, spheres last (trace(): flat loop, then the sphere loop)
+        std::stable_partition(ctx->prims.begin(), ctx->prims.end(), [](const DPrim &g) { return g.type != PRIM_SPHERE; });
     for (DPrim &g : ctx->prims) g.kind_shade = g.type | (g.shade << 8);
     auto up = [&](DevBuf &b, const void *src, size_t bytes) -> bool {
         if (b.alloc(std::max<size_t>(bytes, 64)) != hipSuccess) return false;
@@ -415,18 +417,18 @@ drmlt_ctx *drmlt_create(const drmlt_config *cfg, const drmlt_scene *scene, int d
     if (ok && P.use_bvh) ok = up(ctx->d_bvh, nodes.data(), nodes.size() * sizeof(DBvhNode));
     // flat-primitive fast path of the brute-force loop: interleaved records + two sentinels no ray can hit
     // (ld.z = 0, lo.z = 1: t = -inf fails t >= tmin)
-    P.prims_flat = nullptr; P.has_plain_tri = 0;
-    bool flat_only = !P.use_bvh && !getenv("DRMLT_NO_FLAT_LOOP");
-    for (const DPrim &g : ctx->prims) { if (g.type == PRIM_SPHERE) flat_only = false; if (g.type == PRIM_TRIANGLE) P.has_plain_tri = 1; }
-    if (ok && flat_only) {
-        std::vector<DPrimFlat> flat(ctx->prims.size() + 2);
-        for (size_t i = 0; i < ctx->prims.size(); ++i) {
+    P.prims_flat = nullptr; P.has_plain_tri = 0; P.n_flat = 0;
+    const bool flat_loop = !P.use_bvh && !getenv("DRMLT_NO_FLAT_LOOP");
+    for (const DPrim &g : ctx->prims) { if (g.type != PRIM_SPHERE) P.n_flat++; if (g.type == PRIM_TRIANGLE) P.has_plain_tri = 1; }
+    if (ok && flat_loop) {
+        std::vector<DPrimFlat> flat((size_t) P.n_flat + 2);
+        for (size_t i = 0; i < (size_t) P.n_flat; ++i) {
             const DPrim &g = ctx->prims[i];
             DPrimFlat &f = flat[i];
             for (int c = 0; c < 4; ++c) { f.c[2 * c] = g.m[c]; f.c[2 * c + 1] = g.m[4 + c]; f.rz[c] = g.m[8 + c]; }
             f.kind_shade = g.kind_shade; f.pad[0] = f.pad[1] = f.pad[2] = 0;
         }
-        for (size_t i = ctx->prims.size(); i < flat.size(); ++i) { memset(&flat[i], 0, sizeof(DPrimFlat)); flat[i].rz[3] = 1.f; flat[i].kind_shade = PRIM_RECTANGLE; }
+        for (size_t i = (size_t) P.n_flat; i < flat.size(); ++i) { memset(&flat[i], 0, sizeof(DPrimFlat)); flat[i].rz[3] = 1.f; flat[i].kind_shade = PRIM_RECTANGLE; }
         ok = up(ctx->d_prims_flat, flat.data(), flat.size() * sizeof(DPrimFlat));
         if (ok) P.prims_flat = ctx->d_prims_flat.as<DPrimFlat>();
     }
