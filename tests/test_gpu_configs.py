@@ -1,0 +1,85 @@
+"""BASELINE.json configs 3, 4 (one GPU's share) and 5 at their full sizes: size-independent properties only
+(the oracle cannot follow at these sizes in seconds): unit luminance per mutation, counter identities, b = mean image
+luminance after develop, finite non-negative film, states inside [0,1]."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+LUMW = np.array([0.212671, 0.715160, 0.072169])
+
+
+def lum(img):
+    return img @ LUMW
+
+
+def check_invariants(ctx, M, b, amap=False):
+    st = ctx.stats()
+    assert st.mutations == M
+    assert st.first_base == M and st.large_base + st.bold_base == M
+    assert st.second_base == st.bold_base - st.bold_acc
+    assert st.overall_base == M + st.second_base and st.overall_acc == st.first_acc + st.second_acc == st.accepted
+    assert abs(st.large_base / M - 0.3) < 3e-3
+    film = ctx.film()
+    assert np.all(np.isfinite(film)) and film.min() >= 0
+    if not amap:
+        assert lum(film.astype(np.float64)).sum() == pytest.approx(M * 0.99998 ** 2, rel=3e-3)
+        img = ctx.develop()
+        assert lum(img.astype(np.float64)).mean() == pytest.approx(b, rel=2e-3)
+    return st, film
+
+
+def test_config3_door_green_full_size(pkg, native_lib):
+    """Veach-door-style scene, glossy floor, technique=path type=green (Green's reverse evaluations counted)."""
+    sd = pkg.scenes.door_c3(512)
+    n = 65536
+    cfg = pkg.abi.make_config(technique="path", type="green", max_depth=8, rr_depth=5, direct_samples=-1, work_units=n,
+                              luminance_samples=655360, sample_count=64)
+    ctx = pkg.Context(cfg, sd)
+    b = ctx.seed(0x5EED)
+    M = 512 * 512 * 32
+    ctx.run(M)
+    st, _ = check_invariants(ctx, M, b)
+    assert M + st.second_base <= st.path_evals <= M + 2 * st.second_base      # + one reverse evaluation per valid second stage
+    cur, u = ctx.chain_state(34)
+    assert np.all((u >= 0) & (u <= 1)) and np.all(cur["luminance"] > 0)
+
+
+def test_config4_one_gpu_share_2048(pkg, native_lib):
+    """Cornell 2048 x 2048, one GPU's share of the 8-GPU render: 65 536 chains, (2048^2 * 64) / 8 mutations."""
+    sd = pkg.scenes.cornell_c2(2048)
+    n = 65536
+    cfg = pkg.abi.make_config(technique="path", type="orbital", max_depth=8, rr_depth=5, direct_samples=-1, work_units=n,
+                              luminance_samples=655360, sample_count=64)
+    ctx = pkg.Context(cfg, sd)
+    b = ctx.seed(0x5EED, chain_offset=3 * n)                                   # rank 3 of 8: its own chain ids and bootstrap stream
+    M = 2048 * 2048 * 64 // 8 // n * n
+    ctx.run(M)
+    check_invariants(ctx, M, b)
+    assert ctx.film().shape == (2048, 2048, 3)
+
+
+def test_config5_caustic_mmlt_full_size(pkg, native_lib):
+    """Glass caustic, mmlt / orbital / fixEmitterPath / acceptanceMap at 512 x 512 with 65 536 chains."""
+    sd = pkg.scenes.glass_sphere(512)
+    n = 65536
+    cfg = pkg.abi.make_config(technique="mmlt", type="orbital", max_depth=6, direct_samples=-1, fix_emitter_path=1,
+                              acceptance_map=1, work_units=n, sample_count=64, luminance_samples=100000)
+    ctx = pkg.Context(cfg, sd)
+    assert ctx.seed(0x5EED) == 1.0
+    M = 512 * 512 * 64
+    ctx.run(M)
+    st, film = check_invariants(ctx, M, 1.0, amap=True)
+    f = film.astype(np.float64)
+    assert f[..., 2].max() == 0
+    assert f[..., 0].sum() == pytest.approx(st.bold_acc, rel=1e-3) and f[..., 1].sum() == pytest.approx(st.second_acc, rel=1e-3)
+    heat = pkg.heatmap.stage_ratio(film)
+    assert 0.05 < heat[f[..., :2].sum(-1) > 20].mean() < 0.6
+    cur, u = ctx.chain_state(27)
+    assert set(np.unique(cur["n_dims"])) <= set(range(2, 7)) and np.all((u >= 0) & (u <= 1))
+    # same configuration, radiance output: b is the mean image luminance
+    cfg2 = pkg.abi.make_config(technique="mmlt", type="orbital", max_depth=6, direct_samples=-1, fix_emitter_path=1,
+                               work_units=n, sample_count=16, luminance_samples=100000)
+    ctx2 = pkg.Context(cfg2, sd)
+    b = ctx2.seed(0x5EED)
+    ctx2.run(512 * 512 * 16)
+    check_invariants(ctx2, 512 * 512 * 16, b)
