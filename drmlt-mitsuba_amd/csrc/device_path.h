@@ -847,8 +847,47 @@ DEV void path_step(const DParams &P, const TablesT &T, PathState &ps, SamplerT &
     ps.nrays++;
 }
 
+// PSSMLTSampler (src/integrators/pssmlt/pssmlt_sampler.cpp:93-168, pssmlt_sampler.h:113-143) as a pure function of the
+// addressed stream: at the first primarySample of a mutation the reference rewrites the whole vector in order --
+// components that already exist are mutated (Kelemen: one draw, toroidal wrap; Gaussian: two draws, modulo 1) or
+// redrawn (large step: one draw), components that do not exist yet (beyond what the seed path consumed; only possible
+// in a chain's first mutation) are appended as fresh uniforms (one draw) and survive a rejection.
+struct PssmltSampler {
+    uint32_t key0, key1, chain, major;
+    bool large, kelemen;
+    float sigma;
+    uint32_t lane;
+    uint32_t n_exist; // components that exist before this mutation
+    u4 b1;
+    uint32_t b1_idx;
+    DEV void reset_caches() { b1_idx = 0xffffffffu; }
+    DEV float u_s1(uint32_t idx) {
+        uint32_t blk = idx >> 2;
+        if (blk != b1_idx) { b1 = philox4x32_10(key0, key1, blk, major, chain, TAG_S1); b1_idx = blk; }
+        return pick4(b1, idx & 3u);
+    }
+    DEV float x(uint32_t k) const { return lds_x[k * 64u + lane]; }
+    DEV float next(uint32_t k) {
+        const uint32_t per = (large || kelemen) ? 1u : 2u; // draws taken by an existing component
+        if (k >= n_exist) return u_s1(per * n_exist + (k - n_exist));
+        if (large) return u_s1(k);
+        float value = x(k);
+        if (kelemen) {
+            float xi = u_s1(k);
+            const bool add = xi < 0.5f;
+            xi = add ? 2.f * xi : 2.f * (xi - 0.5f);
+            const float dv = KELEMEN_S2 * fast_exp2(xi * LOG2_S1_OVER_S2);
+            if (add) { value += dv; if (value > 1.f) value -= 1.f; }
+            else { value -= dv; if (value < 0.f) value += 1.f; }
+            return value;
+        }
+        const float v = value + gaussian_sample(u_s1(2u * k), u_s1(2u * k + 1u), sigma);
+        return v - floorf(v); // math::modulo(v, 1)
+    }
+};
+
 // Run one full PSS evaluation (one wave-divergent loop; every step issues at most one ray query).
-DEV DSplat eval_path(const DParams &P, Sampler &smp, uint32_t &nrays, uint32_t &ndims) {
+template <class SamplerT> DEV DSplat eval_path(const DParams &P, SamplerT &smp, uint32_t &nrays, uint32_t &ndims) {
     PathState ps;
     smp.reset_caches();
     path_init(P, ps);

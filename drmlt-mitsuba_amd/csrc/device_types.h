@@ -117,6 +117,9 @@ struct DParams {
     // flat-primitive fast path of the brute-force ray loop (device_path.h: trace_flat)
     const DPrimFlat *prims_flat; // n_flat records + 2 sentinels that no ray can hit, or NULL (BVH scenes)
     int32_t has_plain_tri;       // any PRIM_TRIANGLE record (needs the u + v <= 1 test)
+    // algo=pssmlt (kernels.hip: k_mutate_pssmlt)
+    int32_t kelemen_weights, kelemen_mutation; // "kelemenStyleWeights" (pssmlt_proc.cpp:197-203), Kelemen (1) or Gaussian (0) mutation
+    float pss_sigma, luminance_b;              // Gaussian mutation size; b of the Kelemen weights
     int32_t n_flat;              // records [0, n_flat) of `prims` are flat (and mirrored in prims_flat), [n_flat, n_prims) are spheres
 };
 

@@ -21,6 +21,7 @@
 void launch_bootstrap(const DParams &P, uint32_t n, float *lum_out, hipStream_t st);
 void launch_init_chains(const DParams &P, const uint32_t *seed_index, const float *seed_lum, hipStream_t st);
 void launch_mutate(const DParams &P, uint32_t n_mut, uint32_t mut_base, hipStream_t st);
+void launch_mutate_pssmlt(const DParams &P, uint32_t n_mut, uint32_t mut_base, hipStream_t st);
 void launch_eval_paths(const DParams &P, const float *u, uint32_t n, uint32_t dim, float *out8, hipStream_t st);
 // technique=mmlt (kernels_mmlt.hip)
 void launch_bootstrap_mmlt(const DParams &P, uint32_t n, float *lum_out, hipStream_t st);
@@ -341,7 +342,9 @@ drmlt_ctx *drmlt_create(const drmlt_config *cfg, const drmlt_scene *scene, int d
     if (cfg->struct_size != sizeof(drmlt_config) || scene->struct_size != sizeof(drmlt_scene))
         return bail(nullptr, "struct_size mismatch (ABI version skew)");
     // ---- parameter checks of the DRMLT ctor / PathSampler ctor (drmlt.cpp:193-349, pathsampler.cpp:57-71)
-    if (cfg->algo != DRMLT_ALGO_DRMLT) return bail(nullptr, "algo: only the drmlt chain loop runs on the device (pssmlt is config 1, CPU reference only)");
+    if (cfg->algo != DRMLT_ALGO_DRMLT && cfg->algo != DRMLT_ALGO_PSSMLT) return bail(nullptr, "Unknown algorithm");
+    if (cfg->algo == DRMLT_ALGO_PSSMLT && cfg->technique != DRMLT_TECH_PATH)
+        return bail(nullptr, "algo=pssmlt runs over technique=path on the device (BASELINE config 1)");
     if (cfg->technique != DRMLT_TECH_PATH && cfg->technique != DRMLT_TECH_BDPT && cfg->technique != DRMLT_TECH_MMLT)
         return bail(nullptr, "Unknown technique type");
     if (cfg->type < DRMLT_TYPE_GREEN || cfg->type > DRMLT_TYPE_ORBITAL) return bail(nullptr, "Unknown implementation type");
@@ -463,6 +466,8 @@ drmlt_ctx *drmlt_create(const drmlt_config *cfg, const drmlt_scene *scene, int d
     P.eff_dim = std::min(P.max_dim, effective_dim_path(cfg->max_depth, cfg->rr_depth));
     P.p_large = cfg->p_large; P.sigma2 = cfg->scale_second * cfg->sigma;
     P.n_chains = ctx->n_chains;
+    P.kelemen_weights = cfg->kelemen_style_weights; P.kelemen_mutation = cfg->kelemen_style_mutation;
+    P.pss_sigma = cfg->sigma; P.luminance_b = 1.f;
     P.technique = cfg->technique; P.light_image = cfg->no_light_image ? 0 : 1; P.fix_emitter_path = cfg->fix_emitter_path;
     P.mmlt_S = P.mmlt_E = P.mmlt_dmax = 0;
     if (mmlt) { // PSS layout of a chain: [sensor S | emitter E | direct] (device_bidir.h)
@@ -716,7 +721,9 @@ int drmlt_run(drmlt_ctx *ctx, uint64_t total_mutations, volatile int *stop, drml
         HIP_TRY(ctx, hipEventCreate(&a));
         HIP_TRY(ctx, hipEventCreate(&b));
         HIP_TRY(ctx, hipEventRecord(a, ctx->stream));
-        if (ctx->cfg.technique == DRMLT_TECH_MMLT) launch_mutate_mmlt(ctx->P, n, ctx->mutation_base, ctx->stream);
+        ctx->P.luminance_b = (float) ctx->b;
+        if (ctx->cfg.algo == DRMLT_ALGO_PSSMLT) launch_mutate_pssmlt(ctx->P, n, ctx->mutation_base, ctx->stream);
+        else if (ctx->cfg.technique == DRMLT_TECH_MMLT) launch_mutate_mmlt(ctx->P, n, ctx->mutation_base, ctx->stream);
         else if (ctx->cfg.technique == DRMLT_TECH_BDPT) launch_mutate_bdpt(ctx->P, n, ctx->mutation_base, ctx->stream);
         else launch_mutate(ctx->P, n, ctx->mutation_base, ctx->stream);
         HIP_TRY(ctx, hipGetLastError());
@@ -790,7 +797,11 @@ int drmlt_stats_get(drmlt_ctx *ctx, drmlt_stats *o) {
     memset(o, 0, sizeof *o);
     const uint64_t M = ctx->mutations;
     const uint64_t n_large = v[0], acc1_l = v[1], acc1_b = v[2], sec_l = v[3], sec_b = v[4], acc2_l = v[5], acc2_b = v[6], n_rev = v[7];
-    if (!ctx->cfg.use_mixture) { // drmlt_proc.cpp:715-768
+    if (ctx->cfg.algo == DRMLT_ALGO_PSSMLT) { // pssmlt_proc.cpp:230-260: one acceptance test per mutation
+        o->overall_base = M;               o->overall_acc = acc1_l + acc1_b;
+        o->large_base = n_large;           o->large_acc = acc1_l;
+        o->bold_base = M - n_large;        o->bold_acc = acc1_b;
+    } else if (!ctx->cfg.use_mixture) { // drmlt_proc.cpp:715-768
         o->first_base = M;                 o->first_acc = acc1_l + acc1_b;
         o->large_base = n_large;           o->large_acc = acc1_l;
         o->bold_base = M - n_large;        o->bold_acc = acc1_b;

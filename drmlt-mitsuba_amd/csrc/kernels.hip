@@ -34,6 +34,7 @@ __global__ void __launch_bounds__(256) k_init_chains(DParams P, const uint32_t *
     normalize_splat(s, P);
     P.cur_lum[c] = s.lum; P.cur_px[c] = s.px; P.cur_py[c] = s.py;
     P.cur_r[c] = s.r; P.cur_g[c] = s.g; P.cur_b[c] = s.b;
+    P.chain_depth[c] = (int32_t) nd; // pssmlt: components that exist after the replay (no fillReplay there)
     // replayed components + fillReplay top-up: dimension k of bootstrap sample i is U(BOOT, i, k)
     smp.reset_caches();
     for (uint32_t k = 0; k < (uint32_t) P.eff_dim; ++k) P.x[(size_t) k * P.n_chains + c] = smp.u_boot(k, TAG_BOOT);
@@ -192,6 +193,85 @@ __global__ void __launch_bounds__(CHAIN_BLOCK) k_mutate(DParams P, uint32_t n_mu
     v[8] = wave_sum(ct.rays);
     if (lane == 0 && !(P.debug & 2))
         for (int i = 0; i < 9; ++i) atomicAdd(P.stats + i, v[i]);
+}
+
+// ------------------------------------------------------------------------------------------
+// k_mutate_pssmlt: PSSMLTRenderer::process (src/integrators/pssmlt/pssmlt_proc.cpp:113-297) over sampleSplats(path).
+// One proposal per mutation, Kelemen-style weights (with b and pLarge) or Veach's expectations, and the deferred splat
+// of the current state with its cumulative weight (:215-226,262-266). The cumulative weight is flushed at the end of
+// every launch (the reference does it once per work unit; splatting is linear, so the film is the same).
+__global__ void __launch_bounds__(CHAIN_BLOCK) k_mutate_pssmlt(DParams P, uint32_t n_mut, uint32_t mut_base) {
+    const uint32_t lane = threadIdx.x;
+    const uint32_t c = blockIdx.x * CHAIN_BLOCK + lane;
+    const bool live = c < P.n_chains;
+    const uint32_t cc = live ? c : P.n_chains - 1;
+    const int D = P.eff_dim;
+    for (int k = 0; k < D; ++k) lds_x[k * 64 + lane] = P.x[(size_t) k * P.n_chains + cc];
+    DSplat cur;
+    cur.lum = P.cur_lum[cc]; cur.px = P.cur_px[cc]; cur.py = P.cur_py[cc];
+    cur.r = P.cur_r[cc]; cur.g = P.cur_g[cc]; cur.b = P.cur_b[cc];
+    PssmltSampler smp;
+    smp.key0 = P.key0; smp.key1 = P.key1; smp.chain = P.chain_offset + cc;
+    smp.kelemen = P.kelemen_mutation != 0; smp.sigma = P.pss_sigma; smp.lane = lane;
+    smp.n_exist = mut_base == 0u ? (uint32_t) min(P.chain_depth[cc], D) : (uint32_t) D;
+    Counters ct = {0u, 0u, 0u, 0u, 0u};
+    float cumulative = 0.f;
+    const float b = P.luminance_b, pLarge = P.p_large;
+
+    if (live) for (uint32_t it = 0; it < n_mut; ++it) {
+        const uint32_t m = mut_base + it;
+        const u4 coins = philox4x32_10(P.key0, P.key1, 0u, m, smp.chain, TAG_COIN);
+        const bool large = u32_to_unit(coins.x) < pLarge;
+        smp.major = m; smp.large = large;
+        smp.reset_caches();
+        uint32_t nr, nd;
+        DSplat y = eval_path(P, smp, nr, nd);
+        ct.rays += nr;
+        normalize_splat(y, P);
+        float a = fminf(1.f, y.lum / cur.lum);
+        if (isnan(y.lum) || y.lum < 0.f) a = 0.f; // :188-191
+        bool accept = false;
+        float wc, wp = 0.f;
+        if (a > 0.f) {
+            if (P.kelemen_weights) { // :197-203
+                wc = (1.f - a) * cur.lum / (cur.lum / b + pLarge);
+                wp = (a + (large ? 1.f : 0.f)) * y.lum / (y.lum / b + pLarge);
+            } else {
+                wc = 1.f - a;
+                wp = a;
+            }
+            accept = a == 1.f || u32_to_unit(coins.y) < a;
+        } else {
+            wc = P.kelemen_weights ? cur.lum / (cur.lum / b + pLarge) : 1.f;
+        }
+        cumulative += wc;
+        if (large) ct.large_acc1l += 1u + (accept ? 1u << 16 : 0u);
+        else if (accept) ct.acc1b_secl += 1u;
+        // the whole vector was rewritten by the proposal; components that did not exist yet stay even on rejection
+        const uint32_t n_exist = smp.n_exist;
+        if (accept) {
+            film_put(P, cur.px, cur.py, mk3(cur.r * cumulative, cur.g * cumulative, cur.b * cumulative));
+            cumulative = wp;
+            for (int k = 0; k < D; ++k) lds_x[k * 64 + lane] = smp.next((uint32_t) k);
+            cur = y;
+        } else {
+            film_put(P, y.px, y.py, mk3(y.r * wp, y.g * wp, y.b * wp));
+            for (uint32_t k = n_exist; k < (uint32_t) D; ++k) lds_x[k * 64u + lane] = smp.next(k);
+        }
+        smp.n_exist = (uint32_t) D;
+    }
+    if (live) {
+        film_put(P, cur.px, cur.py, mk3(cur.r * cumulative, cur.g * cumulative, cur.b * cumulative)); // "Perform the last splat"
+        for (int k = 0; k < D; ++k) P.x[(size_t) k * P.n_chains + c] = lds_x[k * 64 + lane];
+        P.cur_lum[c] = cur.lum; P.cur_px[c] = cur.px; P.cur_py[c] = cur.py;
+        P.cur_r[c] = cur.r; P.cur_g[c] = cur.g; P.cur_b[c] = cur.b;
+    }
+    unsigned long long v[9];
+    v[0] = wave_sum(ct.large_acc1l & 0xffffu); v[1] = wave_sum(ct.large_acc1l >> 16);
+    v[2] = wave_sum(ct.acc1b_secl & 0xffffu);  v[3] = 0; v[4] = 0; v[5] = 0; v[6] = 0; v[7] = 0;
+    v[8] = wave_sum(ct.rays);
+    if (lane == 0)
+        for (int i = 0; i < 9; ++i) if (v[i]) atomicAdd(P.stats + i, v[i]);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -664,6 +744,10 @@ void launch_bootstrap(const DParams &P, uint32_t n, float *lum_out, hipStream_t 
 }
 void launch_init_chains(const DParams &P, const uint32_t *seed_index, const float *seed_lum, hipStream_t st) {
     hipLaunchKernelGGL(k_init_chains, dim3((P.n_chains + 255) / 256), dim3(256), 0, st, P, seed_index, seed_lum);
+}
+void launch_mutate_pssmlt(const DParams &P, uint32_t n_mut, uint32_t mut_base, hipStream_t st) {
+    hipLaunchKernelGGL(k_mutate_pssmlt, dim3((P.n_chains + CHAIN_BLOCK - 1) / CHAIN_BLOCK), dim3(CHAIN_BLOCK), (size_t) P.eff_dim * 64 * sizeof(float), st, P,
+                       n_mut, mut_base);
 }
 void launch_mutate(const DParams &P, uint32_t n_mut, uint32_t mut_base, hipStream_t st) {
     const size_t D = (size_t) P.eff_dim, D4 = (D + 3) & ~(size_t) 3;
