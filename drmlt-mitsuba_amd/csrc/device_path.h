@@ -24,7 +24,9 @@ extern __shared__ __attribute__((aligned(16))) float lds_x[];
 // ------------------------------------------------------------------ PSS sampler
 enum { SM_BOOT = 0, SM_ARRAY = 1, SM_STAGE1 = 2, SM_STAGE2 = 3, SM_REVERSE = 4, SM_PT = 5 };
 
-DEV float wrap01(float y) { return y > 1.f ? 2.f - y : (y <= 0.f ? fabsf(y) : y); } // drmlt_sampler.h:140-144
+// drmlt_sampler.h:140-144: y > 1 ? 2 - y : (y <= 0 ? |y| : y). For 0 < y <= 1, |y| = y, so two selects collapse into
+// one select on an |.|-modified operand (the nested form compiled to two exec-mask branches per component).
+DEV float wrap01(float y) { return y > 1.f ? 2.f - y : fabsf(y); }
 
 #define KELEMEN_S1 (1.0f / 1024.0f)
 #define KELEMEN_S2 (1.0f / 64.0f)
@@ -233,6 +235,23 @@ struct LdsSampler {
         if (mode == SM_STAGE2) return wrap01(z_raw(k));
         float du = y_raw(k) - x(k); // Green reverse: y* = z - (y - x)
         return wrap01(z_raw(k) - du);
+    }
+    // Orbital pair (k0, k0 + 1), both components of the first- or second-stage proposal at once (accept(): the
+    // per-component form above evaluates the shared radius / angle / rotation twice per pair). Same arithmetic.
+    DEV void orbital_pair(uint32_t k0, bool second, float &o0, float &o1) const {
+        const float x0 = x(k0), x1 = x(k0 + 1u);
+        const float d = kelemen_sample(u1(k0), KELEMEN_S2 * ORBITAL_SCALE), a = u1(k0 + 1u);
+        const float y0 = fmaf(d, cos_rev(a), x0), y1 = fmaf(d, sin_rev(a), x1);
+        if (!second) { o0 = y0; o1 = y1; return; }
+        float xi = s2(k0 >> 1);
+        float sign = 1.f;
+        if (xi < 0.5f) { xi *= 2.f; } else { sign = -1.f; xi = 2.f * (xi - 0.5f); }
+        const float V = cos_rev(xi);
+        const float A = fminf(1.f, fmaxf(-1.f, (V + WC_DISPERSION) / (1.f + WC_DISPERSION * V)));
+        const float ct = A, st = sign * sqrtf(fmaxf(0.f, 1.f - A * A));
+        const float dx0 = x0 - y0, dx1 = x1 - y1;
+        o0 = y0 + (ct * dx0 - st * dx1);
+        o1 = y1 + (st * dx0 + ct * dx1);
     }
 };
 

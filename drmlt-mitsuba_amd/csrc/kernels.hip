@@ -415,6 +415,15 @@ DEV int mh_decide(const DParams &P, ChainState &cs, LdsSampler &smp, PathState &
 // DRMLTSampler::accept for dimensions [k0, k1): uCurrent = wrap(chosen proposal)
 DEV void commit_range(LdsSampler &smp, int commit_mode, uint32_t k0, uint32_t k1) {
     smp.mode = commit_mode;
+    if (smp.type == 2 && !smp.large && !(k0 & 1u) && !(k1 & 1u)) { // orbital small step: pair by pair (k0, k1 are pair-aligned)
+        for (uint32_t k = k0; k < k1; k += 2u) {
+            float v0, v1;
+            smp.orbital_pair(k, commit_mode == SM_STAGE2, v0, v1);
+            lds_x[k * smp.stride + smp.lane] = wrap01(v0);
+            lds_x[(k + 1u) * smp.stride + smp.lane] = wrap01(v1);
+        }
+        return;
+    }
     for (uint32_t k = k0; k < k1; ++k) lds_x[k * smp.stride + smp.lane] = smp.next(k);
 }
 
@@ -609,6 +618,7 @@ __global__ void __launch_bounds__(CHAIN_BLOCK) k_mutate_v3(DParams P, uint32_t n
 
     const bool stamps = (P.debug & 128) != 0;
     unsigned long long t_mh = 0, t_trace = 0, t_step = 0, n_iter = 0, n_mh = 0, n_busy = 0;
+    unsigned long long t_decide = 0, t_commit = 0, t_start = 0, t_fill = 0;
 #define STAMP() (stamps ? __builtin_amdgcn_s_memtime() : 0ull)
     for (;;) {
         const bool parked = ps.phase == PH_DONE;
@@ -621,6 +631,7 @@ __global__ void __launch_bounds__(CHAIN_BLOCK) k_mutate_v3(DParams P, uint32_t n
             // decide (chain lanes) -> commit (both lanes of a pair) -> start (chain lanes) -> draw (both lanes)
             int commit = 0;
             if (parked) commit = mh_decide(P, cs, smp, ps, ct);
+            const unsigned long long m1 = STAMP();
             const int commit_pair = (int) from_lower_u((unsigned) commit);
             const uint32_t maj_c = from_lower_u(smp.major);
             const bool large_c = from_lower_u(smp.large ? 1u : 0u) != 0u;
@@ -629,8 +640,10 @@ __global__ void __launch_bounds__(CHAIN_BLOCK) k_mutate_v3(DParams P, uint32_t n
                 const uint32_t split = (((uint32_t) D / 2u) + 1u) & ~1u;
                 commit_range(smp, commit_pair, helper ? split : 0u, helper ? (uint32_t) D : split);
             }
+            const unsigned long long m2 = STAMP();
             int fill = 0;
             if (parked) fill = mh_start(P, cs, smp, ps, n_mut, mut_base);
+            const unsigned long long m3 = STAMP();
             const int fill_pair = (int) from_lower_u((unsigned) fill);
             const uint32_t maj_f = from_lower_u(smp.major);
             const bool large_f = from_lower_u(smp.large ? 1u : 0u) != 0u;
@@ -641,6 +654,8 @@ __global__ void __launch_bounds__(CHAIN_BLOCK) k_mutate_v3(DParams P, uint32_t n
             } else if (fill_pair == 2) {
                 smp.fill_stage2(D4, helper ? 1u : 0u, 2u);
             }
+            const unsigned long long m4 = STAMP();
+            t_decide += m1 - s0; t_commit += m2 - m1; t_start += m3 - m2; t_fill += m4 - m3;
         }
         // one ray per lane: chain lanes their camera / bounce ray, helpers the shadow ray they were handed
         const unsigned long long s1 = STAMP();
@@ -672,6 +687,7 @@ __global__ void __launch_bounds__(CHAIN_BLOCK) k_mutate_v3(DParams P, uint32_t n
     if (stamps && lane == 0) {
         atomicAdd(P.stats + 16, t_mh); atomicAdd(P.stats + 17, t_trace); atomicAdd(P.stats + 18, t_step);
         atomicAdd(P.stats + 19, n_iter); atomicAdd(P.stats + 20, n_mh); atomicAdd(P.stats + 21, n_busy);
+        atomicAdd(P.stats + 22, t_decide); atomicAdd(P.stats + 23, t_commit); atomicAdd(P.stats + 24, t_start); atomicAdd(P.stats + 25, t_fill);
     }
 
     if (live) {
