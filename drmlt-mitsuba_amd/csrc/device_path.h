@@ -212,7 +212,7 @@ struct LdsSampler {
         if (type != 2) return x(k) + kelemen_sample(u1(k), KELEMEN_S2);
         const uint32_t k0 = k & ~1u;
         float d = kelemen_sample(u1(k0), KELEMEN_S2 * ORBITAL_SCALE), a = u1(k0 + 1u);
-        return fmaf(d, (k & 1u) ? sin_rev(a) : cos_rev(a), x(k));
+        return fmaf(d, cos_rev(a - ((k & 1u) ? 0.25f : 0.f)), x(k));
     }
     DEV float z_raw(uint32_t k) const {
         if (large) return s2(k);
@@ -220,7 +220,7 @@ struct LdsSampler {
         const uint32_t k0 = k & ~1u;
         float x0 = x(k0), x1 = x(k0 + 1u);
         float d = kelemen_sample(u1(k0), KELEMEN_S2 * ORBITAL_SCALE), a = u1(k0 + 1u);
-        float y0 = fmaf(d, cos_rev(a), x0), y1 = fmaf(d, sin_rev(a), x1);
+        float y0 = fmaf(d, cos_rev(a), x0), y1 = fmaf(d, cos_rev(a - 0.25f), x1);
         float xi = s2(k0 >> 1);
         float sign = 1.f;
         if (xi < 0.5f) { xi *= 2.f; } else { sign = -1.f; xi = 2.f * (xi - 0.5f); }
@@ -231,6 +231,16 @@ struct LdsSampler {
         return (k & 1u) ? y1 + (st * dx0 + ct * dx1) : y0 + (ct * dx0 - st * dx1);
     }
     DEV float next(uint32_t k) const {
+        if (type == 2 && mode == SM_STAGE1) {
+            // The common case (orbital, first stage) without divergent branches: unconditional LDS reads, the
+            // large-step case as a select, sin(2 pi a) as cos(2 pi (a - 1/4)) so that one v_cos serves both components.
+            const uint32_t k0 = k & ~1u;
+            const bool odd = (k & 1u) != 0u;
+            const float ua = u1(k0), ub = u1(k0 + 1u);
+            const float d = kelemen_sample(ua, KELEMEN_S2 * ORBITAL_SCALE);
+            const float y = fmaf(d, cos_rev(ub - (odd ? 0.25f : 0.f)), x(k));
+            return wrap01(large ? (odd ? ub : ua) : y);
+        }
         if (mode == SM_STAGE1) return wrap01(y_raw(k));
         if (mode == SM_STAGE2) return wrap01(z_raw(k));
         float du = y_raw(k) - x(k); // Green reverse: y* = z - (y - x)
@@ -241,7 +251,7 @@ struct LdsSampler {
     DEV void orbital_pair(uint32_t k0, bool second, float &o0, float &o1) const {
         const float x0 = x(k0), x1 = x(k0 + 1u);
         const float d = kelemen_sample(u1(k0), KELEMEN_S2 * ORBITAL_SCALE), a = u1(k0 + 1u);
-        const float y0 = fmaf(d, cos_rev(a), x0), y1 = fmaf(d, sin_rev(a), x1);
+        const float y0 = fmaf(d, cos_rev(a), x0), y1 = fmaf(d, cos_rev(a - 0.25f), x1);
         if (!second) { o0 = y0; o1 = y1; return; }
         float xi = s2(k0 >> 1);
         float sign = 1.f;
