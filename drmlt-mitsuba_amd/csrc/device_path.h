@@ -598,10 +598,11 @@ DEV float ray_eps_shadow(f3 o) { // skdtree.cpp:213-218
 // warp.cpp:81-102 + :43-52 (angles expressed in revolutions for v_sin/v_cos)
 DEV f3 square_to_cosine_hemisphere(float sx, float sy) {
     float r1 = 2.f * sx - 1.f, r2 = 2.f * sy - 1.f;
-    float r, rev;
-    if (r1 == 0.f && r2 == 0.f) { r = 0.f; rev = 0.f; }
-    else if (r1 * r1 > r2 * r2) { r = r1; rev = 0.125f * (r2 / r1); }
-    else { r = r2; rev = 0.25f - 0.125f * (r1 / r2); }
+    // selects instead of the three-way branch: num / den = r2 / r1 or r1 / r2, whichever has the larger denominator
+    const bool first = r1 * r1 > r2 * r2;
+    const float num = first ? r2 : r1, den = first ? r1 : r2;
+    const float q = den != 0.f ? 0.125f * (num / den) : 0.f; // den == 0 only for r1 == r2 == 0: r = 0, angle irrelevant
+    const float r = den, rev = first ? q : 0.25f - q;
     float px = r * cos_rev(rev), py = r * sin_rev(rev);
     float z = sqrtf(fmaxf(0.f, 1.f - px * px - py * py));
     if (z == 0.f) z = 1e-10f;

@@ -375,19 +375,22 @@ DEV int mh_decide(const DParams &P, ChainState &cs, LdsSampler &smp, PathState &
         decided = true;
     }
     if (!decided) return 0;
-    const DSplat &cur = cs.cur, &y = cs.y, &z = cs.z;
-    if (!mix) {
-        float w1 = cs.a1, w2 = (1.f - cs.a1) * a2, w0 = 1.f - w1 - w2;
-        if (!amap) {
-            if (w0 > 0.f) film_put(P, cur.px, cur.py, mk3(cur.r * w0, cur.g * w0, cur.b * w0));
-            if (w1 > 0.f) film_put(P, y.px, y.py, mk3(y.r * w1, y.g * w1, y.b * w1));
-            if (cs.do_second && w2 > 0.f) film_put(P, z.px, z.py, mk3(z.r * w2, z.g * w2, z.b * w2));
-        }
-    } else {
+    // splats of this mutation through ONE film_put site (the call expands to ~150 instructions; six inlined copies
+    // of it were a sixth of the kernel's code): slot 0 current state, 1 first-stage, 2 second-stage proposal
+    float w0, w1, w2;
+    if (!mix) { // expectation weights, drmlt_proc.cpp:677-688
+        w1 = cs.a1; w2 = (1.f - cs.a1) * a2; w0 = 1.f - w1 - w2;
+        if (!cs.do_second) w2 = 0.f;
+        if (amap) w0 = w1 = w2 = 0.f;
+    } else { // processMixture, :327-333: a = acceptance of whichever proposal was tested
         const float a = cs.do_second ? a2 : cs.a1;
-        const DSplat pr = select_splat(cs.do_second, z, y);
-        if (1.f - a > 0.f) film_put(P, cur.px, cur.py, mk3(cur.r * (1.f - a), cur.g * (1.f - a), cur.b * (1.f - a)));
-        if (a > 0.f) film_put(P, pr.px, pr.py, mk3(pr.r * a, pr.g * a, pr.b * a));
+        w0 = 1.f - a; w1 = cs.do_second ? 0.f : a; w2 = cs.do_second ? a : 0.f;
+    }
+#pragma nounroll
+    for (int i = 0; i < 3; ++i) {
+        const float w = i == 0 ? w0 : (i == 1 ? w1 : w2);
+        const DSplat sp = select_splat(i == 0, cs.cur, select_splat(i == 1, cs.y, cs.z));
+        if (w > 0.f) film_put(P, sp.px, sp.py, mk3(sp.r * w, sp.g * w, sp.b * w));
     }
     if (cs.large) {
         ct.large_acc1l += 1u + (acc1 ? 1u << 16 : 0u);
