@@ -6,7 +6,9 @@ tag=$1; shift
 i=0
 for grp in "$@"; do
   out=$GRAFT_REPO_ROOT/gpurun_out/pmc_${tag}_$i
-  rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $out -- python3 $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 0 --spp 64 --no-cpu-baseline --no-quality > $out.log 2>&1 || { tail -5 $out.log; exit 1; }
+  echo "pass $i: $grp" >> $GRAFT_REPO_ROOT/gpurun_out/pmc_${tag}_progress.txt
+  # a counter group the hardware cannot collect in one pass aborts rocprofv3 and can leave the child hanging: bound it
+  timeout -k 10 180 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $out -- python3 $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 0 --spp 64 --no-cpu-baseline --no-quality > $out.log 2>&1 || { tail -5 $out.log; exit 1; }
   i=$((i+1))
 done
 python3 - <<PY
