@@ -241,6 +241,14 @@ struct LdsSampler {
             const float y = fmaf(d, cos_rev(ub - (odd ? 0.25f : 0.f)), x(k));
             return wrap01(large ? (odd ? ub : ua) : y);
         }
+        if (type == 2) {
+            // orbital second stage (the reverse mode belongs to Green and never gets here): the pair once, the
+            // large-step case (timidAfterLarge) as a select on an unconditional read
+            float z0, z1;
+            orbital_pair(k & ~1u, true, z0, z1);
+            const float zl = s2(k);
+            return wrap01(large ? zl : ((k & 1u) ? z1 : z0));
+        }
         if (mode == SM_STAGE1) return wrap01(y_raw(k));
         if (mode == SM_STAGE2) return wrap01(z_raw(k));
         float du = y_raw(k) - x(k); // Green reverse: y* = z - (y - x)
