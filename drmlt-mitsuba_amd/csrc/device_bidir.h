@@ -323,10 +323,14 @@ DEV void eval_mmlt(const DParams &P, const TablesT &T, MSampler &smp, int depth,
             const DShade L = T.shade(E.prim);
             f3 lp;
             if ((L.bsdf >> 24) == PRIM_RECTANGLE) lp = fma3(ld3(L.eu), sx, fma3(ld3(L.ev), u1, ld3(L.origin)));
-            else { float a = sqrtf(fmaxf(0.f, 1.f - sx)); lp = fma3(ld3(L.eu), 1.f - a, fma3(ld3(L.ev), a * u1, ld3(L.origin))); }
+            else if ((L.bsdf >> 24) == PRIM_SPHERE) { // sphere.cpp:257-268: uniform on the sphere
+                const float z = 1.f - 2.f * u1, r = sqrtf(fmaxf(0.f, 1.f - z * z));
+                lp = mk3(r * cos_rev(sx), r * sin_rev(sx), z); // unit normal for now, scaled below
+            } else { float a = sqrtf(fmaxf(0.f, 1.f - sx)); lp = fma3(ld3(L.eu), 1.f - a, fma3(ld3(L.ev), a * u1, ld3(L.origin))); }
             pImp(1) = L.inv_area * emPdf;
             thr = thr * (ld3(E.radiance) * (PI_F / (L.inv_area * emPdf))); // m_power / emitter pdf (area.cpp:96-101)
-            cur.kind = BK_END_E; cur.p = lp; cur.n = ld3(L.n); cur.emitter = ei; cur.shade = E.prim; cur.degenerate = false; cur.e_len2 = 0.f;
+            const bool sph = (L.bsdf >> 24) == PRIM_SPHERE;
+            cur.kind = BK_END_E; cur.n = sph ? lp : ld3(L.n); cur.p = sph ? fma3(lp, L.eu[0], ld3(L.origin)) : lp; cur.emitter = ei; cur.shade = E.prim; cur.degenerate = false; cur.e_len2 = 0.f;
             pos = npos;
             continue;
         }

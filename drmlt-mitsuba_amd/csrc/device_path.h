@@ -603,6 +603,55 @@ DEV float ray_eps_shadow(f3 o) { // skdtree.cpp:213-218
     return EPSILON_F * fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fabsf(o.z));
 }
 
+// Sphere as an area light seen from `ref` (sphere.cpp:286-385): uniform sampling of the cone it subtends when the
+// reference point is outside, uniform area sampling otherwise. Outputs direction, distance, surface normal, solid-angle pdf.
+DEV void sphere_sample_direct(f3 c, float radius, float inv_area, f3 ref, float sx, float sy, f3 &d, float &dist, f3 &n, float &pdf) {
+    const f3 rc = c - ref;
+    const float refDist2 = dot3(rc, rc);
+    const float invRefDist = rsqrtf(refDist2);
+    const float sinAlpha = radius * invRefDist;
+    if (sinAlpha < 1.f - EPSILON_F) {
+        const float cosAlpha = sqrtf(fmaxf(0.f, 1.f - sinAlpha * sinAlpha));
+        const float cosTheta = (1.f - sx) + sx * cosAlpha, sinTheta = sqrtf(fmaxf(0.f, 1.f - cosTheta * cosTheta));
+        const f3 fn = rc * invRefDist;
+        f3 fs, ft; // Frame(n): coordinateSystem (util.cpp:606-616)
+        if (fabsf(fn.x) > fabsf(fn.y)) { float inv = rsqrtf(fn.x * fn.x + fn.z * fn.z); ft = mk3(fn.z * inv, 0.f, -fn.x * inv); }
+        else { float inv = rsqrtf(fn.y * fn.y + fn.z * fn.z); ft = mk3(0.f, fn.z * inv, -fn.y * inv); }
+        fs = cross3(ft, fn);
+        d = fma3(fs, cos_rev(sy) * sinTheta, fma3(ft, sin_rev(sy) * sinTheta, fn * cosTheta));
+        pdf = 0.15915494309189535f / (1.f - cosAlpha);
+        const float projDist = dot3(rc, d);
+        const float baseT = refDist2 / projDist;
+        const f3 qc = c - fma3(d, baseT, ref);
+        const float queryDist2 = dot3(qc, qc), queryProjDist = dot3(qc, d);
+        // solveQuadratic(1, -2 queryProjDist, queryDist2 - r^2), util.cpp:447-485
+        const float B = -2.f * queryProjDist, C = queryDist2 - radius * radius;
+        const float discrim = B * B - 4.f * C;
+        float nearT = queryProjDist;
+        if (discrim >= 0.f) {
+            const float sq = sqrtf(discrim);
+            const float temp = B < 0.f ? -0.5f * (B - sq) : -0.5f * (B + sq);
+            nearT = fminf(temp, C / temp);
+        }
+        dist = baseT + nearT;
+        n = normalize3(d * nearT - qc);
+    } else {
+        const float z = 1.f - 2.f * sy, r = sqrtf(fmaxf(0.f, 1.f - z * z));
+        n = mk3(r * cos_rev(sx), r * sin_rev(sx), z);
+        const f3 dv = fma3(n, radius, c) - ref;
+        const float dist2 = dot3(dv, dv);
+        dist = sqrtf(dist2);
+        d = dv * (1.f / dist);
+        pdf = inv_area * dist2 / fabsf(dot3(d, n));
+    }
+}
+DEV float sphere_pdf_direct(f3 c, float radius, float inv_area, f3 ref, float dist, float cos_light) { // sphere.cpp:357-385
+    const f3 rc = c - ref;
+    const float sinAlpha = radius * rsqrtf(dot3(rc, rc));
+    if (sinAlpha < 1.f - EPSILON_F) return 0.15915494309189535f / (1.f - sqrtf(fmaxf(0.f, 1.f - sinAlpha * sinAlpha)));
+    return inv_area * dist * dist / cos_light;
+}
+
 // warp.cpp:81-102 + :43-52 (angles expressed in revolutions for v_sin/v_cos)
 DEV f3 square_to_cosine_hemisphere(float sx, float sy) {
     float r1 = 2.f * sx - 1.f, r2 = 2.f * sy - 1.f;
@@ -706,7 +755,11 @@ DEV void path_step(const DParams &P, const TablesT &T, PathState &ps, SamplerT &
                     float lumPdf = 0.f;
                     if (!ps.bdelta) { // pdfEmitterDirect: refN belongs to the PREVIOUS vertex (ps.n) or is 0
                         float dr = ps.refn_zero ? 0.f : dot3(ps.d, ps.n);
-                        if (dr >= 0.f) lumPdf = S.inv_area * hit.t * hit.t / fabsf(dn) * (E.cdf_hi - E.cdf_lo);
+                        if (dr >= 0.f) {
+                            lumPdf = S.inv_area * hit.t * hit.t / fabsf(dn);
+                            if ((FEAT & 4) && ptype == PRIM_SPHERE) lumPdf = sphere_pdf_direct(ld3(S.origin), S.eu[0], S.inv_area, ps.o, hit.t, fabsf(dn));
+                            lumPdf *= E.cdf_hi - E.cdf_lo;
+                        }
                     }
                     float a = ps.bpdf * ps.bpdf, b = lumPdf * lumPdf;
                     ps.Li = fma3(ps.thr * ld3(E.radiance), a / (a + b), ps.Li);
@@ -795,6 +848,8 @@ DEV void path_step(const DParams &P, const TablesT &T, PathState &ps, SamplerT &
             f3 dd = dv * (1.f / dist);
             float dln = dot3(dd, ln);
             float pdf = dln != 0.f ? L.inv_area * dist2 / fabsf(dln) : 0.f; // Shape::sampleDirect
+            if ((FEAT & 4) && (L.bsdf >> 24) == PRIM_SPHERE) // sphere light: cone sampling, sphere.cpp:286-355
+                sphere_sample_direct(ld3(L.origin), L.eu[0], L.inv_area, p, sx, sy, dd, dist, ln, pdf), dln = dot3(dd, ln);
             float dr = ps.refn_zero ? 0.f : dot3(dd, n);
             if (dr >= 0.f && dln < 0.f && pdf != 0.f) { // AreaLight::sampleDirect
                 f3 wo = mk3(dot3(dd, s), dot3(dd, t), dot3(dd, n));

@@ -200,7 +200,6 @@ std::string build_scene(drmlt_ctx *ctx, const drmlt_scene &s, std::vector<DBsdf>
         } else if (in.type == DRMLT_SHAPE_SPHERE) {
             double r = in.data[3];
             if (!(r > 0)) return "sphere: radius must be positive";
-            if (in.emitter >= 0) return "sphere emitters are not supported yet";
             for (int k = 0; k < 12; ++k) inv[k] = 0;
             for (int k = 0; k < 3; ++k) { inv[k * 4 + k] = 1.0 / r; inv[k * 4 + 3] = -(double) in.data[k] / r; }
             g.type = PRIM_SPHERE;

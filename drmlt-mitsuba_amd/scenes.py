@@ -118,11 +118,11 @@ class SceneData:
         self.shapes.append(s)
         return len(self.shapes) - 1
 
-    def sphere(self, center, radius, bsdf):
+    def sphere(self, center, radius, bsdf, radiance=None):
         s = abi.Shape()
         s.type = abi.SHAPE_SPHERE
         s.bsdf = bsdf
-        s.emitter = -1
+        s.emitter = self._emit(radiance) if radiance is not None else -1
         s.data[:4] = list(center) + [radius]
         self.shapes.append(s)
         return len(self.shapes) - 1
@@ -266,5 +266,23 @@ def triangle_soup(n_tris=2000, res=128, seed=7):
     return sd
 
 
+def caustic_c5(res=128):
+    """SURVEY 8(d) C5 with the small SPHERE area light (the reference rejects point lights under mmlt, A11):
+    dielectric sphere (eta 1.5, r 0.3) above the diffuse floor, emissive sphere r 0.06 under the ceiling, and a
+    second, dimmer quad light so that emitter selection is exercised."""
+    sd = SceneData("caustic_c5")
+    white = sd.diffuse(0.725, 0.71, 0.68)
+    red = sd.diffuse(0.63, 0.065, 0.05)
+    green = sd.diffuse(0.14, 0.45, 0.091)
+    black = sd.diffuse(0.0)
+    glass = sd.dielectric(1.5, 1.0)
+    _room(sd, white, red, green)
+    sd.sphere((0.0, -0.55, 0.1), 0.3, glass)
+    sd.sphere((0.25, 0.7, 0.0), 0.06, black, radiance=(300.0, 260.0, 200.0))
+    sd.rectangle(translate(-0.6, 0.995, -0.4) @ rotate("x", 90) @ scale(0.1), black, radiance=12.0)
+    sd.set_camera(lookat((0, 0, 3.9), (0, 0, 0), (0, 1, 0)), 39.3077, res, res, abi.FILTER_BOX, 0.5)
+    return sd
+
+
 SCENES = {"cornell_c1": cornell_c1, "cornell_c2": cornell_c2, "glass_sphere": glass_sphere, "door_c3": door_c3,
-          "triangle_soup": triangle_soup}
+          "triangle_soup": triangle_soup, "caustic_c5": caustic_c5}

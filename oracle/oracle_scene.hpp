@@ -177,7 +177,6 @@ public:
                 sh.radius = in.data[3];
                 sh.invArea = F(1) / (F(4 * kPi) * sh.radius * sh.radius);
                 grow(sh.center - V3<F>(sh.radius)); grow(sh.center + V3<F>(sh.radius));
-                if (in.emitter >= 0) return "sphere emitters not supported yet";
             } else {
                 return "unknown shape type";
             }
@@ -381,6 +380,11 @@ public:
         if (sh.type == DRMLT_SHAPE_RECTANGLE) { // rectangle.cpp:210-216
             p = xfPoint(sh.o2w, V3<F>(sx * 2 - 1, sy * 2 - 1, 0));
             n = sh.frame.n;
+        } else if (sh.type == DRMLT_SHAPE_SPHERE) { // sphere.cpp:257-268, warp.cpp:25-31
+            F z = 1 - 2 * sy, r = safe_sqrt(1 - z * z);
+            V3<F> v(r * std::cos(F(2 * kPi) * sx), r * std::sin(F(2 * kPi) * sx), z);
+            p = sh.center + v * sh.radius;
+            n = v;
         } else { // single triangle: Triangle::sample (squareToUniformTriangle)
             F a = safe_sqrt(F(1) - sx);
             F bx = 1 - a, by = a * sy;
@@ -390,20 +394,78 @@ public:
         pdf = sh.invArea;
     }
 
+    // util.cpp:447-485
+    static bool solveQuadratic(F a, F b, F c, F &x0, F &x1) {
+        if (a == 0) { if (b != 0) { x0 = x1 = -c / b; return true; } return false; }
+        F discrim = b * b - 4 * a * c;
+        if (discrim < 0) return false;
+        F sqrtDiscrim = std::sqrt(discrim);
+        F temp = b < 0 ? F(-0.5) * (b - sqrtDiscrim) : F(-0.5) * (b + sqrtDiscrim);
+        x0 = temp / a; x1 = c / temp;
+        if (x0 > x1) std::swap(x0, x1);
+        return true;
+    }
+
+    // Shape::sampleDirect (shape.cpp:102-116) or, for a sphere, the cone sampling of sphere.cpp:286-355.
+    // Fills p, n, d, dist and the solid-angle pdf of dRec.
+    void shapeSampleDirect(const Shape<F> &sh, DirectSample &dRec, F sx, F sy) const {
+        if (sh.type != DRMLT_SHAPE_SPHERE) {
+            samplePosition(sh, sx, sy, dRec.p, dRec.n, dRec.pdf);
+            dRec.d = dRec.p - dRec.ref;
+            F distSquared = dRec.d.lengthSquared();
+            dRec.dist = std::sqrt(distSquared);
+            dRec.d /= dRec.dist;
+            F dp = absDot(dRec.d, dRec.n);
+            dRec.pdf *= dp != 0 ? (distSquared / dp) : F(0);
+            return;
+        }
+        const V3<F> refToCenter = sh.center - dRec.ref;
+        const F refDist2 = refToCenter.lengthSquared();
+        const F invRefDist = F(1) / std::sqrt(refDist2);
+        const F sinAlpha = sh.radius * invRefDist;
+        if (sinAlpha < 1 - Consts<F>::Epsilon) { // outside: sample the cone subtended by the sphere
+            F cosAlpha = safe_sqrt(1 - sinAlpha * sinAlpha);
+            F cosTheta = (1 - sx) + sx * cosAlpha, sinTheta = safe_sqrt(1 - cosTheta * cosTheta);
+            V3<F> local(std::cos(F(2 * kPi) * sy) * sinTheta, std::sin(F(2 * kPi) * sy) * sinTheta, cosTheta);
+            dRec.d = Frame<F>(refToCenter * invRefDist).toWorld(local);
+            dRec.pdf = F(0.5 * kInvPi) / (1 - cosAlpha);
+            const F projDist = dot(refToCenter, dRec.d);
+            const F baseT = refDist2 / projDist;
+            const V3<F> query = dRec.ref + dRec.d * baseT;
+            const V3<F> queryToCenter = sh.center - query;
+            const F queryDist2 = queryToCenter.lengthSquared(), queryProjDist = dot(queryToCenter, dRec.d);
+            F nearT, farT;
+            if (!solveQuadratic(F(1), -2 * queryProjDist, queryDist2 - sh.radius * sh.radius, nearT, farT)) nearT = queryProjDist;
+            dRec.dist = baseT + nearT;
+            dRec.n = normalize(dRec.d * nearT - queryToCenter);
+            dRec.p = sh.center + dRec.n * sh.radius;
+        } else { // inside: uniform on the sphere
+            F pdfPos;
+            samplePosition(sh, sx, sy, dRec.p, dRec.n, pdfPos);
+            dRec.d = dRec.p - dRec.ref;
+            F dist2 = dRec.d.lengthSquared();
+            dRec.dist = std::sqrt(dist2);
+            dRec.d /= dRec.dist;
+            dRec.pdf = sh.invArea * dist2 / absDot(dRec.d, dRec.n);
+        }
+    }
+    // Shape::pdfDirect (shape.cpp:118-127) / sphere.cpp:357-385, solid-angle measure
+    F shapePdfDirect(const Shape<F> &sh, const DirectSample &dRec) const {
+        if (sh.type == DRMLT_SHAPE_SPHERE) {
+            const V3<F> refToCenter = sh.center - dRec.ref;
+            const F sinAlpha = sh.radius / refToCenter.length();
+            if (sinAlpha < 1 - Consts<F>::Epsilon) return F(0.5 * kInvPi) / (1 - safe_sqrt(1 - sinAlpha * sinAlpha));
+        }
+        return sh.invArea * (dRec.dist * dRec.dist) / absDot(dRec.d, dRec.n);
+    }
+
     // scene.cpp:879-904 (testVisibility = true)
     V3<F> sampleEmitterDirect(DirectSample &dRec, F sx, F sy, uint64_t *rayCounter) const {
         F emPdf;
         size_t index = sampleEmitterIndex(sx, emPdf);
         const Emitter<F> &em = emitters[index];
         const Shape<F> &sh = shapes[em.shape];
-        // Shape::sampleDirect, shape.cpp:102-116
-        samplePosition(sh, sx, sy, dRec.p, dRec.n, dRec.pdf);
-        dRec.d = dRec.p - dRec.ref;
-        F distSquared = dRec.d.lengthSquared();
-        dRec.dist = std::sqrt(distSquared);
-        dRec.d /= dRec.dist;
-        F dp = absDot(dRec.d, dRec.n);
-        dRec.pdf *= dp != 0 ? (distSquared / dp) : F(0);
+        shapeSampleDirect(sh, dRec, sx, sy);
         // AreaLight::sampleDirect, area.cpp:164-178
         V3<F> value(0);
         if (dot(dRec.d, dRec.refN) >= 0 && dot(dRec.d, dRec.n) < 0 && dRec.pdf != 0) {
@@ -427,7 +489,7 @@ public:
         const Emitter<F> &em = emitters[dRec.emitter];
         F pdf = 0;
         if (dot(dRec.d, dRec.refN) >= 0 && dot(dRec.d, dRec.n) < 0)
-            pdf = shapes[em.shape].invArea * (dRec.dist * dRec.dist) / absDot(dRec.d, dRec.n);
+            pdf = shapePdfDirect(shapes[em.shape], dRec);
         F discrete = emitterCdf[dRec.emitter + 1] - emitterCdf[dRec.emitter];
         return pdf * discrete;
     }

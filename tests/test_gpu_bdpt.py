@@ -19,7 +19,7 @@ def make(pkg, ob, sd, **kw):
     return cfg, pkg.Context(cfg, sd), ob.Oracle(abi, cfg, sd, 64)
 
 
-@pytest.mark.parametrize("name", ["cornell_c2", "glass_sphere", "door_c3"])
+@pytest.mark.parametrize("name", ["cornell_c2", "glass_sphere", "door_c3", "caustic_c5"])
 def test_lists_match_oracle(pkg, ob, name, native_lib):
     """f(u) = a splat list: same number of light-image splats, same dims / rays, luminance and every splat within 2e-3."""
     sd = pkg.scenes.SCENES[name](res=64)

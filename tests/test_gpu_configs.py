@@ -60,7 +60,7 @@ def test_config4_one_gpu_share_2048(pkg, native_lib):
 
 def test_config5_caustic_mmlt_full_size(pkg, native_lib):
     """Glass caustic, mmlt / orbital / fixEmitterPath / acceptanceMap at 512 x 512 with 65 536 chains."""
-    sd = pkg.scenes.glass_sphere(512)
+    sd = pkg.scenes.caustic_c5(512)
     n = 65536
     cfg = pkg.abi.make_config(technique="mmlt", type="orbital", max_depth=6, direct_samples=-1, fix_emitter_path=1,
                               acceptance_map=1, work_units=n, sample_count=64, luminance_samples=100000)

@@ -21,7 +21,7 @@ def make(pkg, ob, sd, precision=64, **kw):
     return cfg, pkg.Context(cfg, sd), ob.Oracle(abi, cfg, sd, precision)
 
 
-@pytest.mark.parametrize("name", ["cornell_c2", "glass_sphere", "door_c3"])
+@pytest.mark.parametrize("name", ["cornell_c2", "glass_sphere", "door_c3", "caustic_c5"])
 def test_eval_matches_oracle(pkg, ob, name, native_lib):
     """f(u) on identical PSS points, every depth and strategy: same (s, t), same ray count for >= 99.5 %,
     luminance within 2e-3 relative at the 99th percentile."""
@@ -123,7 +123,7 @@ def test_chains_track_the_oracle(pkg, ob, kw, native_lib):
 def test_config5_caustic_acceptance_map(pkg, ob, native_lib):
     """BASELINE config 5: glass caustic, mmlt / orbital / fixEmitterPath / acceptanceMap. The map counts accepted
     first-stage (red) and second-stage (green) small steps per pixel (drmlt_proc.cpp:697-709); b is forced to 1."""
-    sd = pkg.scenes.glass_sphere(64)
+    sd = pkg.scenes.caustic_c5(64)      # dielectric sphere + small SPHERE area light (+ a dim quad light)
     n_chains = 8192
     cfg, ctx, orc = make(pkg, ob, sd, type="orbital", fix_emitter_path=1, acceptance_map=1, work_units=n_chains,
                          sample_count=1, luminance_samples=1000)

@@ -32,7 +32,7 @@ def make(pkg, ob, sd, precision=64, **kw):
     return cfg, pkg.Context(cfg, sd), ob.Oracle(abi, cfg, sd, precision)
 
 
-SCENES = ["cornell_c1", "cornell_c2", "glass_sphere", "door_c3", "triangle_soup"]
+SCENES = ["cornell_c1", "cornell_c2", "glass_sphere", "door_c3", "triangle_soup", "caustic_c5"]
 
 
 @pytest.mark.parametrize("name", SCENES)

@@ -196,3 +196,21 @@ def test_bdpt_refusals(pkg, abi, ob):
     sd = pkg.scenes.cornell_c2(16)
     with pytest.raises(ob.OracleError, match="directSampling=false"):
         ob.Oracle(abi, abi.make_config(technique="bdpt", max_depth=5, work_units=4), sd, 64)
+
+
+def test_sphere_area_light(pkg, abi, ob):
+    """Sphere emitters (sphere.cpp:257-385): the unidirectional estimator samples the cone the sphere subtends (NEE) and
+    weighs BSDF hits with the same solid-angle density; the bidirectional one samples the sphere's area uniformly.
+    Two different sampling routes, one integrand."""
+    sd = pkg.scenes.caustic_c5(16)
+    ref = ob.Oracle(abi, abi.make_config(max_depth=5, rr_depth=100, work_units=4, direct_samples=16), sd, 64) \
+        .render_pt(8000, seed=7, nthreads=8)
+    img = ob.Oracle(abi, abi.make_config(technique="bdpt", max_depth=5, rr_depth=100, work_units=4, direct_samples=16,
+                                          no_direct_sampling=1), sd, 64).bdpt_render(16 * 16 * 8000, seed=3, nthreads=8)
+    assert lum(img).mean() == pytest.approx(lum(ref).mean(), rel=0.02)
+    assert np.abs(blocks(img) - blocks(ref)).mean() / ref.mean() < 0.03
+    direct = ob.Oracle(abi, abi.make_config(max_depth=2, rr_depth=100, work_units=4, direct_samples=-1), sd, 64) \
+        .render_pt(8000, seed=7, nthreads=8)
+    m, strat = ob.Oracle(abi, abi.make_config(technique="mmlt", max_depth=2, work_units=4, direct_samples=-1), sd, 64) \
+        .mmlt_render(2, 16 * 16 * 8000, seed=5, nthreads=8)
+    assert lum(m).mean() == pytest.approx(lum(direct).mean(), rel=0.02) and strat[1] > 0 and strat[2] > 0

@@ -9,7 +9,7 @@ res = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 chains = int(sys.argv[2]) if len(sys.argv) > 2 else 65536
 per_chain = int(sys.argv[3]) if len(sys.argv) > 3 else 256
 amap = int(sys.argv[4]) if len(sys.argv) > 4 else 1
-sd = pkg.scenes.glass_sphere(res)
+sd = pkg.scenes.SCENES[sys.argv[5] if len(sys.argv) > 5 else 'caustic_c5'](res)
 cfg = abi.make_config(technique='mmlt', type='orbital', max_depth=6, direct_samples=-1, fix_emitter_path=1,
                       acceptance_map=amap, work_units=chains, sample_count=1, luminance_samples=1000)
 ctx = pkg.Context(cfg, sd)
