@@ -357,17 +357,17 @@ DEV void eval_bdpt(const DParams &P, const TablesT &T, MSampler &smp, uint32_t c
             };
             double weight = 1.0, pdf = 1.0;
             for (int i = s + 1; i < k; ++i) {
-                double next = pdf * (double) pImp(i) / (double) pRad(i);
+                double next = pdf * (double) (pImp(i) / pRad(i)); // ratio in fp32, product in fp64 (see device_bidir.h)
                 if (conn(i) && conn(i + 1) && (P.light_image || k - i - 1 > 1)) weight += next * next;
                 pdf = next;
             }
             pdf = 1.0;
             for (int i = s - 1; i >= 0; --i) {
-                double next = pdf * (double) pRad(i + 1) / (double) pImp(i + 1);
+                double next = pdf * (double) (pRad(i + 1) / pImp(i + 1));
                 if (conn(i) && conn(i + 1) && (P.light_image || k - i - 1 > 1)) weight += next * next;
                 pdf = next;
             }
-            value = value * (geo * (float) (1.0 / weight));
+            value = value * (geo / (float) weight);
 
             if (t == 1) { // light image: its own splat (:514-516)
                 float sx, sy;

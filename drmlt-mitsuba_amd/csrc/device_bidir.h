@@ -256,43 +256,15 @@ DEV float vert_pdf_sa(const DParams &P, const DBsdf &B, const BVert &v, f3 wi, f
 }
 
 // ------------------------------------------------------------------ the estimator
-// One evaluation of sampleSplats(EMMLT), split at its ray queries so that it can run either to completion
-// (eval_mmlt: bootstrap, seed replay, explicit evaluation) or one ray per call inside the lane state machine of
-// k_mutate_mmlt_v2. LDS rows used for the MIS sweep, per lane: pImp[NV], pRad[NV], gInv[NV] from row `mis_row`,
-// NV = maxDepth + 3.
-enum { ME_RAY = 0, ME_WALKS_DONE = 1, ME_FINISHED = 2 };
+// LDS rows used for the MIS sweep, per lane: pImp[NV], pRad[NV], gInv[NV] from row `mis_row`, NV = maxDepth + 3.
+template <class TablesT>
+DEV void eval_mmlt(const DParams &P, const TablesT &T, MSampler &smp, int depth, uint32_t mis_row, MmltResult &R) {
+    const uint32_t lane = smp.lane;
+    const uint32_t NV = (uint32_t) P.max_depth + 3u;
+    auto pImp = [&](int j) -> float & { return lds_x[(mis_row + (uint32_t) j) * 64u + lane]; };
+    auto pRad = [&](int j) -> float & { return lds_x[(mis_row + NV + (uint32_t) j) * 64u + lane]; };
+    auto gInv = [&](int j) -> float & { return lds_x[(mis_row + 2u * NV + (uint32_t) j) * 64u + lane]; };
 
-struct MmltEval {
-    BVert cur, vt;
-    f3 thr;
-    uint32_t conn;      // bit j: vertex j is connectable
-    float film_x, film_y;
-    int pos, step, s, t, k, depth, nStrats;
-    uint32_t kdim;
-    bool failed, em_started;
-    // between walk_sample and walk_hit
-    f3 d;
-    float pdf_fwd, pdf_rev;
-    bool delta, sensor;
-    // between connect_setup and finish
-    f3 value;
-    float geo;
-    // the ray to trace next (ME_RAY)
-    f3 ro, rd;
-    float rtmin, rtmax;
-    MmltResult R;
-};
-
-struct MisRows {
-    uint32_t row, NV, lane;
-    DEV float &pImp(int j) const { return lds_x[(row + (uint32_t) j) * 64u + lane]; }
-    DEV float &pRad(int j) const { return lds_x[(row + NV + (uint32_t) j) * 64u + lane]; }
-    DEV float &gInv(int j) const { return lds_x[(row + 2u * NV + (uint32_t) j) * 64u + lane]; }
-};
-
-// strategy selection (pathsampler.cpp:96-135). Returns false when the evaluation is already over (depth 1).
-DEV bool mmlt_begin(const DParams &P, MSampler &smp, int depth, MmltEval &E) {
-    MmltResult &R = E.R;
     R.splat.lum = R.splat.px = R.splat.py = R.splat.r = R.splat.g = R.splat.b = 0.f;
     R.nrays = 0u; R.n_sensor = R.n_emitter = 0u; R.n_direct = 1u;
     smp.reset_caches();
@@ -302,51 +274,42 @@ DEV bool mmlt_begin(const DParams &P, MSampler &smp, int depth, MmltEval &E) {
     if (P.light_image) { nStrats = depth + 1; s = min((int) ((float) nStrats * decision), nStrats - 1); t = nStrats - s; }
     else { nStrats = depth; s = min((int) ((float) nStrats * decision), nStrats - 1); t = 1 + (nStrats - s); }
     R.s = s; R.t = t;
-    E.s = s; E.t = t; E.k = s + t + 1; E.depth = depth; E.nStrats = nStrats;
-    E.cur.kind = BK_SUPER_S; E.cur.p = E.cur.n = E.cur.s = E.cur.wi = mk3(0.f, 0.f, 0.f);
-    E.cur.e_len2 = 0.f; E.cur.e_cos = 0.f; E.cur.bsdf = 0; E.cur.emitter = -1; E.cur.shade = 0; E.cur.degenerate = true;
-    E.vt = E.cur;
-    E.thr = mk3(1.f, 1.f, 1.f);
-    E.conn = 1u; // emitter supernode: area emitters only
-    E.film_x = E.film_y = 0.f;
-    E.pos = E.k; E.kdim = 0u; E.step = 0; E.failed = false; E.em_started = false;
-    E.value = mk3(0.f, 0.f, 0.f); E.geo = 1.f;
+    if (depth == 1) return;
+    const int k = s + t + 1;
+
+    BVert cur, vt;
+    cur.kind = BK_SUPER_S; cur.p = cur.n = cur.s = cur.wi = mk3(0.f, 0.f, 0.f);
+    cur.e_len2 = 0.f; cur.e_cos = 0.f; cur.bsdf = 0; cur.emitter = -1; cur.shade = 0; cur.degenerate = true;
+    vt = cur;
+    f3 thr = mk3(1.f, 1.f, 1.f);
+    uint32_t conn = 1u; // bit j: vertex j is connectable. Emitter supernode: area emitters only
+    float film_x = 0.f, film_y = 0.f;
+    int pos = k;
+    uint32_t kdim = 0u;
     smp.select(SEG_SENSOR);
-    return depth != 1;
-}
 
-// A walk that fails ends there, but the other walk is still made (pathsampler.cpp:140-160 checks both lengths
-// afterwards): the PSS components and rays it consumes are part of the chain's bookkeeping.
-DEV void mmlt_walk_fail(MmltEval &E) {
-    E.failed = true;
-    E.step = E.sensor ? E.t : E.s + E.t;
-}
-
-// Advance the walks until a ray has to be traced (ME_RAY: E.ro/rd/rtmin/rtmax) or both are complete (ME_WALKS_DONE).
-template <class TablesT>
-DEV int mmlt_walk_sample(const DParams &P, const TablesT &T, MSampler &smp, const MisRows &M, MmltEval &E) {
-    BVert &cur = E.cur;
-    const int s = E.s, t = E.t, k = E.k;
+    // A walk that fails ends there, but the other walk is still made (pathsampler.cpp:140-160 checks both
+    // lengths afterwards): the PSS components and rays it consumes are part of the chain's bookkeeping.
+    bool failed = false;
+#define WALK_FAIL { failed = true; if (sensor) { step = t - 1; continue; } break; }
 #pragma nounroll
-    while (E.step < s + t) {
-        const bool sensor = E.step < t;
-        E.sensor = sensor;
-        if (!sensor && !E.em_started) { // sensor walk complete (or abandoned): park its end vertex, start at the emitter supernode
-            E.vt = cur;
+    for (int step = 0; step < s + t; ++step) {
+        const bool sensor = step < t;
+        if (step == t) { // sensor walk complete: park its end vertex, start at the emitter supernode
+            vt = cur;
             cur.kind = BK_SUPER_E; cur.e_len2 = 0.f; cur.degenerate = false;
-            E.pos = 0; E.kdim = 0u;
+            pos = 0; kdim = 0u;
             smp.select(SEG_EMITTER);
-            E.em_started = true;
         }
-        const float u0 = smp.next(E.kdim), u1 = smp.next(E.kdim + 1u);
-        E.kdim += 2u;
-        if (sensor) E.R.n_sensor = E.kdim; else E.R.n_emitter = E.kdim;
-        const int npos = sensor ? E.pos - 1 : E.pos + 1;
+        const float u0 = smp.next(kdim), u1 = smp.next(kdim + 1u);
+        kdim += 2u;
+        if (sensor) R.n_sensor = kdim; else R.n_emitter = kdim;
+        const int npos = sensor ? pos - 1 : pos + 1;
 
         if (cur.kind == BK_SUPER_S) { // perspective.cpp:299-307: pinhole position, discrete
-            M.pRad(k - 1) = 1.f;
+            pRad(k - 1) = 1.f;
             cur.kind = BK_END_S; cur.p = cam_pos(P); cur.n = cam_dir(P); cur.degenerate = false; cur.e_len2 = 0.f;
-            E.pos = npos; E.step++;
+            pos = npos;
             continue;
         }
         if (cur.kind == BK_SUPER_E) { // Scene::sampleEmitterPosition, scene.cpp:1066-1079
@@ -354,256 +317,226 @@ DEV int mmlt_walk_sample(const DParams &P, const TablesT &T, MSampler &smp, cons
             int ei = 0;
             for (int i = 1; i < P.n_emitters; ++i)
                 if (T.emitter_cdf_lo(i) < sx) ei = i;
-            const DEmitter Em = T.emitter(ei);
-            const float emPdf = Em.cdf_hi - Em.cdf_lo;
-            sx = (sx - Em.cdf_lo) / emPdf;
-            const DShade L = T.shade(Em.prim);
+            const DEmitter E = T.emitter(ei);
+            const float emPdf = E.cdf_hi - E.cdf_lo;
+            sx = (sx - E.cdf_lo) / emPdf;
+            const DShade L = T.shade(E.prim);
             f3 lp;
             if ((L.bsdf >> 24) == PRIM_RECTANGLE) lp = fma3(ld3(L.eu), sx, fma3(ld3(L.ev), u1, ld3(L.origin)));
             else if ((L.bsdf >> 24) == PRIM_SPHERE) { // sphere.cpp:257-268: uniform on the sphere
                 const float z = 1.f - 2.f * u1, r = sqrtf(fmaxf(0.f, 1.f - z * z));
                 lp = mk3(r * cos_rev(sx), r * sin_rev(sx), z); // unit normal for now, scaled below
             } else { float a = sqrtf(fmaxf(0.f, 1.f - sx)); lp = fma3(ld3(L.eu), 1.f - a, fma3(ld3(L.ev), a * u1, ld3(L.origin))); }
-            M.pImp(1) = L.inv_area * emPdf;
-            E.thr = E.thr * (ld3(Em.radiance) * (PI_F / (L.inv_area * emPdf))); // m_power / emitter pdf (area.cpp:96-101)
+            pImp(1) = L.inv_area * emPdf;
+            thr = thr * (ld3(E.radiance) * (PI_F / (L.inv_area * emPdf))); // m_power / emitter pdf (area.cpp:96-101)
             const bool sph = (L.bsdf >> 24) == PRIM_SPHERE;
-            cur.kind = BK_END_E; cur.n = sph ? lp : ld3(L.n); cur.p = sph ? fma3(lp, L.eu[0], ld3(L.origin)) : lp;
-            cur.emitter = ei; cur.shade = Em.prim; cur.degenerate = false; cur.e_len2 = 0.f;
-            E.pos = npos; E.step++;
+            cur.kind = BK_END_E; cur.n = sph ? lp : ld3(L.n); cur.p = sph ? fma3(lp, L.eu[0], ld3(L.origin)) : lp; cur.emitter = ei; cur.shade = E.prim; cur.degenerate = false; cur.e_len2 = 0.f;
+            pos = npos;
             continue;
         }
 
         // ---- sample a direction at `cur`
-        E.pdf_rev = 1.f;
-        E.delta = false;
+        f3 d;
+        float pdf_fwd, pdf_rev = 1.f;
+        bool delta = false;
         if (cur.kind == BK_END_E) { // area.cpp:117-130
             f3 fs, ft;
             frame_from_normal(cur.n, fs, ft);
             f3 l = square_to_cosine_hemisphere(u0, u1);
-            E.d = fma3(fs, l.x, fma3(ft, l.y, cur.n * l.z));
-            E.pdf_fwd = INV_PI_F * l.z;
-            E.conn |= 1u << E.pos;
+            d = fma3(fs, l.x, fma3(ft, l.y, cur.n * l.z));
+            pdf_fwd = INV_PI_F * l.z;
+            conn |= 1u << pos;
         } else if (cur.kind == BK_END_S) { // perspective.cpp:317-343
             f3 nearP = mk3((1.f - 2.f * u0) * P.tan_half_fov * P.near_clip, (1.f - 2.f * u1) * P.tan_half_fov * P.inv_aspect * P.near_clip,
                            P.near_clip);
             f3 dl = normalize3(nearP);
-            E.d = cam_to_world(P, dl);
-            E.pdf_fwd = cam_normalization(P) / (dl.z * dl.z * dl.z);
-            E.conn |= 1u << E.pos;
-            E.film_x = u0 * (float) P.width; E.film_y = u1 * (float) P.height;
+            d = cam_to_world(P, dl);
+            pdf_fwd = cam_normalization(P) / (dl.z * dl.z * dl.z);
+            conn |= 1u << pos;
         } else {
             const DBsdf B = T.bsdf(cur.bsdf);
             f3 wo;
             f3 w;
             if (B.type == 0) {
-                if (!(cur.wi.z > 0.f)) { mmlt_walk_fail(E); continue; }
+                if (!(cur.wi.z > 0.f)) WALK_FAIL;
                 wo = square_to_cosine_hemisphere(u0, u1);
-                E.pdf_fwd = INV_PI_F * wo.z;
+                pdf_fwd = INV_PI_F * wo.z;
                 w = ld3(B.rgb);
             } else if (B.type == 1) { // dielectric.cpp:270-306; radiance scaling only in ERadiance mode
                 float cosThetaT;
                 float F = fresnel_dielectric_ext(cur.wi.z, cosThetaT, B.p[0]);
-                E.delta = true;
+                delta = true;
                 if (u0 <= F) {
                     wo = mk3(-cur.wi.x, -cur.wi.y, cur.wi.z);
-                    E.pdf_fwd = F;
+                    pdf_fwd = F;
                     w = mk3(1.f, 1.f, 1.f);
                 } else {
                     float scale = -(cosThetaT < 0.f ? B.p[1] : B.p[0]);
                     wo = mk3(scale * cur.wi.x, scale * cur.wi.y, cosThetaT);
-                    E.pdf_fwd = 1.f - F;
+                    pdf_fwd = 1.f - F;
                     float factor = sensor ? (cosThetaT < 0.f ? B.p[1] : B.p[0]) : 1.f;
                     w = mk3(factor * factor, factor * factor, factor * factor);
                 }
             } else {
-                E.pdf_fwd = 0.f;
-                w = make_rc(B).sample(cur.wi, u0, u1, wo, E.pdf_fwd);
+                pdf_fwd = 0.f;
+                w = make_rc(B).sample(cur.wi, u0, u1, wo, pdf_fwd);
             }
-            if (is_zero3(w)) { mmlt_walk_fail(E); continue; }
-            if (cur.wi.z == 0.f || wo.z == 0.f) { mmlt_walk_fail(E); continue; } // vertex.cpp:206-211 with ng == ns
-            E.pdf_rev = E.delta ? dielectric_pdf_delta(B, wo, cur.wi) : bsdf_pdf_sa(B, wo, cur.wi);
-            if (!(E.pdf_rev > 2.93873587705571876e-39f)) { mmlt_walk_fail(E); continue; } // RCPOVERFLOW, :236-239
-            E.thr = E.thr * w;
-            if (!cur.degenerate && !E.delta) E.conn |= 1u << E.pos;
-            E.d = fma3(cur.s, wo.x, fma3(cross3(cur.n, cur.s), wo.y, cur.n * wo.z));
+            if (is_zero3(w)) WALK_FAIL;
+            if (cur.wi.z == 0.f || wo.z == 0.f) WALK_FAIL; // vertex.cpp:206-211 with ng == ns
+            pdf_rev = delta ? dielectric_pdf_delta(B, wo, cur.wi) : bsdf_pdf_sa(B, wo, cur.wi);
+            if (!(pdf_rev > 2.93873587705571876e-39f)) WALK_FAIL; // RCPOVERFLOW, :236-239
+            thr = thr * w;
+            if (!cur.degenerate && !delta) conn |= 1u << pos;
+            d = fma3(cur.s, wo.x, fma3(cross3(cur.n, cur.s), wo.y, cur.n * wo.z));
         }
-        E.ro = cur.p; E.rd = E.d; E.rtmin = ray_eps_closest(cur.p); E.rtmax = INFINITY;
-        E.R.nrays++;
-        return ME_RAY;
-    }
-    return ME_WALKS_DONE;
-}
 
-// The ray of mmlt_walk_sample came back: PathEdge::sampleNext (edge.cpp:27-84) and the area-measure conversion of
-// the vertex just sampled (vertex.cpp:332-347).
-template <class TablesT>
-DEV void mmlt_walk_hit(const DParams &P, const TablesT &T, const MisRows &M, MmltEval &E, const Hit &h) {
-    BVert &cur = E.cur;
-    if (h.prim < 0) { mmlt_walk_fail(E); return; }
-    const bool sensor = E.sensor;
-    const int npos = sensor ? E.pos - 1 : E.pos + 1;
-    const f3 d = E.d;
-    const DShade Sh = T.shade(h.prim);
-    BVert nv;
-    if ((Sh.bsdf >> 24) != PRIM_SPHERE) {
-        nv.p = fma3(ld3(Sh.eu), h.u, fma3(ld3(Sh.ev), h.v, ld3(Sh.origin)));
-        nv.n = ld3(Sh.n);
-        nv.s = ld3(Sh.eu) * Sh.inv_len_eu;
-    } else {
-        f3 c = ld3(Sh.origin);
-        f3 local = normalize3(fma3(d, h.t, cur.p) - c);
-        nv.p = fma3(local, Sh.eu[0], c);
-        nv.n = local;
-        float zrad2 = local.x * local.x + local.y * local.y;
-        float inv = rsqrtf(zrad2);
-        nv.s = zrad2 > 0.f ? mk3(-local.y * inv, local.x * inv, 0.f) : mk3(1.f, 0.f, 0.f);
-    }
-    if (h.t == 0.f) { mmlt_walk_fail(E); return; }
-    const float len2 = h.t * h.t;
-    const float cosNew = fabsf(dot3(d, nv.n)), cosCur = fabsf(dot3(d, cur.n));
-    float fwd = E.pdf_fwd, rev = E.pdf_rev;
-    if (!E.delta) {
-        fwd = E.pdf_fwd * cosNew / len2;
-        if (cur.e_len2 != 0.f) rev = E.pdf_rev * cur.e_cos / cur.e_len2;
-    }
-    if (sensor) { M.pRad(npos) = fwd; if (cur.kind == BK_SURF || cur.kind == BK_END_S) M.pImp(E.pos + 1) = rev; }
-    else { M.pImp(npos) = fwd; if (cur.kind == BK_SURF || cur.kind == BK_END_E) M.pRad(E.pos - 1) = rev; }
-    M.gInv(sensor ? npos : E.pos) = len2 / (cosNew * cosCur);
+        // ---- PathEdge::sampleNext: next surface along the ray
+        const Hit h = trace(P, cur.p, d, ray_eps_closest(cur.p), INFINITY, false);
+        R.nrays++;
+        if (h.prim < 0) WALK_FAIL;
+        const DShade Sh = T.shade(h.prim);
+        BVert nv;
+        if ((Sh.bsdf >> 24) != PRIM_SPHERE) {
+            nv.p = fma3(ld3(Sh.eu), h.u, fma3(ld3(Sh.ev), h.v, ld3(Sh.origin)));
+            nv.n = ld3(Sh.n);
+            nv.s = ld3(Sh.eu) * Sh.inv_len_eu;
+        } else {
+            f3 c = ld3(Sh.origin);
+            f3 local = normalize3(fma3(d, h.t, cur.p) - c);
+            nv.p = fma3(local, Sh.eu[0], c);
+            nv.n = local;
+            float zrad2 = local.x * local.x + local.y * local.y;
+            float inv = rsqrtf(zrad2);
+            nv.s = zrad2 > 0.f ? mk3(-local.y * inv, local.x * inv, 0.f) : mk3(1.f, 0.f, 0.f);
+        }
+        if (h.t == 0.f) WALK_FAIL;
+        const float len2 = h.t * h.t;
+        const float cosNew = fabsf(dot3(d, nv.n)), cosCur = fabsf(dot3(d, cur.n));
+        // solid angle -> area (vertex.cpp:332-347)
+        float fwd = pdf_fwd, rev = pdf_rev;
+        if (!delta) {
+            fwd = pdf_fwd * cosNew / len2;
+            if (cur.e_len2 != 0.f) rev = pdf_rev * cur.e_cos / cur.e_len2;
+        }
+        if (sensor) { pRad(npos) = fwd; if (cur.kind == BK_SURF || cur.kind == BK_END_S) pImp(pos + 1) = rev; }
+        else { pImp(npos) = fwd; if (cur.kind == BK_SURF || cur.kind == BK_END_E) pRad(pos - 1) = rev; }
+        gInv(sensor ? npos : pos) = len2 / (cosNew * cosCur);
+        if (cur.kind == BK_END_S) { film_x = u0 * (float) P.width; film_y = u1 * (float) P.height; }
 
-    nv.kind = BK_SURF;
-    nv.bsdf = Sh.bsdf & 0xffffff;
-    nv.emitter = Sh.emitter;
-    nv.shade = h.prim;
+        nv.kind = BK_SURF;
+        nv.bsdf = Sh.bsdf & 0xffffff;
+        nv.emitter = Sh.emitter;
+        nv.shade = h.prim;
+        {
+            const int bt = T.bsdf(nv.bsdf).type;
+            nv.degenerate = !(bt == 0 || bt == 2 || Sh.emitter >= 0); // edge.cpp:66-69
+        }
+        nv.wi = to_local(nv, -d);
+        nv.e_len2 = len2;
+        nv.e_cos = cosCur;
+        cur = nv;
+        pos = npos;
+    }
+
+#undef WALK_FAIL
+    if (failed) return;
+
+    // ---- both walks complete
+    BVert vs;
+    if (s == 0) { vt = cur; vs.kind = BK_SUPER_E; vs.degenerate = false; vs.p = vs.n = vs.s = vs.wi = mk3(0.f, 0.f, 0.f); vs.e_len2 = vs.e_cos = 0.f; vs.bsdf = 0; vs.emitter = -1; vs.shade = 0; }
+    else vs = cur;
+    if (s >= 1 && !vs.degenerate) conn |= 1u << s;
+    if (!vt.degenerate) conn |= 1u << (s + 1);
+    // "Check if subpaths are connectable", pathsampler.cpp:161-173: vertices 2 .. k-2
     {
-        const int bt = T.bsdf(nv.bsdf).type;
-        nv.degenerate = !(bt == 0 || bt == 2 || Sh.emitter >= 0); // edge.cpp:66-69
-    }
-    nv.wi = to_local(nv, -d);
-    nv.e_len2 = len2;
-    nv.e_cos = cosCur;
-    cur = nv;
-    E.pos = npos;
-    E.step++;
-}
-
-// Both walks are complete: the connection (pathsampler.cpp:161-280). ME_RAY: a visibility ray has to be traced before
-// mmlt_finish; ME_FINISHED: no contribution; ME_WALKS_DONE: no ray needed (pure sensor path), go on to mmlt_finish.
-template <class TablesT>
-DEV int mmlt_connect(const DParams &P, const TablesT &T, const MisRows &M, MmltEval &E) {
-    if (E.failed) return ME_FINISHED;
-    const int s = E.s, k = E.k;
-    if (s == 0) E.vt = E.cur; // the sensor walk's end vertex was never parked
-    BVert &vt = E.vt;
-    const BVert &vs = E.cur;  // meaningful for s >= 1
-    if (s >= 1 && !vs.degenerate) E.conn |= 1u << s;
-    if (!vt.degenerate) E.conn |= 1u << (s + 1);
-    { // "Check if subpaths are connectable", pathsampler.cpp:161-173: vertices 2 .. k-2
         uint32_t inner = 0u;
         if (k - 2 >= 2) inner = ((1u << (k - 1)) - 1u) & ~3u;
-        if ((E.conn & inner) == 0u) return ME_FINISHED;
+        if ((conn & inner) == 0u) return;
     }
+
+    f3 value;
+    float geo = 1.f;
     if (s == 0) {
         // PathVertex::cast(EEmitterSample): the sensor path must end on an emitter
-        if (vt.kind != BK_SURF || vt.emitter < 0) return ME_FINISHED;
-        const DEmitter Em = T.emitter(vt.emitter);
+        if (vt.kind != BK_SURF || vt.emitter < 0) return;
+        const DEmitter E = T.emitter(vt.emitter);
         const f3 wo = to_world(vt, vt.wi); // unit direction towards vtPred
         float dp = dot3(wo, vt.n);
         float r = dp < 0.f ? 0.f : INV_PI_F * dp;
         if (dp != 0.f) r /= fabsf(dp);
-        E.value = E.thr * (ld3(Em.radiance) * (PI_F * r)); // evalPosition = radiance * pi (area.cpp:103-105)
-        if (is_zero3(E.value)) return ME_FINISHED;
-        M.pImp(1) = T.shade(vt.shade).inv_area * (Em.cdf_hi - Em.cdf_lo);
+        value = thr * (ld3(E.radiance) * (PI_F * r)); // evalPosition = radiance * pi (area.cpp:103-105)
+        if (is_zero3(value)) return;
+        // densities at the connection (emitter supernode -> vt -> vtPred)
+        pImp(1) = T.shade(vt.shade).inv_area * (E.cdf_hi - E.cdf_lo);
         {
             float pd = dp < 0.f ? 0.f : INV_PI_F * dp; // cosine lobe towards vtPred
-            M.pImp(2) = pd * vt.e_cos / vt.e_len2;
+            pImp(2) = pd * vt.e_cos / vt.e_len2;
         }
-        M.pRad(0) = 0.f; // evalPdf(..) * connectionEdge.pdf[ERadiance] = 0, never read (i >= s + 1)
-        E.geo = 1.f;
-        return ME_WALKS_DONE;
+        pRad(0) = 0.f; // evalPdf(..) * connectionEdge.pdf[ERadiance] = 0, never read (i >= s + 1)
+    } else {
+        if (vs.degenerate || vt.degenerate) return;
+        f3 dc = vt.p - vs.p; // vs -> vt
+        const float len2 = dot3(dc, dc);
+        const float len = sqrtf(len2);
+        if (len == 0.f) return;
+        dc = dc * (1.f / len);
+        const DBsdf Bs = T.bsdf(vs.bsdf), Bt = T.bsdf(vt.bsdf);
+        value = thr * vert_eval(P, Bs, vs, dc, true) * vert_eval(P, Bt, vt, -dc, false);
+        if (is_zero3(value)) return;
+        // mutual visibility, ray from vt towards vs (edge.cpp:575-600)
+        const Hit h = trace(P, vt.p, -dc, ray_eps_closest(vt.p), len * (1.f - SHADOW_EPSILON_F), true);
+        R.nrays++;
+        if (h.prim >= 0) return;
+        const float cs = fabsf(dot3(vs.n, dc)), ct = fabsf(dot3(vt.n, dc));
+        geo = cs * ct / len2;
+        // densities at the connection
+        const f3 wos = to_local(vs, dc), wot = to_local(vt, -dc);
+        pImp(s + 1) = vert_pdf_sa(P, Bs, vs, vs.wi, wos, dc) * ct / len2;
+        pRad(s) = vert_pdf_sa(P, Bt, vt, vt.wi, wot, -dc) * cs / len2;
+        // reverse densities towards the predecessors
+        if (vt.kind == BK_END_S) pImp(s + 2) = 1.f;
+        else pImp(s + 2) = bsdf_pdf_sa(Bt, wot, vt.wi) * ((wot.z == 0.f || vt.wi.z == 0.f) ? 0.f : 1.f) * vt.e_cos / vt.e_len2;
+        if (vs.kind == BK_END_E) pRad(s - 1) = 1.f;
+        else pRad(s - 1) = bsdf_pdf_sa(Bs, wos, vs.wi) * ((wos.z == 0.f || vs.wi.z == 0.f) ? 0.f : 1.f) * vs.e_cos / vs.e_len2;
     }
-    if (vs.degenerate || vt.degenerate) return ME_FINISHED;
-    f3 dc = vt.p - vs.p; // vs -> vt
-    const float len2 = dot3(dc, dc);
-    const float len = sqrtf(len2);
-    if (len == 0.f) return ME_FINISHED;
-    dc = dc * (1.f / len);
-    const DBsdf Bs = T.bsdf(vs.bsdf), Bt = T.bsdf(vt.bsdf);
-    E.value = E.thr * vert_eval(P, Bs, vs, dc, true) * vert_eval(P, Bt, vt, -dc, false);
-    if (is_zero3(E.value)) return ME_FINISHED;
-    const float cs = fabsf(dot3(vs.n, dc)), ct = fabsf(dot3(vt.n, dc));
-    E.geo = cs * ct / len2;
-    // densities at the connection and towards the predecessors
-    const f3 wos = to_local(vs, dc), wot = to_local(vt, -dc);
-    M.pImp(s + 1) = vert_pdf_sa(P, Bs, vs, vs.wi, wos, dc) * ct / len2;
-    M.pRad(s) = vert_pdf_sa(P, Bt, vt, vt.wi, wot, -dc) * cs / len2;
-    if (vt.kind == BK_END_S) M.pImp(s + 2) = 1.f;
-    else M.pImp(s + 2) = bsdf_pdf_sa(Bt, wot, vt.wi) * ((wot.z == 0.f || vt.wi.z == 0.f) ? 0.f : 1.f) * vt.e_cos / vt.e_len2;
-    if (vs.kind == BK_END_E) M.pRad(s - 1) = 1.f;
-    else M.pRad(s - 1) = bsdf_pdf_sa(Bs, wos, vs.wi) * ((wos.z == 0.f || vs.wi.z == 0.f) ? 0.f : 1.f) * vs.e_cos / vs.e_len2;
-    // mutual visibility, ray from vt towards vs (edge.cpp:575-600)
-    E.ro = vt.p; E.rd = -dc; E.rtmin = ray_eps_closest(vt.p); E.rtmax = len * (1.f - SHADOW_EPSILON_F);
-    E.R.nrays++;
-    return ME_RAY;
-}
+    if (P.exclude_direct && depth <= 2) return; // pathsampler.cpp:274-280
 
-// Path::miWeight + the splat (pathsampler.cpp:274-313)
-DEV void mmlt_finish(const DParams &P, const MisRows &M, MmltEval &E, bool occluded) {
-    if (occluded) return;
-    const int s = E.s, t = E.t, k = E.k;
-    if (P.exclude_direct && E.depth <= 2) return; // pathsampler.cpp:274-280
-    const uint32_t conn = E.conn;
-    M.pImp(0) = 1.f;
-    M.pRad(k) = 1.f;
+    // ---- Path::miWeight
+    pImp(0) = 1.f;
+    pRad(k) = 1.f;
     for (int i = 1; i <= k - 3; ++i) { // densities next to specular chains: area -> projected solid angle
         if (i == s || !((conn >> i) & 1u) || ((conn >> (i + 1)) & 1u)) continue;
-        M.pImp(i + 1) *= M.gInv(i);
+        pImp(i + 1) *= gInv(i);
     }
     for (int i = k - 1; i >= 3; --i) {
         if (i - 1 == s || !((conn >> i) & 1u) || ((conn >> (i - 1)) & 1u)) continue;
-        M.pRad(i - 1) *= M.gInv(i - 1);
+        pRad(i - 1) *= gInv(i - 1);
     }
+    // The reference sweeps in fp64 (path.cpp:985-1024) so that products of many densities neither overflow nor vanish.
+    // Each density RATIO is formed in fp32 here (one v_rcp instead of a software fp64 division per vertex; a ratio of
+    // two fp32 densities fits fp32 with room to spare), the running products and their squares stay in fp64.
     double weight = 1.0, pdf = 1.0;
     for (int i = s + 1; i < k; ++i) {
-        double next = pdf * (double) M.pImp(i) / (double) M.pRad(i);
+        double next = pdf * (double) (pImp(i) / pRad(i));
         int tPrime = k - i - 1;
         if (((conn >> i) & 1u) && ((conn >> (i + 1)) & 1u) && (P.light_image || tPrime > 1)) weight += next * next;
         pdf = next;
     }
     pdf = 1.0;
     for (int i = s - 1; i >= 0; --i) {
-        double next = pdf * (double) M.pRad(i + 1) / (double) M.pImp(i + 1);
+        double next = pdf * (double) (pRad(i + 1) / pImp(i + 1));
         int tPrime = k - i - 1;
         if (((conn >> i) & 1u) && ((conn >> (i + 1)) & 1u) && (P.light_image || tPrime > 1)) weight += next * next;
         pdf = next;
     }
-    const float miw = (float) (1.0 / weight);
-    const f3 value = E.value * (E.geo * miw * (float) E.nStrats);
-    float sx = 0.f, sy = 0.f;
-    if (t >= 2) { sx = E.film_x; sy = E.film_y; }
-    else if (!cam_sample_position(P, E.cur.p - E.vt.p, sx, sy)) return;
-    E.R.splat.px = sx; E.R.splat.py = sy;
-    E.R.splat.r = value.x; E.R.splat.g = value.y; E.R.splat.b = value.z;
-    E.R.splat.lum = luminance3(value);
-}
+    const float miw = 1.f / (float) weight;
+    value = value * (geo * miw * (float) nStrats);
 
-// run one evaluation to completion
-template <class TablesT>
-DEV void eval_mmlt(const DParams &P, const TablesT &T, MSampler &smp, int depth, uint32_t mis_row, MmltResult &R) {
-    const MisRows M{mis_row, (uint32_t) P.max_depth + 3u, smp.lane};
-    MmltEval E;
-    if (mmlt_begin(P, smp, depth, E)) {
-        for (;;) {
-            if (mmlt_walk_sample(P, T, smp, M, E) != ME_RAY) break;
-            const Hit h = trace(P, E.ro, E.rd, E.rtmin, E.rtmax, false);
-            mmlt_walk_hit(P, T, M, E, h);
-        }
-        const int c = mmlt_connect(P, T, M, E);
-        if (c == ME_RAY) {
-            const Hit h = trace(P, E.ro, E.rd, E.rtmin, E.rtmax, true);
-            mmlt_finish(P, M, E, h.prim >= 0);
-        } else if (c == ME_WALKS_DONE) {
-            mmlt_finish(P, M, E, false);
-        }
-    }
-    R = E.R;
+    // ---- splat position
+    float sx = 0.f, sy = 0.f;
+    if (t >= 2) { sx = film_x; sy = film_y; }
+    else if (!cam_sample_position(P, vs.p - vt.p, sx, sy)) return;
+    R.splat.px = sx; R.splat.py = sy;
+    R.splat.r = value.x; R.splat.g = value.y; R.splat.b = value.z;
+    R.splat.lum = luminance3(value);
 }
