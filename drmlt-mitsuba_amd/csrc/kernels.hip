@@ -576,7 +576,10 @@ DEV unsigned from_upper_u(unsigned u) { // value of lane 32 + (l & 31) for every
     return __builtin_amdgcn_permlane32_swap(u, u, false, false)[1];
 }
 
-template <int FEAT>
+// LDS_TABLES: scene tables staged in LDS (small scenes) or read from HBM/L2 -- a launch-time property, compiled in so
+// that the kernel carries ONE copy of the path step (the two-way runtime branch doubled the hot loop's code and pushed
+// it past the 64 KB instruction cache).
+template <int FEAT, bool LDS_TABLES>
 __global__ void __launch_bounds__(CHAIN_BLOCK) k_mutate_v3(DParams P, uint32_t n_mut, uint32_t mut_base) {
     const uint32_t lane = threadIdx.x;
     const uint32_t sub = lane & 31u;
@@ -616,8 +619,7 @@ __global__ void __launch_bounds__(CHAIN_BLOCK) k_mutate_v3(DParams P, uint32_t n
     LT.bsdf_off = LT.shade_off + (uint32_t) P.n_shade * 16u;
     LT.emit_off = LT.bsdf_off + (uint32_t) P.n_bsdfs * 12u;
     const GlobalTables GT{P.shade, P.bsdfs, P.emitters};
-    const bool lds_tables = P.tables_in_lds != 0;
-    if (lds_tables) stage_tables(P, LT, lane);
+    if (LDS_TABLES) stage_tables(P, LT, lane);
 
     const bool stamps = (P.debug & 128) != 0;
     unsigned long long t_mh = 0, t_trace = 0, t_step = 0, n_iter = 0, n_mh = 0, n_busy = 0;
@@ -671,7 +673,7 @@ __global__ void __launch_bounds__(CHAIN_BLOCK) k_mutate_v3(DParams P, uint32_t n
         ShadowRay sr;
         sr.o = ps.o; sr.d = ps.d; sr.tmin = 0.f; sr.tmax = 0.f; sr.valid = false;
         if (!helper && ps.phase != PH_DONE && ps.phase != PH_IDLE) {
-            if (lds_tables) path_step<true, FEAT>(P, LT, ps, smp, h, occluded == 0u, sr);
+            if (LDS_TABLES) path_step<true, FEAT>(P, LT, ps, smp, h, occluded == 0u, sr);
             else path_step<true, FEAT>(P, GT, ps, smp, h, occluded == 0u, sr);
         }
         // hand the shadow ray of this vertex to the helper lane
@@ -778,9 +780,14 @@ void launch_mutate(const DParams &P, uint32_t n_mut, uint32_t mut_base, hipStrea
         if (P.tables_in_lds) lds += (size_t) P.n_shade * 64 + (size_t) P.n_bsdfs * 48 + (size_t) P.n_emitters * 32;
         // specialisations: 0 = diffuse polygons (Cornell configs); 3 = + rough conductor / dielectric, still flat primitives
         // under the brute-force loop (door config); 15 = everything (spheres, BVH traversal)
-        if (P.features == 0) hipLaunchKernelGGL(k_mutate_v3<0>, dim3((P.n_chains + 31) / 32), block, lds, st, P, n_mut, mut_base);
-        else if ((P.features & ~3) == 0) hipLaunchKernelGGL(k_mutate_v3<3>, dim3((P.n_chains + 31) / 32), block, lds, st, P, n_mut, mut_base);
-        else hipLaunchKernelGGL(k_mutate_v3<15>, dim3((P.n_chains + 31) / 32), block, lds, st, P, n_mut, mut_base);
+        const dim3 g3((P.n_chains + 31) / 32);
+        if (P.tables_in_lds) {
+            if (P.features == 0) hipLaunchKernelGGL((k_mutate_v3<0, true>), g3, block, lds, st, P, n_mut, mut_base);
+            else if ((P.features & ~3) == 0) hipLaunchKernelGGL((k_mutate_v3<3, true>), g3, block, lds, st, P, n_mut, mut_base);
+            else hipLaunchKernelGGL((k_mutate_v3<15, true>), g3, block, lds, st, P, n_mut, mut_base);
+        } else { // large scenes (BVH, tables in HBM/L2): one general variant
+            hipLaunchKernelGGL((k_mutate_v3<15, false>), g3, block, lds, st, P, n_mut, mut_base);
+        }
     } else { // x + first-stage uniforms + second-stage values, one 256 B row per dimension
         size_t lds = (D + 2 * D4) * 64 * sizeof(float);
         if (P.debug & 512) { grid = dim3((P.n_chains + 31) / 32); lds /= 2; }
