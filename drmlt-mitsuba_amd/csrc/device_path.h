@@ -249,10 +249,12 @@ struct LdsSampler {
             const float zl = s2(k);
             return wrap01(large ? zl : ((k & 1u) ? z1 : z0));
         }
-        if (mode == SM_STAGE1) return wrap01(y_raw(k));
-        if (mode == SM_STAGE2) return wrap01(z_raw(k));
-        float du = y_raw(k) - x(k); // Green reverse: y* = z - (y - x)
-        return wrap01(z_raw(k) - du);
+        // iid kernels (Green, Mira): all three modes from unconditional reads and selects
+        const float xk = x(k), a = u1(k), g = s2(k);
+        const float y = large ? a : xk + kelemen_sample(a, KELEMEN_S2);
+        const float z = large ? g : xk + g;
+        const float v = mode == SM_STAGE1 ? y : (mode == SM_STAGE2 ? z : z - (y - xk)); // reverse: y* = z - (y - x)
+        return wrap01(v);
     }
     // Orbital pair (k0, k0 + 1), both components of the first- or second-stage proposal at once (accept(): the
     // per-component form above evaluates the shared radius / angle / rotation twice per pair). Same arithmetic.
