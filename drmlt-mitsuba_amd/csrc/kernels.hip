@@ -418,12 +418,16 @@ DEV int mh_decide(const DParams &P, ChainState &cs, LdsSampler &smp, PathState &
 // DRMLTSampler::accept for dimensions [k0, k1): uCurrent = wrap(chosen proposal)
 DEV void commit_range(LdsSampler &smp, int commit_mode, uint32_t k0, uint32_t k1) {
     smp.mode = commit_mode;
-    if (smp.type == 2 && !smp.large && !(k0 & 1u) && !(k1 & 1u)) { // orbital small step: pair by pair (k0, k1 are pair-aligned)
+    if (smp.type == 2 && !(k0 & 1u) && !(k1 & 1u)) { // orbital: pair by pair (k0, k1 are pair-aligned)
+        const bool second = commit_mode == SM_STAGE2;
         for (uint32_t k = k0; k < k1; k += 2u) {
             float v0, v1;
-            smp.orbital_pair(k, commit_mode == SM_STAGE2, v0, v1);
-            lds_x[k * smp.stride + smp.lane] = wrap01(v0);
-            lds_x[(k + 1u) * smp.stride + smp.lane] = wrap01(v1);
+            smp.orbital_pair(k, second, v0, v1);
+            // a large step's proposal is the uniforms themselves (second stage after a large step: the s2 rows): selects,
+            // so that lanes committing a large step do not drag the wave through the per-component loop
+            const float l0 = second ? smp.s2(k) : smp.u1(k), l1 = second ? smp.s2(k + 1u) : smp.u1(k + 1u);
+            lds_x[k * smp.stride + smp.lane] = wrap01(smp.large ? l0 : v0);
+            lds_x[(k + 1u) * smp.stride + smp.lane] = wrap01(smp.large ? l1 : v1);
         }
         return;
     }
