@@ -192,13 +192,22 @@ def main():
         muts_per_launch = muts / max(launches, 1)
         achieved = bytes_per_mut * muts_per_launch / (launch_ms * 1e-3) / 1e9 if launch_ms > 0 else 0.0
         traffic = None
+        valu_frac = None
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc):
             try:
                 # PMC passes were taken on 1.68e7-mutation launches; traffic is proportional to the mutation count
-                traffic = json.load(open(pmc)).get("hbm_bytes_per_mutation") * muts_per_launch
+                pj = json.load(open(pmc))
+                traffic = pj.get("hbm_bytes_per_mutation") * muts_per_launch
+                # wave-level VALU instructions per mutation (SQ_INSTS_VALU) against 1024 SIMDs issuing one per 4 cycles
+                valu_frac = pj["instructions_per_mutation"]["valu"] * muts_per_launch / (launch_ms * 1e-3) / (1024 * 2.4e9 / 4)
             except Exception:
                 traffic = None
+        # SURVEY 8(d) asks for three separately labelled byte figures: (i) measured HBM traffic, (ii) algorithmic bytes
+        # (= roofline.achieved), (iii) bytes REQUESTED per lane including what the scalar cache / LDS serves (every ray
+        # tests every 64-byte primitive record of this BVH-less scene) -- (iii) is never used as the roofline figure
+        n_records = len(sd.shapes)   # rectangles stay one record each (quad test); no triangle meshes in this scene
+        requested = (rays / muts) * n_records * 64.0 + bytes_per_mut
         out = {
             "metric": "mutations/sec (accepted+rejected)", "value": value, "unit": "mutations/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -213,7 +222,11 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "k_mutate_v3", "avg_launch_ms": launch_ms, "launches": launches,
                          "algorithmic_bytes_per_mutation": bytes_per_mut,
-                         "mutations_per_launch": muts_per_launch},
+                         "mutations_per_launch": muts_per_launch,
+                         "hbm_measured_gbs": (traffic / (launch_ms * 1e-3) / 1e9) if traffic and launch_ms > 0 else None,
+                         "requested_gbs_incl_cache_served": requested * muts_per_launch / (launch_ms * 1e-3) / 1e9
+                         if launch_ms > 0 else None,
+                         "valu_issue_frac_at_2.4GHz": valu_frac},
             "accepted_mutations_per_s": world * accepted / elapsed,
             "path_evals_per_s": world * evals / elapsed, "rays_per_s": world * rays / elapsed,
             "acceptance": {k: round(v, 5) for k, v in st1.ratios().items()},
