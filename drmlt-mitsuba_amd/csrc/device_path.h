@@ -372,57 +372,53 @@ template <int FEAT = 15> DEV Hit trace_brute(const DParams &P, f3 o, f3 d, float
     return h;
 }
 
-// 2-wide BVH traversal with a short per-lane stack; leaves index into the prim array.
+// 2-wide BVH traversal, one ray per lane. The per-lane stack lives in LDS (a stack in registers is indexed by a
+// divergent sp: the compiler turns every push and pop into a compare-and-select over all entries, ~100 VALU per node
+// against ~30 for the two box tests). Column layout [slot][lane]: a push or pop is one ds access without bank conflicts.
+// "while-while" order: a lane descends through inner nodes until it holds a leaf, then all lanes holding leaves test
+// primitives together. Leaves travel through `cur` and the stack as ~((first << 3) | count), count <= 4 (bvh_build.h).
+#define BVH_STACK 24
 DEV Hit trace_bvh(const DParams &P, f3 o, f3 d, float tmin, float tmax, bool any_hit) {
+    __shared__ int bvh_stack[BVH_STACK * 64];
+    int *const stk = bvh_stack + (threadIdx.x & 63u); // every kernel that traces runs one wave per workgroup
     Hit h{-1, tmax, 0.f, 0.f};
-    f3 inv = mk3(1.f / d.x, 1.f / d.y, 1.f / d.z);
-    int stack[24];
+    const f3 inv = mk3(1.f / d.x, 1.f / d.y, 1.f / d.z);
+    const f3 oi = mk3(-o.x * inv.x, -o.y * inv.y, -o.z * inv.z);
     int sp = 0;
-    int node = 0;
+    int cur = 0;
     for (;;) {
-        const DBvhNode N = P.bvh[node];
-        float t0x = (N.lo0[0] - o.x) * inv.x, t1x = (N.hi0[0] - o.x) * inv.x;
-        float t0y = (N.lo0[1] - o.y) * inv.y, t1y = (N.hi0[1] - o.y) * inv.y;
-        float t0z = (N.lo0[2] - o.z) * inv.z, t1z = (N.hi0[2] - o.z) * inv.z;
-        float nearA = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fmaxf(fminf(t0z, t1z), tmin));
-        float farA = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fminf(fmaxf(t0z, t1z), h.t));
-        t0x = (N.lo1[0] - o.x) * inv.x; t1x = (N.hi1[0] - o.x) * inv.x;
-        t0y = (N.lo1[1] - o.y) * inv.y; t1y = (N.hi1[1] - o.y) * inv.y;
-        t0z = (N.lo1[2] - o.z) * inv.z; t1z = (N.hi1[2] - o.z) * inv.z;
-        float nearB = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fmaxf(fminf(t0z, t1z), tmin));
-        float farB = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fminf(fmaxf(t0z, t1z), h.t));
-        bool hitA = nearA <= farA, hitB = nearB <= farB;
-        int next = -1;
-        // leaves are intersected immediately; inner children are pushed far-first
-        int cA = N.c0, cB = N.c1, nA = N.n0, nB = N.n1;
-        if (hitA && cA < 0) {
-            int first = ~cA;
-            for (int i = 0; i < nA; ++i) intersect_prim(P.prims[first + i], P.prims[first + i].shade, o, d, tmin, h);
-            hitA = false;
+        while (cur >= 0) {
+            const DBvhNode N = P.bvh[cur];
+            float t0x = fmaf(N.lo0[0], inv.x, oi.x), t1x = fmaf(N.hi0[0], inv.x, oi.x);
+            float t0y = fmaf(N.lo0[1], inv.y, oi.y), t1y = fmaf(N.hi0[1], inv.y, oi.y);
+            float t0z = fmaf(N.lo0[2], inv.z, oi.z), t1z = fmaf(N.hi0[2], inv.z, oi.z);
+            const float nearA = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fmaxf(fminf(t0z, t1z), tmin));
+            const float farA = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fminf(fmaxf(t0z, t1z), h.t));
+            t0x = fmaf(N.lo1[0], inv.x, oi.x); t1x = fmaf(N.hi1[0], inv.x, oi.x);
+            t0y = fmaf(N.lo1[1], inv.y, oi.y); t1y = fmaf(N.hi1[1], inv.y, oi.y);
+            t0z = fmaf(N.lo1[2], inv.z, oi.z); t1z = fmaf(N.hi1[2], inv.z, oi.z);
+            const float nearB = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fmaxf(fminf(t0z, t1z), tmin));
+            const float farB = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fminf(fmaxf(t0z, t1z), h.t));
+            const bool hitA = nearA <= farA, hitB = nearB <= farB;
+            const int cA = N.c0 < 0 ? ~((~N.c0 << 3) | N.n0) : N.c0;
+            const int cB = N.c1 < 0 ? ~((~N.c1 << 3) | N.n1) : N.c1;
+            if (hitA && hitB) {
+                const bool aFirst = nearA <= nearB;
+                cur = aFirst ? cA : cB;
+                if (sp < BVH_STACK) { stk[sp * 64] = aFirst ? cB : cA; sp++; }
+            } else if (hitA || hitB) {
+                cur = hitA ? cA : cB;
+            } else {
+                if (sp == 0) return h;
+                cur = stk[--sp * 64];
+            }
         }
-        if (hitB && cB < 0) {
-            int first = ~cB;
-            if (nearB <= h.t)
-                for (int i = 0; i < nB; ++i) intersect_prim(P.prims[first + i], P.prims[first + i].shade, o, d, tmin, h);
-            hitB = false;
-        }
+        const int first = ~cur >> 3, n = ~cur & 7;
+        for (int i = 0; i < n; ++i) intersect_prim(P.prims[first + i], P.prims[first + i].shade, o, d, tmin, h);
         if (any_hit && h.prim >= 0) return h;
-        if (hitA && hitB) {
-            bool aFirst = nearA <= nearB;
-            next = aFirst ? cA : cB;
-            if (sp < 24) stack[sp++] = aFirst ? cB : cA;
-        } else if (hitA) {
-            next = cA;
-        } else if (hitB) {
-            next = cB;
-        }
-        if (next < 0) {
-            if (sp == 0) break;
-            next = stack[--sp];
-        }
-        node = next;
+        if (sp == 0) return h;
+        cur = stk[--sp * 64];
     }
-    return h;
 }
 
 // Brute-force loop for scenes of flat primitives only (rectangles, triangles, merged pairs). Same tests as

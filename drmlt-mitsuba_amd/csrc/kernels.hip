@@ -10,7 +10,7 @@
 
 #include "kernel_common.h"
 
-__global__ void __launch_bounds__(256) k_bootstrap(DParams P, uint32_t n, float *lum_out) {
+__global__ void __launch_bounds__(64) k_bootstrap(DParams P, uint32_t n, float *lum_out) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     Sampler smp;
@@ -21,7 +21,7 @@ __global__ void __launch_bounds__(256) k_bootstrap(DParams P, uint32_t n, float 
     lum_out[i] = s.lum;
 }
 
-__global__ void __launch_bounds__(256) k_init_chains(DParams P, const uint32_t *seed_index, const float *seed_lum) {
+__global__ void __launch_bounds__(64) k_init_chains(DParams P, const uint32_t *seed_index, const float *seed_lum) {
     uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= P.n_chains) return;
     Sampler smp;
@@ -714,7 +714,7 @@ __global__ void __launch_bounds__(CHAIN_BLOCK) k_mutate_v3(DParams P, uint32_t n
         for (int i = 0; i < 9; ++i) atomicAdd(P.stats + i, v[i]);
 }
 
-__global__ void __launch_bounds__(256) k_eval_paths(DParams P, const float *u, uint32_t n, uint32_t dim, float *out8) {
+__global__ void __launch_bounds__(64) k_eval_paths(DParams P, const float *u, uint32_t n, uint32_t dim, float *out8) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     Sampler smp;
@@ -728,7 +728,7 @@ __global__ void __launch_bounds__(256) k_eval_paths(DParams P, const float *u, u
     o[6] = __int_as_float((int) nd); o[7] = __int_as_float((int) nr);
 }
 
-__global__ void __launch_bounds__(256) k_render_pt(DParams P, uint64_t n_samples, uint32_t stream, float scale) {
+__global__ void __launch_bounds__(64) k_render_pt(DParams P, uint64_t n_samples, uint32_t stream, float scale) {
     uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
     const uint64_t stride = (uint64_t) gridDim.x * blockDim.x;
     for (; i < n_samples; i += stride) {
@@ -765,10 +765,10 @@ __global__ void __launch_bounds__(256) k_develop(const float *film, const float 
 
 // ---- host-callable launchers (C++ linkage, used by drmlt_capi.cpp) --------------------------
 void launch_bootstrap(const DParams &P, uint32_t n, float *lum_out, hipStream_t st) {
-    hipLaunchKernelGGL(k_bootstrap, dim3((n + 255) / 256), dim3(256), 0, st, P, n, lum_out);
+    hipLaunchKernelGGL(k_bootstrap, dim3((n + 63) / 64), dim3(64), 0, st, P, n, lum_out);
 }
 void launch_init_chains(const DParams &P, const uint32_t *seed_index, const float *seed_lum, hipStream_t st) {
-    hipLaunchKernelGGL(k_init_chains, dim3((P.n_chains + 255) / 256), dim3(256), 0, st, P, seed_index, seed_lum);
+    hipLaunchKernelGGL(k_init_chains, dim3((P.n_chains + 63) / 64), dim3(64), 0, st, P, seed_index, seed_lum);
 }
 void launch_mutate_pssmlt(const DParams &P, uint32_t n_mut, uint32_t mut_base, hipStream_t st) {
     hipLaunchKernelGGL(k_mutate_pssmlt, dim3((P.n_chains + CHAIN_BLOCK - 1) / CHAIN_BLOCK), dim3(CHAIN_BLOCK), (size_t) P.eff_dim * 64 * sizeof(float), st, P,
@@ -783,11 +783,12 @@ void launch_mutate(const DParams &P, uint32_t n_mut, uint32_t mut_base, hipStrea
         size_t lds = (D + 2 * D4) * 32 * sizeof(float);
         if (P.tables_in_lds) lds += (size_t) P.n_shade * 64 + (size_t) P.n_bsdfs * 48 + (size_t) P.n_emitters * 32;
         // specialisations: 0 = diffuse polygons (Cornell configs); 3 = + rough conductor / dielectric, still flat primitives
-        // under the brute-force loop (door config); 15 = everything (spheres, BVH traversal)
+        // under the brute-force loop (door config); 7 = + spheres; 15 = everything (BVH traversal, with its 6 KB LDS stack)
         const dim3 g3((P.n_chains + 31) / 32);
         if (P.tables_in_lds) {
             if (P.features == 0) hipLaunchKernelGGL((k_mutate_v3<0, true>), g3, block, lds, st, P, n_mut, mut_base);
             else if ((P.features & ~3) == 0) hipLaunchKernelGGL((k_mutate_v3<3, true>), g3, block, lds, st, P, n_mut, mut_base);
+            else if ((P.features & 8) == 0) hipLaunchKernelGGL((k_mutate_v3<7, true>), g3, block, lds, st, P, n_mut, mut_base);
             else hipLaunchKernelGGL((k_mutate_v3<15, true>), g3, block, lds, st, P, n_mut, mut_base);
         } else { // large scenes (BVH, tables in HBM/L2): one general variant
             hipLaunchKernelGGL((k_mutate_v3<15, false>), g3, block, lds, st, P, n_mut, mut_base);
@@ -800,10 +801,10 @@ void launch_mutate(const DParams &P, uint32_t n_mut, uint32_t mut_base, hipStrea
     }
 }
 void launch_eval_paths(const DParams &P, const float *u, uint32_t n, uint32_t dim, float *out8, hipStream_t st) {
-    hipLaunchKernelGGL(k_eval_paths, dim3((n + 255) / 256), dim3(256), 0, st, P, u, n, dim, out8);
+    hipLaunchKernelGGL(k_eval_paths, dim3((n + 63) / 64), dim3(64), 0, st, P, u, n, dim, out8);
 }
 void launch_render_pt(const DParams &P, uint64_t n_samples, uint32_t stream, float scale, hipStream_t st) {
-    hipLaunchKernelGGL(k_render_pt, dim3(4096), dim3(256), 0, st, P, n_samples, stream, scale);
+    hipLaunchKernelGGL(k_render_pt, dim3(16384), dim3(64), 0, st, P, n_samples, stream, scale);
 }
 void launch_lum_sum(const float *film, const float *importance, uint32_t n_pixels, double *sum, hipStream_t st) {
     hipLaunchKernelGGL(k_lum_sum, dim3(256), dim3(256), 0, st, film, importance, n_pixels, sum);
