@@ -1,5 +1,6 @@
 #!/bin/bash
 # usage: tools/pmc_run.sh <tag> "<counter list>" ...   (one rocprofv3 --pmc pass per counter group)
+# PMC_CMD="python3 <script> args" replaces the default workload (config 2, one 1.68e7-mutation launch)
 set -e
 cd /tmp && export TMPDIR=/tmp
 tag=$1; shift
@@ -8,7 +9,7 @@ for grp in "$@"; do
   out=$GRAFT_REPO_ROOT/gpurun_out/pmc_${tag}_$i
   echo "pass $i: $grp" >> $GRAFT_REPO_ROOT/gpurun_out/pmc_${tag}_progress.txt
   # a counter group the hardware cannot collect in one pass aborts rocprofv3 and can leave the child hanging: bound it
-  timeout -k 10 180 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $out -- python3 $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 0 --spp 64 --no-cpu-baseline --no-quality > $out.log 2>&1 || { tail -5 $out.log; exit 1; }
+  timeout -k 10 180 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $out -- ${PMC_CMD:-python3 $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 0 --spp 64 --no-cpu-baseline --no-quality} > $out.log 2>&1 || { tail -5 $out.log; exit 1; }
   i=$((i+1))
 done
 python3 - <<PY
