@@ -33,10 +33,19 @@ struct Box {
 constexpr int kLeafMax = 4;
 constexpr int kBins = 16;
 
+// inner levels of a subtree over n primitives built by median splits
+inline int median_depth(int n) {
+    int d = 0;
+    while (n > kLeafMax) { n = (n + 1) / 2; d++; }
+    return d;
+}
+
 struct Builder {
     const std::vector<PrimBounds> &pb;
     std::vector<int> &order; // primitive indices, leaf ranges are contiguous
     std::vector<DBvhNode> &nodes;
+    int max_depth = BVH_STACK; // inner nodes on any root-to-leaf path: the traversal pushes at most one entry per level
+    int median_splits = 0;
 
     Box range_box(int first, int count) const {
         Box b;
@@ -93,17 +102,32 @@ struct Builder {
         return nl;
     }
 
+    // median split along the widest centroid axis: bounds the depth where SAH would build a degenerate chain
+    int split_median(int first, int count) {
+        Box cb;
+        auto centre = [&](int idx, int k) { return 0.5f * (pb[idx].lo[k] + pb[idx].hi[k]); };
+        for (int i = 0; i < count; ++i)
+            for (int k = 0; k < 3; ++k) { float c = centre(order[first + i], k); cb.lo[k] = std::min(cb.lo[k], c); cb.hi[k] = std::max(cb.hi[k], c); }
+        int axis = 0;
+        for (int k = 1; k < 3; ++k) if (cb.hi[k] - cb.lo[k] > cb.hi[axis] - cb.lo[axis]) axis = k;
+        const int nl = (count + 1) / 2;
+        std::nth_element(order.begin() + first, order.begin() + first + nl, order.begin() + first + count,
+                         [&](int a, int b) { return centre(a, axis) < centre(b, axis); });
+        return nl;
+    }
+
     // builds the subtree over order[first, first+count) (count > kLeafMax) and returns its node index
-    int build(int first, int count) {
+    int build(int first, int count, int depth = 0) {
         int self = (int) nodes.size();
         nodes.emplace_back();
         Box bounds = range_box(first, count);
         int nl = split(first, count, bounds);
+        if (depth + 1 + median_depth(std::max(nl, count - nl)) > max_depth) { nl = split_median(first, count); median_splits++; }
         int nr = count - nl;
         Box bl = range_box(first, nl), br = range_box(first + nl, nr);
         int c0, c1, n0 = 0, n1 = 0;
-        if (nl <= kLeafMax) { c0 = ~first; n0 = nl; } else { c0 = build(first, nl); }
-        if (nr <= kLeafMax) { c1 = ~(first + nl); n1 = nr; } else { c1 = build(first + nl, nr); }
+        if (nl <= kLeafMax) { c0 = ~first; n0 = nl; } else { c0 = build(first, nl, depth + 1); }
+        if (nr <= kLeafMax) { c1 = ~(first + nl); n1 = nr; } else { c1 = build(first + nl, nr, depth + 1); }
         DBvhNode &N = nodes[self];
         for (int k = 0; k < 3; ++k) { N.lo0[k] = bl.lo[k]; N.hi0[k] = bl.hi[k]; N.lo1[k] = br.lo[k]; N.hi1[k] = br.hi[k]; }
         N.c0 = c0; N.c1 = c1; N.n0 = n0; N.n1 = n1;
@@ -113,14 +137,15 @@ struct Builder {
 
 } // namespace bvh_detail
 
-// nodes[0] is the root. `order[i]` = original index of the primitive stored in slot i.
-inline void build_bvh(const std::vector<PrimBounds> &pb, std::vector<DBvhNode> &nodes, std::vector<int> &order) {
+// nodes[0] is the root; returns the number of depth-bounded (median) splits. `order[i]` = original index of the primitive stored in slot i.
+inline int build_bvh(const std::vector<PrimBounds> &pb, std::vector<DBvhNode> &nodes, std::vector<int> &order, int max_depth = BVH_STACK) {
     using namespace bvh_detail;
     const int n = (int) pb.size();
     order.resize(n);
     for (int i = 0; i < n; ++i) order[i] = i;
     nodes.clear();
     Builder b{pb, order, nodes};
+    b.max_depth = std::max(std::min(max_depth, BVH_STACK), median_depth(n)); // never below what a balanced tree needs
     if (n <= kLeafMax) {
         // single leaf under a root whose second child is empty
         nodes.emplace_back();
@@ -128,7 +153,8 @@ inline void build_bvh(const std::vector<PrimBounds> &pb, std::vector<DBvhNode> &
         DBvhNode &N = nodes[0];
         for (int k = 0; k < 3; ++k) { N.lo0[k] = box.lo[k]; N.hi0[k] = box.hi[k]; N.lo1[k] = FLT_MAX; N.hi1[k] = -FLT_MAX; }
         N.c0 = ~0; N.n0 = n; N.c1 = ~0; N.n1 = 0;
-        return;
+        return 0;
     }
     b.build(0, n);
+    return b.median_splits; // nodes where the depth bound overrode the SAH split
 }

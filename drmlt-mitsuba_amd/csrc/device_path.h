@@ -376,8 +376,7 @@ template <int FEAT = 15> DEV Hit trace_brute(const DParams &P, f3 o, f3 d, float
 // divergent sp: the compiler turns every push and pop into a compare-and-select over all entries, ~100 VALU per node
 // against ~30 for the two box tests). Column layout [slot][lane]: a push or pop is one ds access without bank conflicts.
 // "while-while" order: a lane descends through inner nodes until it holds a leaf, then all lanes holding leaves test
-// primitives together. Leaves travel through `cur` and the stack as ~((first << 3) | count), count <= 4 (bvh_build.h).
-#define BVH_STACK 24
+// primitives together. The builder bounds the tree depth by BVH_STACK, so a push never overflows. Leaves travel through `cur` and the stack as ~((first << 3) | count), count <= 4 (bvh_build.h).
 DEV Hit trace_bvh(const DParams &P, f3 o, f3 d, float tmin, float tmax, bool any_hit) {
     __shared__ int bvh_stack[BVH_STACK * 64];
     int *const stk = bvh_stack + (threadIdx.x & 63u); // every kernel that traces runs one wave per workgroup
@@ -405,7 +404,8 @@ DEV Hit trace_bvh(const DParams &P, f3 o, f3 d, float tmin, float tmax, bool any
             if (hitA && hitB) {
                 const bool aFirst = nearA <= nearB;
                 cur = aFirst ? cA : cB;
-                if (sp < BVH_STACK) { stk[sp * 64] = aFirst ? cB : cA; sp++; }
+                stk[sp * 64] = aFirst ? cB : cA;
+                sp++;
             } else if (hitA || hitB) {
                 cur = hitA ? cA : cB;
             } else {

@@ -62,6 +62,7 @@ struct DEmitter {
     float pad[2];
 };
 
+#define BVH_STACK 24 // per-lane traversal stack entries (LDS) = bound on the BVH depth (bvh_build.h)
 struct DBvhNode {      // 64 B
     float lo0[3], hi0[3]; // child 0 box
     float lo1[3], hi1[3]; // child 1 box

@@ -74,6 +74,7 @@ struct drmlt_ctx {
     DParams P{};
     std::string error;
 
+    int bvh_depth = 0;
     DevBuf d_prims, d_shade, d_bsdfs, d_emitters, d_bvh, d_lut, d_film, d_x, d_cur, d_stats, d_err, d_scratch, d_chain_i, d_importance, d_bd_verts, d_bd_lists, d_prims_flat;
     std::vector<DPrim> prims;
     std::vector<DShade> shade;
@@ -395,7 +396,22 @@ drmlt_ctx *drmlt_create(const drmlt_config *cfg, const drmlt_scene *scene, int d
     P.use_bvh = (int) ctx->prims.size() > bvh_threshold ? 1 : 0;
     if (P.use_bvh) {
         std::vector<int> order;
-        build_bvh(bounds, nodes, order);
+        int max_depth = BVH_STACK;
+        if (const char *t = getenv("DRMLT_BVH_MAX_DEPTH")) max_depth = atoi(t); // tests: exercise the depth-bounded splits
+        const int median_splits = build_bvh(bounds, nodes, order, max_depth);
+        // the kernels' per-lane stack holds BVH_STACK entries and does not check for overflow: verify the builder's bound
+        std::vector<std::pair<int, int>> todo{{0, 1}};
+        int depth = 0;
+        while (!todo.empty()) {
+            const auto [node, d] = todo.back();
+            todo.pop_back();
+            depth = std::max(depth, d);
+            if (nodes[node].c0 >= 0) todo.push_back({nodes[node].c0, d + 1});
+            if (nodes[node].c1 >= 0) todo.push_back({nodes[node].c1, d + 1});
+        }
+        if (depth > BVH_STACK) return bail(ctx, "internal error: BVH deeper than the traversal stack");
+        ctx->bvh_depth = depth;
+        if (getenv("DRMLT_VERBOSE")) fprintf(stderr, "[drmlt] BVH: %zu primitives, %zu nodes, depth %d (stack %d), %d median splits\n", order.size(), nodes.size(), depth, BVH_STACK, median_splits);
         // intersection records go into leaf order; shading records stay where the emitters expect them
         std::vector<DPrim> np(order.size());
         for (size_t i = 0; i < order.size(); ++i) np[i] = ctx->prims[order[i]];

@@ -71,6 +71,38 @@ def test_bvh_and_brute_force_agree_on_device(pkg, ob, native_lib):
     assert np.allclose(a["luminance"][same], b["luminance"][same], rtol=1e-4, atol=1e-6)
 
 
+def test_deep_bvh_stays_within_the_traversal_stack(pkg, ob, native_lib, capfd):
+    """Geometrically shrinking triangles make SAH peel a few primitives per level (a chain 24 levels deep for this
+    scene). The kernels' stack holds 24 entries, so the builder bounds the depth by falling back to median splits;
+    DRMLT_BVH_MAX_DEPTH lowers the bound so that the fallback is exercised, and traversal must still agree with the
+    brute-force loop."""
+    import re
+    sd = pkg.scenes.cornell_c2(64)
+    white = 0
+    for i in range(160):
+        s = 0.7 * 0.5 ** (i * 0.3)        # down to 2e-15: areas stay representable in fp32
+        x = 0.9 * 0.5 ** (i * 0.3)        # clustered towards the origin, where fp32 keeps resolving them
+        sd.triangle((x, 0.0, 0.0), (x + 0.3 * s, 0.0, 0.0), (x, 0.3 * s, 0.1 * s), white)
+    u = np.random.default_rng(5).random((8192, 50), dtype=np.float32)
+    cfg = pkg.abi.make_config(type="orbital", max_depth=8, direct_samples=-1, work_units=64)
+    os.environ["DRMLT_BVH_THRESHOLD"] = "1000000"
+    a = pkg.Context(cfg, sd).eval_paths(u)
+    os.environ["DRMLT_BVH_THRESHOLD"] = "0"
+    os.environ["DRMLT_VERBOSE"] = "1"
+    try:
+        for bound, want_median in (("24", False), ("10", True)):
+            os.environ["DRMLT_BVH_MAX_DEPTH"] = bound
+            b = pkg.Context(cfg, sd).eval_paths(u)
+            log = capfd.readouterr().err
+            m = re.search(r"BVH: (\d+) primitives, (\d+) nodes, depth (\d+) \(stack 24\), (\d+) median splits", log)
+            assert m and int(m.group(3)) <= int(bound) and (int(m.group(4)) > 0) == want_median, log
+            same = a["n_dims"] == b["n_dims"]
+            assert same.mean() > 0.999
+            assert np.allclose(a["luminance"][same], b["luminance"][same], rtol=1e-4, atol=1e-6)
+    finally:
+        del os.environ["DRMLT_BVH_THRESHOLD"], os.environ["DRMLT_VERBOSE"], os.environ["DRMLT_BVH_MAX_DEPTH"]
+
+
 def test_bootstrap_and_seed_replay(pkg, ob, native_lib):
     sd = pkg.scenes.cornell_c2(64)
     cfg, ctx, orc = make(pkg, ob, sd, type="orbital", work_units=4096, sample_count=1)

@@ -1,6 +1,7 @@
 """Throughput of the technique=bdpt chain kernel (Cornell config-2 scene, orbital, directSampling=false)."""
 import sys, time
-sys.path.insert(0, '.')
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import __graft_entry__ as g
 pkg = g.load_package()
 abi = pkg.abi

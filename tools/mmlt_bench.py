@@ -1,7 +1,8 @@
 """Throughput of the technique=mmlt chain kernel on BASELINE config 5 (glass caustic, orbital, fixEmitterPath)."""
 import sys, time
 import numpy as np
-sys.path.insert(0, '.')
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import __graft_entry__ as g
 pkg = g.load_package()
 abi = pkg.abi
