@@ -1,4 +1,4 @@
-// Host-side builder of the 2-wide BVH the kernels traverse (binned SAH, leaves <= 4 prims).
+// Host-side builder of the 2-wide BVH the kernels traverse (binned SAH, one primitive per leaf by default).
 // The reference uses a SAH kd-tree (src/librender/skdtree.cpp, sahkdtree3.h); a closest-hit
 // query returns the same primitive through either structure, so the builder is free to pick
 // the layout that suits the GPU: one 64 B node = both child boxes, fetched as one line.
@@ -7,6 +7,7 @@
 
 #include <algorithm>
 #include <cfloat>
+#include <cstdlib>
 #include <vector>
 
 struct PrimBounds {
@@ -30,13 +31,14 @@ struct Box {
     }
 };
 
-constexpr int kLeafMax = 4;
+constexpr int kLeafMax = 1; // measured on the 2000-triangle soup: 1 -> 2.08e8, 2 or 3 -> 1.84e8, 4 -> 1.80e8 mutations/s (no leaf loop to diverge in)
+constexpr int kLeafCap = 4; // DRMLT_BVH_LEAF may raise it to this (the leaf reference keeps 3 bits for the count)
 constexpr int kBins = 16;
 
 // inner levels of a subtree over n primitives built by median splits
-inline int median_depth(int n) {
+inline int median_depth(int n, int leaf_max) {
     int d = 0;
-    while (n > kLeafMax) { n = (n + 1) / 2; d++; }
+    while (n > leaf_max) { n = (n + 1) / 2; d++; }
     return d;
 }
 
@@ -46,6 +48,7 @@ struct Builder {
     std::vector<DBvhNode> &nodes;
     int max_depth = BVH_STACK; // inner nodes on any root-to-leaf path: the traversal pushes at most one entry per level
     int median_splits = 0;
+    int leaf_max = kLeafMax;
 
     Box range_box(int first, int count) const {
         Box b;
@@ -122,12 +125,12 @@ struct Builder {
         nodes.emplace_back();
         Box bounds = range_box(first, count);
         int nl = split(first, count, bounds);
-        if (depth + 1 + median_depth(std::max(nl, count - nl)) > max_depth) { nl = split_median(first, count); median_splits++; }
+        if (depth + 1 + median_depth(std::max(nl, count - nl), leaf_max) > max_depth) { nl = split_median(first, count); median_splits++; }
         int nr = count - nl;
         Box bl = range_box(first, nl), br = range_box(first + nl, nr);
         int c0, c1, n0 = 0, n1 = 0;
-        if (nl <= kLeafMax) { c0 = ~first; n0 = nl; } else { c0 = build(first, nl, depth + 1); }
-        if (nr <= kLeafMax) { c1 = ~(first + nl); n1 = nr; } else { c1 = build(first + nl, nr, depth + 1); }
+        if (nl <= leaf_max) { c0 = ~first; n0 = nl; } else { c0 = build(first, nl, depth + 1); }
+        if (nr <= leaf_max) { c1 = ~(first + nl); n1 = nr; } else { c1 = build(first + nl, nr, depth + 1); }
         DBvhNode &N = nodes[self];
         for (int k = 0; k < 3; ++k) { N.lo0[k] = bl.lo[k]; N.hi0[k] = bl.hi[k]; N.lo1[k] = br.lo[k]; N.hi1[k] = br.hi[k]; }
         N.c0 = c0; N.c1 = c1; N.n0 = n0; N.n1 = n1;
@@ -145,8 +148,9 @@ inline int build_bvh(const std::vector<PrimBounds> &pb, std::vector<DBvhNode> &n
     for (int i = 0; i < n; ++i) order[i] = i;
     nodes.clear();
     Builder b{pb, order, nodes};
-    b.max_depth = std::max(std::min(max_depth, BVH_STACK), median_depth(n)); // never below what a balanced tree needs
-    if (n <= kLeafMax) {
+    if (const char *t = getenv("DRMLT_BVH_LEAF")) b.leaf_max = std::max(1, std::min(kLeafCap, atoi(t)));
+    b.max_depth = std::max(std::min(max_depth, BVH_STACK), median_depth(n, b.leaf_max)); // never below what a balanced tree needs
+    if (n <= b.leaf_max) {
         // single leaf under a root whose second child is empty
         nodes.emplace_back();
         Box box = b.range_box(0, n);
