@@ -83,6 +83,8 @@ DEV void eval_bdpt(const DParams &P, const TablesT &T, MSampler &smp, uint32_t c
 
     R.lum = 0.f; R.nrays = 0u; R.n_sensor = R.n_emitter = 0u; R.n_more = 0; R.has_main = false;
     smp.reset_caches();
+    const bool stamps = (P.debug & 128) != 0; // diagnostic: per-wave cycles of the walks / the pair loop -> stats[16], [17]
+    const unsigned long long st0 = stamps ? __builtin_amdgcn_s_memtime() : 0ull;
 
     // ------------------------------------------------------------ the two random walks (emitter first, :331-340)
     int nE = 1, nS = 1;            // vertices of each subpath, supernode included
@@ -265,6 +267,7 @@ DEV void eval_bdpt(const DParams &P, const TablesT &T, MSampler &smp, uint32_t c
 #undef WALK_FAIL
     }
 
+    const unsigned long long st1 = stamps ? __builtin_amdgcn_s_memtime() : 0ull;
     // ------------------------------------------------------------ the splat list
     float total_lum = 0.f;
     f3 main_v = mk3(0.f, 0.f, 0.f);
@@ -381,6 +384,12 @@ DEV void eval_bdpt(const DParams &P, const TablesT &T, MSampler &smp, uint32_t c
                 main_v = main_v + value;
             }
             total_lum += luminance3(value);
+        }
+    }
+    if (stamps) {
+        const unsigned long long st2 = __builtin_amdgcn_s_memtime();
+        if (__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == 0u) { // first active lane
+            atomicAdd(P.stats + 16, st1 - st0); atomicAdd(P.stats + 17, st2 - st1); atomicAdd(P.stats + 19, 1ull);
         }
     }
     lrow(BL_LUM) = total_lum;

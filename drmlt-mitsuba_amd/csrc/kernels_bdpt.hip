@@ -134,6 +134,7 @@ __global__ void __launch_bounds__(CHAIN_BLOCK) k_mutate_bdpt(DParams P, uint32_t
     const bool amap = P.acceptance_map != 0;
     const bool mix = P.use_mixture != 0;
 
+    const unsigned long long k0 = (P.debug & 128) ? __builtin_amdgcn_s_memtime() : 0ull;
     if (live) for (uint32_t it = 0; it < n_mut; ++it) {
         const uint32_t m = mut_base + it;
         const u4 coins = philox4x32_10(P.key0, P.key1, 0u, m, smp.chain, TAG_COIN);
@@ -275,6 +276,7 @@ __global__ void __launch_bounds__(CHAIN_BLOCK) k_mutate_bdpt(DParams P, uint32_t
     v[8] = wave_sum(ct.rays);
     if (lane == 0)
         for (int i = 0; i < 9; ++i) atomicAdd(P.stats + i, v[i]);
+    if ((P.debug & 128) && lane == 0) atomicAdd(P.stats + 18, __builtin_amdgcn_s_memtime() - k0); // whole chain loop, per wave
 }
 
 // u: [sensor S | emitter E] per point (dim >= S + E); out: rows of `stride` floats:
