@@ -811,7 +811,8 @@ int drmlt_stats_get(drmlt_ctx *ctx, drmlt_stats *o) {
     else if (ctx->P.debug & 128) // diagnostic stamps of k_mutate_v2 / v3
         fprintf(stderr, "[drmlt stamps] cycles: mh %llu trace %llu step %llu | iterations %llu mh-branches %llu tracing-lanes %llu\n",
                 v[16], v[17], v[18], v[19], v[20], v[21]),
-        fprintf(stderr, "[drmlt stamps] mh sections: decide+splat %llu commit %llu start %llu fill %llu\n", v[22], v[23], v[24], v[25]);
+        fprintf(stderr, "[drmlt stamps] mh sections: decide+splat %llu commit %llu start %llu fill %llu\n", v[22], v[23], v[24], v[25]),
+        fprintf(stderr, "[drmlt stamps] iterations by chains tracing (of 32): 0: %llu, 1-4: %llu, 5-8: %llu, 9-16: %llu, 17-24: %llu, 25-32: %llu\n", v[26], v[27], v[28], v[29], v[30], v[31]);
     memset(o, 0, sizeof *o);
     const uint64_t M = ctx->mutations;
     const uint64_t n_large = v[0], acc1_l = v[1], acc1_b = v[2], sec_l = v[3], sec_b = v[4], acc2_l = v[5], acc2_b = v[6], n_rev = v[7];

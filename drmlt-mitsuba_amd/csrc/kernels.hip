@@ -6,6 +6,8 @@
 //   k_eval_paths    PathSampler::sampleSplats on caller-supplied PSS points (pathsampler.cpp:529-567)
 //   k_render_pt     independent samples of the same integrand (validation image)
 //   k_lum_sum / k_develop   DRMLTProcess::develop (drmlt_proc.cpp:824-849)
+#include <cstdlib>
+#include <cstdio>
 #include "device_path.h"
 
 #include "kernel_common.h"
@@ -628,6 +630,7 @@ __global__ void __launch_bounds__(CHAIN_BLOCK) k_mutate_v3(DParams P, uint32_t n
     const bool stamps = (P.debug & 128) != 0;
     unsigned long long t_mh = 0, t_trace = 0, t_step = 0, n_iter = 0, n_mh = 0, n_busy = 0;
     unsigned long long t_decide = 0, t_commit = 0, t_start = 0, t_fill = 0;
+    unsigned long long hist[6] = {0, 0, 0, 0, 0, 0}; // iterations by number of chains tracing a closest-hit ray: 0, 1-4, 5-8, 9-16, 17-24, 25-32
 #define STAMP() (stamps ? __builtin_amdgcn_s_memtime() : 0ull)
     for (;;) {
         const bool parked = ps.phase == PH_DONE;
@@ -670,6 +673,7 @@ __global__ void __launch_bounds__(CHAIN_BLOCK) k_mutate_v3(DParams P, uint32_t n
         const unsigned long long s1 = STAMP();
         const bool tracing = helper ? helper_has_ray : ps.phase == PH_CLOSEST;
         if (stamps) n_busy += __popcll(__ballot(tracing));
+        if (stamps) { const int nl = __popcll(__ballot(tracing && !helper)); hist[nl == 0 ? 0 : (nl <= 4 ? 1 : (nl <= 8 ? 2 : (nl <= 16 ? 3 : (nl <= 24 ? 4 : 5))))]++; }
         if (tracing) h = trace<FEAT>(P, ps.o, ps.d, ps.tmin, ps.tmax, helper);
         const unsigned long long s2 = STAMP();
         const unsigned occluded = from_upper_u((helper_has_ray && h.prim >= 0) ? 1u : 0u);
@@ -696,6 +700,7 @@ __global__ void __launch_bounds__(CHAIN_BLOCK) k_mutate_v3(DParams P, uint32_t n
     if (stamps && lane == 0) {
         atomicAdd(P.stats + 16, t_mh); atomicAdd(P.stats + 17, t_trace); atomicAdd(P.stats + 18, t_step);
         atomicAdd(P.stats + 19, n_iter); atomicAdd(P.stats + 20, n_mh); atomicAdd(P.stats + 21, n_busy);
+        for (int q = 0; q < 6; ++q) atomicAdd(P.stats + 26 + q, hist[q]);
         atomicAdd(P.stats + 22, t_decide); atomicAdd(P.stats + 23, t_commit); atomicAdd(P.stats + 24, t_start); atomicAdd(P.stats + 25, t_fill);
     }
 
@@ -782,6 +787,7 @@ void launch_mutate(const DParams &P, uint32_t n_mut, uint32_t mut_base, hipStrea
     } else if (P.kernel_variant == 3) { // 32 chains per wave, rows of 32 floats
         size_t lds = (D + 2 * D4) * 32 * sizeof(float);
         if (P.tables_in_lds) lds += (size_t) P.n_shade * 64 + (size_t) P.n_bsdfs * 48 + (size_t) P.n_emitters * 32;
+        if (getenv("DRMLT_VERBOSE")) fprintf(stderr, "[drmlt] k_mutate_v3: %zu B of LDS per wave\n", lds);
         // specialisations: 0 = diffuse polygons (Cornell configs); 3 = + rough conductor / dielectric, still flat primitives
         // under the brute-force loop (door config); 7 = + spheres; 15 = everything (BVH traversal, with its 6 KB LDS stack)
         const dim3 g3((P.n_chains + 31) / 32);
