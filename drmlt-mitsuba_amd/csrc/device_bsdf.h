@@ -64,7 +64,9 @@ struct DMicrofacet {
         if (wi.z == 0.f) return 0.f;
         return smithG1(wi, m) * fabsf(dot3(wi, m)) * eval(m) / fabsf(wi.z);
     }
-    DEV void sampleVisible11(float thetaI, float sx, float sy, float &slx, float &sly) const {
+    // thetaI with its tangent supplied by the caller: tan = sin / cos from the direction's components is the same
+    // number as tanf(acosf(z)) without the two libm calls (tanf's range reduction alone is ~100 instructions)
+    DEV void sampleVisible11(float thetaI, float tanThetaI, float sx, float sy, float &slx, float &sly) const {
         const float SQRT_PI_INV = 0.5641895835477563f;
         if (!ggx) {
             if (thetaI < 1e-4f) {
@@ -72,11 +74,11 @@ struct DMicrofacet {
                 slx = r * cos_rev(sy); sly = r * sin_rev(sy);
                 return;
             }
-            float tanThetaI = tanf(thetaI), cotThetaI = 1.f / tanThetaI;
+            float cotThetaI = 1.f / tanThetaI;
             float a = -1.f, c = mts_erf(cotThetaI);
             float sample_x = fmaxf(sx, 1e-6f);
             float fit = 1.f + thetaI * (-0.876f + thetaI * (0.4265f - 0.0594f * thetaI));
-            float b = c - (1.f + c) * powf(1.f - sample_x, fit);
+            float b = c - (1.f + c) * fast_exp2(fit * fast_log2(1.f - sample_x)); // pow(): only the Newton start value
             float normalization = 1.f / (1.f + c + SQRT_PI_INV * tanThetaI * expf(-cotThetaI * cotThetaI));
             int it = 0;
             while (++it < 10) {
@@ -97,7 +99,6 @@ struct DMicrofacet {
             slx = r * cos_rev(sy); sly = r * sin_rev(sy);
             return;
         }
-        float tanThetaI = tanf(thetaI);
         float a = 1.f / tanThetaI;
         float G1 = 2.f / (1.f + sqrtf(fmaxf(0.f, 1.f + 1.f / (a * a))));
         float A = 2.f * sx / G1 - 1.f;
@@ -115,11 +116,17 @@ struct DMicrofacet {
     }
     DEV f3 sampleVisible(f3 _wi, float sx, float sy) const {
         f3 wi = normalize3(mk3(alpha * _wi.x, alpha * _wi.y, _wi.z));
-        float theta = 0.f, phi = 0.f;
-        if (wi.z < 0.99999f) { theta = acosf(wi.z); phi = atan2f(wi.y, wi.x); }
-        float sinPhi = sinf(phi), cosPhi = cosf(phi);
+        // (theta, phi) of wi (microfacet.h:428-437). Only tan(theta), cos(phi), sin(phi) are used -- read them off the
+        // components -- and theta itself by the Beckmann fit polynomial and the theta < 1e-4 test.
+        float theta = 0.f, tanTheta = 0.f, sinPhi = 0.f, cosPhi = 1.f;
+        if (wi.z < 0.99999f) {
+            const float r2 = wi.x * wi.x + wi.y * wi.y, inv = rsqrtf(r2);
+            theta = ggx ? 1.f : acosf(wi.z);             // GGX only compares it with 1e-4
+            tanTheta = r2 * inv / wi.z;
+            cosPhi = wi.x * inv; sinPhi = wi.y * inv;
+        }
         float slx, sly;
-        sampleVisible11(theta, sx, sy, slx, sly);
+        sampleVisible11(theta, tanTheta, sx, sy, slx, sly);
         float rx = (cosPhi * slx - sinPhi * sly) * alpha, ry = (sinPhi * slx + cosPhi * sly) * alpha;
         float nrm = rsqrtf(rx * rx + ry * ry + 1.f);
         return mk3(-rx * nrm, -ry * nrm, nrm);
