@@ -115,6 +115,12 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args()
 
+    # Libraries loaded below write to the process's stdout on their own (RCCL prints a version banner when its first
+    # communicator comes up): keep file descriptor 1 pointed at stderr until the one JSON line is ready.
+    sys.stdout.flush()
+    saved_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     import torch.distributed as dist
 
@@ -254,7 +260,10 @@ def main():
     elif rank == 0:
         out["cpu_baseline"] = None
     if rank == 0:
-        print(json.dumps(_clean(out)))
+        sys.stdout.flush()
+        os.dup2(saved_stdout, 1)
+        print(json.dumps(_clean(out)), flush=True)
+        os.dup2(2, 1)  # whatever is printed during teardown goes to stderr as well
     ctx.close()
     if use_dist:
         dist.destroy_process_group()
