@@ -32,12 +32,14 @@ def make(pkg, ob, sd, precision=64, **kw):
     return cfg, pkg.Context(cfg, sd), ob.Oracle(abi, cfg, sd, precision)
 
 
-SCENES = ["cornell_c1", "cornell_c2", "glass_sphere", "door_c3", "triangle_soup", "caustic_c5"]
+SCENES = ["cornell_c1", "cornell_c2", "glass_sphere", "door_c3", "door_ggx", "triangle_soup", "caustic_c5"]
 
 
 @pytest.mark.parametrize("name", SCENES)
 def test_eval_paths_matches_oracle(pkg, ob, name, native_lib):
-    sd = pkg.scenes.SCENES[name](res=64) if name != "triangle_soup" else pkg.scenes.triangle_soup(600, 64)
+    if name == "triangle_soup": sd = pkg.scenes.triangle_soup(600, 64)
+    elif name == "door_ggx": sd = pkg.scenes.door_c3(64, ggx=True)      # the GGX branch of the microfacet sampler
+    else: sd = pkg.scenes.SCENES[name](res=64)
     cfg, ctx, orc = make(pkg, ob, sd, type="orbital", work_units=64)
     u = np.random.default_rng(1).random((8192, 50), dtype=np.float32)
     g, o = ctx.eval_paths(u), orc.eval_paths(u)
