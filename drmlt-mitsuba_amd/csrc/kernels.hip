@@ -627,6 +627,11 @@ __global__ void __launch_bounds__(CHAIN_BLOCK) k_mutate_v3(DParams P, uint32_t n
     const GlobalTables GT{P.shade, P.bsdfs, P.emitters};
     if (LDS_TABLES) stage_tables(P, LT, lane);
 
+    // Wave priority by loop section: the two waves of a SIMD are then rarely in the same section with the same claim on the
+    // issue port -- the ray loop (dense VALU, its scalar loads pipelined) yields to a partner that is in the latency-bound
+    // path step or bookkeeping branch. Measured +5 % on config 2 (any assignment of distinct levels gives most of it;
+    // DRMLT_DEBUG bit 1024 switches it off for A/B runs).
+    const bool prio = (P.debug & 1024) == 0;
     const bool stamps = (P.debug & 128) != 0;
     unsigned long long t_mh = 0, t_trace = 0, t_step = 0, n_iter = 0, n_mh = 0, n_busy = 0;
     unsigned long long t_decide = 0, t_commit = 0, t_start = 0, t_fill = 0;
@@ -640,6 +645,7 @@ __global__ void __launch_bounds__(CHAIN_BLOCK) k_mutate_v3(DParams P, uint32_t n
         const unsigned long long s0 = STAMP();
         if (pmask && (__popcll(pmask) >= batch || !rmask)) {
             n_mh++;
+            if (prio) __builtin_amdgcn_s_setprio(2);
             // decide (chain lanes) -> commit (both lanes of a pair) -> start (chain lanes) -> draw (both lanes)
             int commit = 0;
             if (parked) commit = mh_decide(P, cs, smp, ps, ct);
@@ -674,7 +680,9 @@ __global__ void __launch_bounds__(CHAIN_BLOCK) k_mutate_v3(DParams P, uint32_t n
         const bool tracing = helper ? helper_has_ray : ps.phase == PH_CLOSEST;
         if (stamps) n_busy += __popcll(__ballot(tracing));
         if (stamps) { const int nl = __popcll(__ballot(tracing && !helper)); hist[nl == 0 ? 0 : (nl <= 4 ? 1 : (nl <= 8 ? 2 : (nl <= 16 ? 3 : (nl <= 24 ? 4 : 5))))]++; }
+        if (prio) __builtin_amdgcn_s_setprio(0);
         if (tracing) h = trace<FEAT>(P, ps.o, ps.d, ps.tmin, ps.tmax, helper);
+        if (prio) __builtin_amdgcn_s_setprio(3);
         const unsigned long long s2 = STAMP();
         const unsigned occluded = from_upper_u((helper_has_ray && h.prim >= 0) ? 1u : 0u);
         helper_has_ray = false;

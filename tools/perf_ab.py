@@ -37,4 +37,5 @@ for rep in range(int(os.environ.get("REPS", 5))):
 for v in variants:
     r = np.array(rates[v])
     st = ctxs[v].stats()
+    if os.environ.get("ALL"): print("   rates:", " ".join("%.3e" % x for x in r))
     print("variant %-24s median %.4e  min %.4e  max %.4e mut/s   rays/mut %.2f  acc %.3f" % (v, np.median(r), r.min(), r.max(), st.rays / st.mutations, st.accepted / st.mutations))
