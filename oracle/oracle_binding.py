@@ -12,8 +12,22 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 
 
+def _native_name():
+    """-march=native code must run on the CPU it was built for: tag the file with this host's instruction-set flags."""
+    import hashlib
+    flags = ""
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("flags"):
+                flags = " ".join(sorted(line.split(":", 1)[1].split()))
+                break
+    except OSError:
+        pass
+    return "liboracle_native_%s.so" % hashlib.md5(flags.encode()).hexdigest()[:8]
+
+
 def build(native=False):
-    target = "liboracle_native.so" if native else "liboracle.so"
+    target = _native_name() if native else "liboracle.so"
     subprocess.check_call(["make", "-C", _HERE, target], stdout=subprocess.DEVNULL)
     return os.path.join(_HERE, target)
 
@@ -23,7 +37,7 @@ _libs = {}
 
 def lib(native=False):
     if native not in _libs:
-        path = os.path.join(_HERE, "liboracle_native.so" if native else "liboracle.so")
+        path = os.path.join(_HERE, _native_name() if native else "liboracle.so")
         if not os.path.exists(path):
             build(native)
         L = C.CDLL(path)
