@@ -21,6 +21,11 @@
 // (ds_read), never through a generic pointer: LDS offset 0 casts to the flat null pointer.
 extern __shared__ __attribute__((aligned(16))) float lds_x[];
 
+// The proposal arithmetic is evaluated at several sites (on demand in k_mutate / k_mutate_v2 / v3, for whole rows in
+// k_mutate_v4, pair-wise at a commit): without this the compiler contracts a*b+c into an fma at some sites and not at
+// others, and the kernels' chains drift apart in the last bit. Explicit fmaf() calls stay fused everywhere.
+#define FP_STRICT _Pragma("clang fp contract(off)")
+
 // ------------------------------------------------------------------ PSS sampler
 enum { SM_BOOT = 0, SM_ARRAY = 1, SM_STAGE1 = 2, SM_STAGE2 = 3, SM_REVERSE = 4, SM_PT = 5 };
 
@@ -37,12 +42,14 @@ DEV float wrap01(float y) { return y > 1.f ? 2.f - y : fabsf(y); }
 
 // Kelemen kernel (transition.h:97-111): sign * s2 * (s1/s2)^(1 - xi')
 DEV float kelemen_sample(float xi, float s2) {
+        FP_STRICT;
     float sign = 1.f;
     if (xi < 0.5f) { xi *= 2.f; } else { sign = -1.f; xi = 2.f * (xi - 0.5f); }
     return sign * s2 * fast_exp2((1.f - xi) * LOG2_S1_OVER_S2);
 }
 // Gaussian kernel (transition.h:61-66), Box-Muller cosine branch
 DEV float gaussian_sample(float u1, float u2, float sigma) {
+        FP_STRICT;
     float tmp = sqrtf(-1.3862943611198906f * fast_log2(1.f - u1)); // -2 ln(v) = -2 ln2 log2(v)
     return tmp * cos_rev(u2) * sigma;
 }
@@ -90,6 +97,7 @@ struct Sampler {
 
     // first-stage proposal, unwrapped (fillSpace with isFirst = true)
     DEV float y_raw(uint32_t k) {
+        FP_STRICT;
         if (large) return u_s1(k);
         if (type != 2 /*orbital*/) return x(k) + kelemen_sample(u_s1(k), KELEMEN_S2);
         ensure_pair(k & ~1u, false);
@@ -97,6 +105,7 @@ struct Sampler {
     }
     // second-stage proposal, unwrapped (fillSpace with isFirst = false)
     DEV float z_raw(uint32_t k) {
+        FP_STRICT;
         // second stage of a large step (timidAfterLarge): the reference's fillSpace takes its
         // uniform branch again (drmlt_sampler.cpp:319-321 behind a debug-only assertion)
         if (large) return u_s2(k);
@@ -106,6 +115,7 @@ struct Sampler {
     }
     // orbital pair (k0, k0+1): y = x + d (cos a, sin a); z = y + R(theta) (x - y)
     DEV void ensure_pair(uint32_t k0, bool need_z) {
+        FP_STRICT;
         if (pair_base != k0) {
             pair_base = k0;
             float x0 = x(k0), x1 = x(k0 + 1u);
@@ -140,6 +150,7 @@ struct Sampler {
 
     // value handed to the path code for PSS dimension k (primarySample)
     DEV float next(uint32_t k) {
+        FP_STRICT;
         switch (mode) {
             case SM_BOOT: return u_boot(k, TAG_BOOT);
             case SM_PT: return u_boot(k, TAG_PT);
@@ -190,6 +201,7 @@ struct LdsSampler {
     }
     // second-stage values (see layout above); blocks first, first + step, ... (step 2 = shared by two lanes)
     DEV void fill_stage2(uint32_t D4, uint32_t first, uint32_t step) {
+        FP_STRICT;
         if (large || type == 2) {
             const uint32_t rows = large ? D4 : (D4 / 2u + 3u) & ~3u; // uniforms: one per dim, or one per pair
             for (uint32_t b = first; b < rows / 4u; b += step) {
@@ -208,6 +220,7 @@ struct LdsSampler {
     }
 
     DEV float y_raw(uint32_t k) const {
+        FP_STRICT;
         if (large) return u1(k);
         if (type != 2) return x(k) + kelemen_sample(u1(k), KELEMEN_S2);
         const uint32_t k0 = k & ~1u;
@@ -215,6 +228,7 @@ struct LdsSampler {
         return fmaf(d, cos_rev(a - ((k & 1u) ? 0.25f : 0.f)), x(k));
     }
     DEV float z_raw(uint32_t k) const {
+        FP_STRICT;
         if (large) return s2(k);
         if (type != 2) return x(k) + s2(k);
         const uint32_t k0 = k & ~1u;
@@ -231,6 +245,7 @@ struct LdsSampler {
         return (k & 1u) ? y1 + (st * dx0 + ct * dx1) : y0 + (ct * dx0 - st * dx1);
     }
     DEV float next(uint32_t k) const {
+        FP_STRICT;
         if (type == 2 && mode == SM_STAGE1) {
             // The common case (orbital, first stage) without divergent branches: unconditional LDS reads, the
             // large-step case as a select, sin(2 pi a) as cos(2 pi (a - 1/4)) so that one v_cos serves both components.
@@ -259,6 +274,7 @@ struct LdsSampler {
     // Orbital pair (k0, k0 + 1), both components of the first- or second-stage proposal at once (accept(): the
     // per-component form above evaluates the shared radius / angle / rotation twice per pair). Same arithmetic.
     DEV void orbital_pair(uint32_t k0, bool second, float &o0, float &o1) const {
+        FP_STRICT;
         const float x0 = x(k0), x1 = x(k0 + 1u);
         const float d = kelemen_sample(u1(k0), KELEMEN_S2 * ORBITAL_SCALE), a = u1(k0 + 1u);
         const float y0 = fmaf(d, cos_rev(a), x0), y1 = fmaf(d, cos_rev(a - 0.25f), x1);
@@ -272,6 +288,91 @@ struct LdsSampler {
         const float dx0 = x0 - y0, dx1 = x1 - y1;
         o0 = y0 + (ct * dx0 - st * dx1);
         o1 = y1 + (st * dx0 + ct * dx1);
+    }
+};
+
+// ------------------------------------------------------------------ PSS sampler of k_mutate_v4
+// The proposals themselves are parked in LDS, not the uniforms they are made of: the bookkeeping branch of k_mutate_v4
+// evaluates the transition kernels for ALL dimensions of the chains that start an evaluation, flattened over the 64
+// lanes of the wave (items = chain x Philox block, every lane busy), so that inside the divergent path step a PSS
+// component is one LDS read and a reflection. Rows (stride `stride` floats, column = chain):
+//   x  [0 .. D)    current state
+//   y  [D4 rows]   first-stage proposal, unwrapped (a large step: the uniforms themselves)
+//   z  [D4 rows]   second-stage proposal, unwrapped
+// Same arithmetic per component as LdsSampler (and Sampler): the chains are bit-identical.
+struct RowSampler {
+    uint32_t key0, key1;
+    int mode, type;
+    float sigma2;
+    uint32_t lane, stride, y_off, z_off;
+
+    DEV void reset_caches() {}
+    DEV float x(uint32_t k) const { return lds_x[k * stride + lane]; }
+    DEV float y_raw(uint32_t k) const { return lds_x[y_off + k * stride + lane]; }
+    DEV float z_raw(uint32_t k) const { return lds_x[z_off + k * stride + lane]; }
+    DEV float next(uint32_t k) const {
+        FP_STRICT;
+        float v = y_raw(k);
+        if (mode != SM_STAGE1) {
+            const float z = z_raw(k);
+            v = mode == SM_STAGE2 ? z : z - (v - x(k)); // Green's reverse move: y* = z - (y - x)
+        }
+        return wrap01(v);
+    }
+    // first-stage proposal of chain column `col`, dimensions 4b .. 4b+3, from Philox block b of (major, chain)
+    DEV void fill_first(uint32_t col, uint32_t b, uint32_t major, uint32_t chain, bool large) const {
+        FP_STRICT;
+        const u4 r = philox4x32_10(key0, key1, b, major, chain, TAG_S1);
+        const float u0 = u32_to_unit(r.x), u1 = u32_to_unit(r.y), u2 = u32_to_unit(r.z), u3 = u32_to_unit(r.w);
+        const float *xs = &lds_x[4u * b * stride + col];
+        float *ys = &lds_x[y_off + 4u * b * stride + col];
+        const float x0 = xs[0], x1 = xs[stride], x2 = xs[2u * stride], x3 = xs[3u * stride];
+        float y0, y1, y2, y3;
+        if (type == 2) { // pairwise orbital: radius from the Kelemen kernel (x 1.9), uniform angle (drmlt_sampler.cpp:354-361)
+            const float d0 = kelemen_sample(u0, KELEMEN_S2 * ORBITAL_SCALE), d1 = kelemen_sample(u2, KELEMEN_S2 * ORBITAL_SCALE);
+            y0 = fmaf(d0, cos_rev(u1), x0); y1 = fmaf(d0, cos_rev(u1 - 0.25f), x1);
+            y2 = fmaf(d1, cos_rev(u3), x2); y3 = fmaf(d1, cos_rev(u3 - 0.25f), x3);
+        } else {
+            y0 = x0 + kelemen_sample(u0, KELEMEN_S2); y1 = x1 + kelemen_sample(u1, KELEMEN_S2);
+            y2 = x2 + kelemen_sample(u2, KELEMEN_S2); y3 = x3 + kelemen_sample(u3, KELEMEN_S2);
+        }
+        ys[0] = large ? u0 : y0; ys[stride] = large ? u1 : y1; ys[2u * stride] = large ? u2 : y2; ys[3u * stride] = large ? u3 : y3;
+    }
+    // second-stage proposal of chain column `col` from Philox block b of the TAG_S2 stream: a large step (timidAfterLarge)
+    // -> dims 4b..4b+3 (uniforms); orbital -> the angles of pairs 4b..4b+3 = dims 8b..8b+7; iid kernels -> the Gaussian
+    // perturbations of dims 2b, 2b+1 (draws 2k, 2k+1 belong to dim k). Blocks beyond the chain's kind of stage do nothing.
+    DEV void fill_second(uint32_t col, uint32_t b, uint32_t D4, uint32_t major, uint32_t chain, bool large) const {
+        FP_STRICT;
+        const uint32_t nblk = large ? D4 / 4u : (type == 2 ? (D4 / 2u + 3u) / 4u : D4 / 2u);
+        if (b >= nblk) return;
+        const u4 r = philox4x32_10(key0, key1, b, major, chain, TAG_S2);
+        const float u[4] = {u32_to_unit(r.x), u32_to_unit(r.y), u32_to_unit(r.z), u32_to_unit(r.w)};
+        if (large) {
+#pragma unroll
+            for (uint32_t i = 0; i < 4u; ++i) lds_x[z_off + (4u * b + i) * stride + col] = u[i];
+        } else if (type == 2) {
+#pragma unroll
+            for (uint32_t i = 0; i < 4u; ++i) {
+                const uint32_t k0 = 2u * (4u * b + i);
+                if (k0 + 1u < D4) {
+                    const float x0 = lds_x[k0 * stride + col], x1 = lds_x[(k0 + 1u) * stride + col];
+                    const float y0 = lds_x[y_off + k0 * stride + col], y1 = lds_x[y_off + (k0 + 1u) * stride + col];
+                    // theta ~ wrapped Cauchy by inverse CDF (transition.h:157-173); z = y + R(theta)(x - y) (drmlt_sampler.cpp:374-391)
+                    float xi = u[i], sign = 1.f;
+                    if (xi < 0.5f) { xi *= 2.f; } else { sign = -1.f; xi = 2.f * (xi - 0.5f); }
+                    const float V = cos_rev(xi);
+                    const float A = fminf(1.f, fmaxf(-1.f, (V + WC_DISPERSION) / (1.f + WC_DISPERSION * V)));
+                    const float ct = A, st = sign * sqrtf(fmaxf(0.f, 1.f - A * A));
+                    const float dx0 = x0 - y0, dx1 = x1 - y1;
+                    lds_x[z_off + k0 * stride + col] = y0 + (ct * dx0 - st * dx1);
+                    lds_x[z_off + (k0 + 1u) * stride + col] = y1 + (st * dx0 + ct * dx1);
+                }
+            }
+        } else {
+            const uint32_t k = 2u * b;
+            lds_x[z_off + k * stride + col] = lds_x[k * stride + col] + gaussian_sample(u[0], u[1], sigma2);
+            lds_x[z_off + (k + 1u) * stride + col] = lds_x[(k + 1u) * stride + col] + gaussian_sample(u[2], u[3], sigma2);
+        }
     }
 };
 
@@ -693,6 +794,25 @@ DEV void path_init(const DParams &P, PathState &ps) {
     ps.px = ps.py = 0.f;
 }
 
+// First step of every path: film position from the first two PSS components (pathsampler.cpp:538-543) and the
+// camera ray (sampleRayDifferential, perspective.cpp:271-286). Leaves the path in PH_CLOSEST.
+DEV void path_begin(const DParams &P, PathState &ps, float v0, float v1) {
+    ps.k = 2u;
+    ps.px = v0 * (float) P.width;
+    ps.py = v1 * (float) P.height;
+    f3 nearP = mk3((1.f - 2.f * v0) * P.tan_half_fov * P.near_clip, (1.f - 2.f * v1) * P.tan_half_fov * P.inv_aspect * P.near_clip,
+                   P.near_clip);
+    f3 dl = normalize3(nearP);
+    float invZ = 1.f / dl.z;
+    ps.tmin = P.near_clip * invZ;
+    ps.tmax = P.far_clip * invZ;
+    ps.o = mk3(P.cam[3], P.cam[7], P.cam[11]);
+    ps.d = mk3(fmaf(P.cam[0], dl.x, fmaf(P.cam[1], dl.y, P.cam[2] * dl.z)), fmaf(P.cam[4], dl.x, fmaf(P.cam[5], dl.y, P.cam[6] * dl.z)),
+               fmaf(P.cam[8], dl.x, fmaf(P.cam[9], dl.y, P.cam[10] * dl.z)));
+    ps.phase = PH_CLOSEST;
+    ps.nrays = 1u;
+}
+
 // Consume the result of the ray query issued for `ps` (none in PH_BEGIN) and either issue the
 // next ray (PH_CLOSEST / PH_SHADOW) or finish the path (PH_DONE, radiance in ps.Li).
 // DUAL = false: one lane per chain, shadow rays take a step of their own (PH_SHADOW).
@@ -702,7 +822,9 @@ DEV void path_init(const DParams &P, PathState &ps) {
 //   order of the radiance additions is the same in both modes (NEE of vertex i, then MIS of i+1).
 // FEAT: scene features compiled in (bit 0 rough conductor, bit 1 dielectric, bit 2 spheres, bit 3 BVH); kernels for
 // plain diffuse polygon scenes (the Cornell configs) carry none of the other code or its registers.
-template <bool DUAL, int FEAT, class SamplerT, class TablesT>
+// HAS_BEGIN = false: the caller starts every path with path_begin itself (k_mutate_v4: in its bookkeeping branch), the
+// step never sees PH_BEGIN and carries none of its code.
+template <bool DUAL, int FEAT, class SamplerT, class TablesT, bool HAS_BEGIN = true>
 DEV void path_step(const DParams &P, const TablesT &T, PathState &ps, SamplerT &smp, const Hit &hit, bool shadow_clear,
                    ShadowRay &sr) {
     // ---------------- part 1: digest the ray query, decide which PSS components are needed
@@ -719,7 +841,7 @@ DEV void path_step(const DParams &P, const TablesT &T, PathState &ps, SamplerT &
         }
         if (ps.phase == PH_FLUSH) { ps.phase = PH_DONE; return; }
     }
-    if (ps.phase == PH_BEGIN) {
+    if (HAS_BEGIN && ps.phase == PH_BEGIN) {
         need = 2; // film position, pathsampler.cpp:538-543
     } else if (!DUAL && ps.phase == PH_SHADOW) {
         if (hit.prim < 0) ps.Li = ps.Li + ps.nee; // unoccluded
@@ -794,22 +916,8 @@ DEV void path_step(const DParams &P, const TablesT &T, PathState &ps, SamplerT &
     }
 
     // ---------------- part 3: use them
-    if (ps.phase == PH_BEGIN) {
-        // sampleRayDifferential, perspective.cpp:271-286
-        ps.k = 2u;
-        ps.px = v0 * (float) P.width;
-        ps.py = v1 * (float) P.height;
-        f3 nearP = mk3((1.f - 2.f * v0) * P.tan_half_fov * P.near_clip, (1.f - 2.f * v1) * P.tan_half_fov * P.inv_aspect * P.near_clip,
-                       P.near_clip);
-        f3 dl = normalize3(nearP);
-        float invZ = 1.f / dl.z;
-        ps.tmin = P.near_clip * invZ;
-        ps.tmax = P.far_clip * invZ;
-        ps.o = mk3(P.cam[3], P.cam[7], P.cam[11]);
-        ps.d = mk3(fmaf(P.cam[0], dl.x, fmaf(P.cam[1], dl.y, P.cam[2] * dl.z)), fmaf(P.cam[4], dl.x, fmaf(P.cam[5], dl.y, P.cam[6] * dl.z)),
-                   fmaf(P.cam[8], dl.x, fmaf(P.cam[9], dl.y, P.cam[10] * dl.z)));
-        ps.phase = PH_CLOSEST;
-        ps.nrays = 1u;
+    if (HAS_BEGIN && ps.phase == PH_BEGIN) {
+        path_begin(P, ps, v0, v1);
         return;
     }
     if (ps.phase == PH_CLOSEST) {

@@ -99,7 +99,7 @@ struct DParams {
     unsigned long long *stats; // 18 counters, layout of drmlt_stats
     int32_t *error_flag;
     int32_t debug;          // DRMLT_DEBUG bit mask (diagnostics only)
-    int32_t kernel_variant; // 1: k_mutate (nested loops), 2: k_mutate_v2 (lane state machines), 3: k_mutate_v3 (2 lanes per chain)
+    int32_t kernel_variant; // 1: k_mutate (nested loops), 2: k_mutate_v2 (lane state machines), 3: k_mutate_v3 (2 lanes per chain), 4: k_mutate_v4 (free-running, flattened bookkeeping; default)
     int32_t features;       // bit 0 rough conductor, bit 1 dielectric, bit 2 spheres, bit 3 BVH traversal needed
     int32_t mh_batch;       // k_mutate_v2: parked lanes needed before the bookkeeping branch is taken
     // technique=mmlt (device_bidir.h)

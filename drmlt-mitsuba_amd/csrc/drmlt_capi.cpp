@@ -529,14 +529,14 @@ drmlt_ctx *drmlt_create(const drmlt_config *cfg, const drmlt_scene *scene, int d
     P.error_flag = ctx->d_err.as<int32_t>();
     P.debug = 0;
     if (const char *d = getenv("DRMLT_DEBUG")) P.debug = atoi(d);
-    P.kernel_variant = 3;
-    if (const char *k = getenv("DRMLT_KERNEL")) { int kv = atoi(k); P.kernel_variant = (kv >= 1 && kv <= 3) ? kv : 2; }
+    P.kernel_variant = 4;
+    if (const char *k = getenv("DRMLT_KERNEL")) { int kv = atoi(k); P.kernel_variant = (kv >= 1 && kv <= 4) ? kv : 2; }
     P.features = 0;
     for (const DBsdf &b : bsdfs) P.features |= b.type == DRMLT_BSDF_ROUGHCONDUCTOR ? 1 : (b.type == DRMLT_BSDF_DIELECTRIC ? 2 : 0);
     for (const DPrim &g : ctx->prims) if (g.type == PRIM_SPHERE) P.features |= 4;
     if (P.use_bvh) P.features |= 8;
     if (getenv("DRMLT_FEAT_ALL")) P.features = 15;
-    P.mh_batch = 32;
+    P.mh_batch = P.kernel_variant == 4 ? 8 : 32; // v4: chains run free, the bookkeeping branch fires as soon as a few are parked
     if (const char *k = getenv("DRMLT_MH_BATCH")) P.mh_batch = std::max(1, std::min(64, atoi(k)));
     if (hipDeviceSynchronize() != hipSuccess) return bail(ctx, "device synchronisation failed after setup");
     return ctx;

@@ -306,10 +306,22 @@ struct MhStamps { unsigned long long digest, splat, commit, start; };
 //   mh_start   advance to the next evaluation (next stage or next mutation); returns which
 //              uniforms must be drawn (0 none, 1 first stage, 2 second stage)
 //   fill       Philox draws into LDS for a range of blocks                    (shareable)
-DEV int mh_decide(const DParams &P, ChainState &cs, LdsSampler &smp, PathState &ps, Counters &ct) {
+// Outcome of one digested evaluation. `decided`: the mutation is over and w0 / w1 / w2 are the expectation weights of
+// the current state, the first-stage and the second-stage proposal (drmlt_proc.cpp:677-688, mixture :327-333);
+// `commit`: 0 none, SM_STAGE1 = adopt y, SM_STAGE2 = adopt z; `amap`: acceptance-map mark at the adopted state's pixel
+// (1 red = first stage, 2 green = second stage, drmlt_proc.cpp:697-709). The caller splats: k_mutate_v2/v3 at once,
+// k_mutate_v4 through its LDS queue.
+struct MhOutcome {
+    bool decided;
+    int commit, amap;
+    float w0, w1, w2;
+};
+
+template <class SamplerT> DEV MhOutcome mh_decide(const DParams &P, ChainState &cs, SamplerT &smp, PathState &ps, Counters &ct) {
     const bool mix = P.use_mixture != 0;
     const bool amap = P.acceptance_map != 0;
-    if (cs.stage < 0) return 0; // nothing evaluated yet (first call of a launch)
+    MhOutcome out{false, 0, 0, 0.f, 0.f, 0.f};
+    if (cs.stage < 0) return out; // nothing evaluated yet (first call of a launch)
     bool decided = false;
     float a2 = 0.f;
     bool acc1 = false, acc2 = false;
@@ -325,7 +337,7 @@ DEV int mh_decide(const DParams &P, ChainState &cs, LdsSampler &smp, PathState &
         acc1 = cs.a1 >= 1.f || (cs.a1 > 0.f && cs.coin_acc1 < cs.a1);
         if (!mix) cs.do_second = !acc1 && (P.timid_after_large || !cs.large);
         else cs.do_second = !cs.large && cs.coin_mix < 0.5f;
-        if (cs.do_second) { cs.stage = 1; return 0; }
+        if (cs.do_second) { cs.stage = 1; return out; }
         decided = true;
     } else if (cs.stage == 1) {
         cs.z = res; cs.nd2 = ps.k;
@@ -337,7 +349,7 @@ DEV int mh_decide(const DParams &P, ChainState &cs, LdsSampler &smp, PathState &
                 acc2 = a2 >= 1.f || cs.coin_acc2 < a2;
             }
         } else if (!lum_invalid(res.lum)) {
-            if (P.type == 0) { cs.stage = 2; return 0; } // Green: evaluate the reverse move first
+            if (P.type == 0) { cs.stage = 2; return out; } // Green: evaluate the reverse move first
             if (P.type == 1) {
                 float aRev = fminf(1.f, cs.y.lum / res.lum);
                 if (!(aRev >= 1.f)) {
@@ -376,23 +388,15 @@ DEV int mh_decide(const DParams &P, ChainState &cs, LdsSampler &smp, PathState &
         }
         decided = true;
     }
-    if (!decided) return 0;
-    // splats of this mutation through ONE film_put site (the call expands to ~150 instructions; six inlined copies
-    // of it were a sixth of the kernel's code): slot 0 current state, 1 first-stage, 2 second-stage proposal
-    float w0, w1, w2;
+    if (!decided) return out;
+    out.decided = true;
     if (!mix) { // expectation weights, drmlt_proc.cpp:677-688
-        w1 = cs.a1; w2 = (1.f - cs.a1) * a2; w0 = 1.f - w1 - w2;
-        if (!cs.do_second) w2 = 0.f;
-        if (amap) w0 = w1 = w2 = 0.f;
+        out.w1 = cs.a1; out.w2 = (1.f - cs.a1) * a2; out.w0 = 1.f - out.w1 - out.w2;
+        if (!cs.do_second) out.w2 = 0.f;
+        if (amap) out.w0 = out.w1 = out.w2 = 0.f;
     } else { // processMixture, :327-333: a = acceptance of whichever proposal was tested
         const float a = cs.do_second ? a2 : cs.a1;
-        w0 = 1.f - a; w1 = cs.do_second ? 0.f : a; w2 = cs.do_second ? a : 0.f;
-    }
-#pragma nounroll
-    for (int i = 0; i < 3; ++i) {
-        const float w = i == 0 ? w0 : (i == 1 ? w1 : w2);
-        const DSplat sp = select_splat(i == 0, cs.cur, select_splat(i == 1, cs.y, cs.z));
-        if (w > 0.f) film_put(P, sp.px, sp.py, mk3(sp.r * w, sp.g * w, sp.b * w));
+        out.w0 = 1.f - a; out.w1 = cs.do_second ? 0.f : a; out.w2 = cs.do_second ? a : 0.f;
     }
     if (cs.large) {
         ct.large_acc1l += 1u + (acc1 ? 1u << 16 : 0u);
@@ -403,18 +407,32 @@ DEV int mh_decide(const DParams &P, ChainState &cs, LdsSampler &smp, PathState &
         if (cs.do_second) ct.secb_acc2l += 1u;
         if (acc2) ct.acc2b_rev += 1u;
     }
-    int commit = 0;
     if (acc1 || acc2) {
-        commit = acc1 ? SM_STAGE1 : SM_STAGE2;
-        cs.cur = select_splat(acc1, cs.y, cs.z);
-        if (amap && !mix) {
-            if (acc1) { if (!cs.large) film_put(P, cs.cur.px, cs.cur.py, mk3(1.f, 0.f, 0.f)); }
-            else film_put(P, cs.cur.px, cs.cur.py, mk3(0.f, 1.f, 0.f));
-        }
+        out.commit = acc1 ? SM_STAGE1 : SM_STAGE2;
+        if (amap && !mix) out.amap = acc1 ? (cs.large ? 0 : 1) : 2;
     }
     cs.it++;
     cs.stage = -1;
-    return commit;
+    return out;
+}
+
+// k_mutate_v2 / v3: splat the decided mutation at once and adopt the accepted proposal. The three splats go through ONE
+// film_put site (the call expands to ~150 instructions; six inlined copies of it were a sixth of the kernel's code):
+// slot 0 current state, 1 first-stage, 2 second-stage proposal.
+DEV int mh_decide_splat(const DParams &P, ChainState &cs, LdsSampler &smp, PathState &ps, Counters &ct) {
+    const MhOutcome o = mh_decide(P, cs, smp, ps, ct);
+    if (!o.decided) return 0;
+#pragma nounroll
+    for (int i = 0; i < 3; ++i) {
+        const float w = i == 0 ? o.w0 : (i == 1 ? o.w1 : o.w2);
+        const DSplat sp = select_splat(i == 0, cs.cur, select_splat(i == 1, cs.y, cs.z));
+        if (w > 0.f) film_put(P, sp.px, sp.py, mk3(sp.r * w, sp.g * w, sp.b * w));
+    }
+    if (o.commit) {
+        cs.cur = select_splat(o.commit == SM_STAGE1, cs.y, cs.z);
+        if (o.amap) film_put(P, cs.cur.px, cs.cur.py, o.amap == 1 ? mk3(1.f, 0.f, 0.f) : mk3(0.f, 1.f, 0.f));
+    }
+    return o.commit;
 }
 
 // DRMLTSampler::accept for dimensions [k0, k1): uCurrent = wrap(chosen proposal)
@@ -462,7 +480,7 @@ DEV int mh_start(const DParams &P, ChainState &cs, LdsSampler &smp, PathState &p
 DEV void mh_advance(const DParams &P, ChainState &cs, LdsSampler &smp, PathState &ps, Counters &ct, uint32_t n_mut,
                     uint32_t mut_base, uint32_t lane, MhStamps &ms, bool stamps) {
     const unsigned long long m0 = stamps ? __builtin_amdgcn_s_memtime() : 0ull;
-    const int commit = mh_decide(P, cs, smp, ps, ct);
+    const int commit = mh_decide_splat(P, cs, smp, ps, ct);
     const unsigned long long m1 = stamps ? __builtin_amdgcn_s_memtime() : 0ull;
     if (commit) commit_range(smp, commit, 0u, (uint32_t) P.eff_dim);
     const unsigned long long m2 = stamps ? __builtin_amdgcn_s_memtime() : 0ull;
@@ -648,7 +666,7 @@ __global__ void __launch_bounds__(CHAIN_BLOCK) k_mutate_v3(DParams P, uint32_t n
             if (prio) __builtin_amdgcn_s_setprio(2);
             // decide (chain lanes) -> commit (both lanes of a pair) -> start (chain lanes) -> draw (both lanes)
             int commit = 0;
-            if (parked) commit = mh_decide(P, cs, smp, ps, ct);
+            if (parked) commit = mh_decide_splat(P, cs, smp, ps, ct);
             const unsigned long long m1 = STAMP();
             const int commit_pair = (int) from_lower_u((unsigned) commit);
             const uint32_t maj_c = from_lower_u(smp.major);
@@ -727,6 +745,331 @@ __global__ void __launch_bounds__(CHAIN_BLOCK) k_mutate_v3(DParams P, uint32_t n
         for (int i = 0; i < 9; ++i) atomicAdd(P.stats + i, v[i]);
 }
 
+// ------------------------------------------------------------------------------------------
+// k_mutate_v4: k_mutate_v3's two lanes per chain, without its lock-step rounds.
+//
+// In v3 the bookkeeping branch fires when all 32 chains of a wave are parked: a round lasts as long as the longest of 32
+// paths (9.6 loop iterations per mutation where the mean path needs 3.9), because the branch costs the wave the same
+// whether 1 or 32 chains take it -- per lane it walks D_eff dimensions (commit) and ~10 Philox blocks (next draws).
+// Here that per-chain work is FLATTENED over the wave: the parked chains are compacted into a list (ballot + prefix
+// count -> LDS) and all 64 lanes share the (chain, dimension pair) commit items and the (chain, Philox block) draw
+// items, so the branch costs in proportion to the number of chains that take it and chains can run free: a chain starts
+// its next evaluation as soon as its last one is digested. What is left per lane is the decision itself.
+//
+// Film: splats are queued in LDS and flushed by whole waves with the three colour channels of a splat in three adjacent
+// lanes (one 12-byte segment per splat at the memory side instead of three scattered dwords), and the current state is
+// splatted with its CUMULATIVE weight when it is replaced (or the launch ends) instead of once per mutation -- the
+// reference's own PSSMLT loop does the same (pssmlt_proc.cpp:215-226,262-266); splatting is linear, the film is the
+// same sum. An accepted proposal's weight starts the cumulative weight of the new current state.
+//
+// Chains are the same as k_mutate_v2/v3's (same addressed draws, same arithmetic per chain).
+#define V4_STRIDE 33u // row stride of the sampler rows: (row + chain) mod 32 banks serve per-chain AND per-dimension access patterns
+#define V4_QCAP 160u  // splat queue entries: flushed at >= 63, one bookkeeping branch adds at most 3 x 32
+
+struct V4Lds {
+    uint32_t coin_off, list_off, q_off; // float offsets into lds_x
+};
+
+// one colour channel of ImageBlock::put (see film_put): lanes 3s, 3s+1, 3s+2 carry the channels of splat s
+DEV void film_put_channel(const DParams &P, float px, float py, float v, int ch) {
+    if (P.debug & 1) return;
+    float posx = px - 0.5f, posy = py - 0.5f;
+    int minx = max((int) ceilf(posx - P.filter_radius), 0), miny = max((int) ceilf(posy - P.filter_radius), 0);
+    int maxx = min((int) floorf(posx + P.filter_radius), P.width - 1), maxy = min((int) floorf(posy + P.filter_radius), P.height - 1);
+    const bool box = P.box_weight > 0.f;
+    for (int y = miny; y <= maxy; ++y) {
+        const int iy = min((int) fabsf(((float) y - posy) * P.filter_scale), 31);
+        float wy = box ? (iy < 31 ? P.box_weight : 0.f) : P.filter_lut[iy];
+        for (int x = minx; x <= maxx; ++x) {
+            const int ix = min((int) fabsf(((float) x - posx) * P.filter_scale), 31);
+            float w = (box ? (ix < 31 ? P.box_weight : 0.f) : P.filter_lut[ix]) * wy;
+            atomicAdd(P.film + ((size_t) y * P.width + x) * 3 + ch, w * v);
+        }
+    }
+}
+
+// queue a splat (all lanes call; `want` selects). ImageBlock::put's validity test (imageblock.h:155-165) is applied here.
+DEV void v4_enqueue(const V4Lds &L, uint32_t &qn, bool want, float px, float py, float r, float g, float b) {
+    want = want && isfinite(r) && isfinite(g) && isfinite(b) && r >= 0.f && g >= 0.f && b >= 0.f;
+    const unsigned long long m = __ballot(want);
+    if (want) {
+        const uint32_t slot = qn + __builtin_amdgcn_mbcnt_hi((uint32_t) (m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) m, 0u));
+        float *q = &lds_x[L.q_off + slot];
+        q[0] = px; q[V4_QCAP] = py; q[2u * V4_QCAP] = r; q[3u * V4_QCAP] = g; q[4u * V4_QCAP] = b;
+    }
+    qn += (uint32_t) __popcll(m);
+}
+DEV void v4_flush(const DParams &P, const V4Lds &L, uint32_t &qn, uint32_t lane) {
+    const uint32_t s = lane / 3u, ch = lane - 3u * s;
+    for (uint32_t base = 0u; base < qn; base += 21u) {
+        const uint32_t e = base + s;
+        if (e < qn && s < 21u) {
+            const float *q = &lds_x[L.q_off + e];
+            film_put_channel(P, q[0], q[V4_QCAP], q[(2u + ch) * V4_QCAP], (int) ch);
+        }
+    }
+    qn = 0u;
+}
+
+template <int FEAT, bool LDS_TABLES>
+__global__ void __launch_bounds__(CHAIN_BLOCK) k_mutate_v4(DParams P, uint32_t n_mut, uint32_t mut_base) {
+    const uint32_t lane = threadIdx.x;
+    const uint32_t sub = lane & 31u;
+    const bool helper = lane >= 32u;
+    const uint32_t c = blockIdx.x * 32u + sub;
+    const bool live = !helper && c < P.n_chains;
+    const uint32_t cc = c < P.n_chains ? c : P.n_chains - 1;
+    const int D = P.eff_dim;
+    const uint32_t D4 = ((uint32_t) D + 3u) & ~3u;
+    const uint32_t S = V4_STRIDE;
+    if (!helper)
+        for (int k = 0; k < D; ++k) lds_x[(uint32_t) k * S + sub] = P.x[(size_t) k * P.n_chains + cc];
+
+    ChainState cs;
+    cs.cur.lum = P.cur_lum[cc]; cs.cur.px = P.cur_px[cc]; cs.cur.py = P.cur_py[cc];
+    cs.cur.r = P.cur_r[cc]; cs.cur.g = P.cur_g[cc]; cs.cur.b = P.cur_b[cc];
+    cs.y = cs.cur; cs.z = cs.cur;
+    cs.a1 = 0.f; cs.coin_acc1 = cs.coin_acc2 = cs.coin_mix = 0.f;
+    cs.it = 0u; cs.nd1 = cs.nd2 = 0u; cs.stage = -1; cs.large = false; cs.do_second = false;
+    float cum = 0.f; // cumulative weight of the current state since it was adopted
+
+    RowSampler smp;
+    smp.key0 = P.key0; smp.key1 = P.key1;
+    smp.mode = SM_STAGE1; smp.type = P.type; smp.sigma2 = P.sigma2; smp.lane = sub;
+    smp.stride = S;
+    smp.y_off = (uint32_t) D * S;
+    smp.z_off = smp.y_off + D4 * S;
+    V4Lds L;
+    L.coin_off = smp.z_off + D4 * S;
+    L.list_off = L.coin_off + 4u * S;
+    L.q_off = L.list_off + 32u;
+    uint32_t qn = 0u;
+    Counters ct = {0u, 0u, 0u, 0u, 0u};
+    PathState ps;
+    path_init(P, ps);
+    ps.phase = (live && n_mut > 0u) ? PH_DONE : PH_IDLE; // helpers stay PH_IDLE for good
+    ps.o = mk3(0.f, 0.f, 0.f); ps.d = mk3(0.f, 0.f, 1.f); ps.tmin = 0.f; ps.tmax = 0.f;
+    bool helper_has_ray = false;
+    Hit h{-1, 0.f, 0.f, 0.f};
+    const int batch = P.mh_batch > 32 ? 32 : P.mh_batch;
+    LdsTables LT;
+    LT.shade_off = (L.q_off + 5u * V4_QCAP + 3u) & ~3u;
+    LT.bsdf_off = LT.shade_off + (uint32_t) P.n_shade * 16u;
+    LT.emit_off = LT.bsdf_off + (uint32_t) P.n_bsdfs * 12u;
+    const GlobalTables GT{P.shade, P.bsdfs, P.emitters};
+    if (LDS_TABLES) stage_tables(P, LT, lane);
+    int *const lds_list = reinterpret_cast<int *>(&lds_x[L.list_off]);
+    const uint32_t nb1 = D4 / 4u; // first-stage Philox blocks of a mutation; item nb1 of a chain = the coins of its NEXT mutation
+    const uint32_t chain_base = P.chain_offset + blockIdx.x * 32u; // chain ids of a wave are consecutive
+    // coins of every chain's first mutation of this launch (afterwards they are drawn one mutation ahead, beside the proposal)
+    if (!helper) {
+        const u4 coins = philox4x32_10(P.key0, P.key1, 0u, mut_base, chain_base + sub, TAG_COIN);
+        float *dst = &lds_x[L.coin_off + sub];
+        dst[0] = u32_to_unit(coins.x); dst[S] = u32_to_unit(coins.y); dst[2u * S] = u32_to_unit(coins.z); dst[3u * S] = u32_to_unit(coins.w);
+    }
+
+    const bool prio = (P.debug & 1024) == 0;
+    const bool stamps = (P.debug & 128) != 0;
+    unsigned long long t_mh = 0, t_trace = 0, t_step = 0, n_iter = 0, n_mh = 0, n_busy = 0;
+    unsigned long long t_decide = 0, t_commit = 0, t_start = 0, t_fill = 0;
+    unsigned long long hist[6] = {0, 0, 0, 0, 0, 0};
+#define STAMP() (stamps ? __builtin_amdgcn_s_memtime() : 0ull)
+    for (;;) {
+        const bool parked = ps.phase == PH_DONE;
+        const unsigned long long pmask = __ballot(parked);
+        const unsigned long long rmask = __ballot(ps.phase != PH_DONE && ps.phase != PH_IDLE);
+        if (!pmask && !rmask) break;
+        const unsigned long long s0 = STAMP();
+        if (pmask && (__popcll(pmask) >= batch || !rmask)) {
+            n_mh++;
+            if (prio) __builtin_amdgcn_s_setprio(2);
+            if (qn >= 63u) v4_flush(P, L, qn, lane);
+            // ---- decide (parked chain lanes): weights, commit mode, what the chain does next
+            int commit = 0, kind = 0; // kind: 0 nothing / finished, 1 next mutation, 2 second stage, 3 Green's reverse
+            bool want0 = false, want1 = false, want2 = false;
+            float e0x = 0.f, e0y = 0.f, e0r = 0.f, e0g = 0.f, e0b = 0.f;
+            float e1x = 0.f, e1y = 0.f, e1r = 0.f, e1g = 0.f, e1b = 0.f;
+            float e2x = 0.f, e2y = 0.f, e2r = 0.f, e2g = 0.f, e2b = 0.f;
+            if (parked) {
+                const MhOutcome o = mh_decide(P, cs, smp, ps, ct);
+                if (o.decided) {
+                    cum += o.w0;
+                    const bool a1st = o.commit == SM_STAGE1, a2nd = o.commit == SM_STAGE2;
+                    // rejected proposals are splatted now, an adopted one carries its weight into `cum`
+                    want1 = !a1st && o.w1 > 0.f;
+                    e1x = cs.y.px; e1y = cs.y.py; e1r = cs.y.r * o.w1; e1g = cs.y.g * o.w1; e1b = cs.y.b * o.w1;
+                    want2 = !a2nd && o.w2 > 0.f;
+                    e2x = cs.z.px; e2y = cs.z.py; e2r = cs.z.r * o.w2; e2g = cs.z.g * o.w2; e2b = cs.z.b * o.w2;
+                    if (o.commit) {
+                        want0 = cum > 0.f;
+                        e0x = cs.cur.px; e0y = cs.cur.py; e0r = cs.cur.r * cum; e0g = cs.cur.g * cum; e0b = cs.cur.b * cum;
+                        cum = a1st ? o.w1 : o.w2;
+                        cs.cur = select_splat(a1st, cs.y, cs.z);
+                        if (o.amap) { // acceptance map: a mark at the adopted state's pixel (the weights are all zero)
+                            want1 = true; e1x = cs.cur.px; e1y = cs.cur.py;
+                            e1r = o.amap == 1 ? 1.f : 0.f; e1g = o.amap == 1 ? 0.f : 1.f; e1b = 0.f;
+                        }
+                    }
+                    commit = o.commit;
+                }
+                kind = cs.stage < 0 ? (cs.it < n_mut ? 1 : 0) : (cs.stage == 1 ? 2 : 3);
+            }
+            v4_enqueue(L, qn, want0, e0x, e0y, e0r, e0g, e0b);
+            v4_enqueue(L, qn, want1, e1x, e1y, e1r, e1g, e1b);
+            v4_enqueue(L, qn, want2, e2x, e2y, e2r, e2g, e2b);
+            const unsigned long long m1 = STAMP();
+
+            // ---- commit (DRMLTSampler::accept: uCurrent = wrap(chosen proposal)), flattened: items (accepted chain j, row
+            // quad q), chain-minor so that a pass touches as many different chains (banks) as possible
+            const uint32_t cmask = (uint32_t) __ballot(commit != 0);
+            if (cmask) {
+                if (commit) lds_list[__builtin_amdgcn_mbcnt_lo(cmask, 0u)] = (int) sub;
+                const uint32_t n = (uint32_t) __popc(cmask), total = n * nb1;
+                const float rcp_n = 1.f / (float) n;
+                for (uint32_t base = 0u; base < total; base += 64u) {
+                    const uint32_t i = base + lane;
+                    const bool valid = i < total;
+                    const uint32_t ii = valid ? i : 0u;
+                    const uint32_t q = (uint32_t) (((float) ii + 0.5f) * rcp_n), j = ii - q * n;
+                    const uint32_t cj = (uint32_t) lds_list[j];
+                    const int mode_j = __shfl(commit, (int) cj, 64);
+                    if (valid) {
+                        const float *src = &lds_x[(mode_j == SM_STAGE1 ? smp.y_off : smp.z_off) + 4u * q * S + cj];
+                        float *dst = &lds_x[4u * q * S + cj];
+#pragma unroll
+                        for (uint32_t r = 0; r < 4u; ++r)
+                            if (4u * q + r < (uint32_t) D) dst[r * S] = wrap01(src[r * S]);
+                    }
+                }
+            }
+            const unsigned long long m2 = STAMP();
+
+            // ---- start (parked chain lanes): the coins of the mutation that begins were drawn with the previous one
+            if (parked && kind == 1) {
+                const float *cn = &lds_x[L.coin_off + sub];
+                cs.large = cn[0] < P.p_large;
+                cs.coin_acc1 = cn[S]; cs.coin_acc2 = cn[2u * S]; cs.coin_mix = cn[3u * S];
+                cs.stage = 0;
+                cs.do_second = false;
+                cs.nd1 = cs.nd2 = 0u;
+            }
+            const unsigned long long m3 = STAMP();
+
+            // ---- proposals of the chains that start a mutation, flattened: items (chain j, Philox block b) -> dimensions
+            // 4b..4b+3 of y; block nb1 = the four coins (large step, first / second acceptance, mixture) of the NEXT mutation
+            const uint32_t maj_mine = mut_base + cs.it; // the mutation in flight (cs.it counts decided mutations)
+            const unsigned info = cs.large ? 1u : 0u;
+            const uint32_t f1mask = (uint32_t) __ballot(kind == 1);
+            if (f1mask) {
+                if (kind == 1) lds_list[__builtin_amdgcn_mbcnt_lo(f1mask, 0u)] = (int) sub;
+                const uint32_t n = (uint32_t) __popc(f1mask), total = n * (nb1 + 1u);
+                const float rcp_n = 1.f / (float) n;
+                for (uint32_t base = 0u; base < total; base += 64u) {
+                    const uint32_t i = base + lane;
+                    const bool valid = i < total;
+                    const uint32_t ii = valid ? i : 0u;
+                    const uint32_t b = (uint32_t) (((float) ii + 0.5f) * rcp_n), j = ii - b * n;
+                    const uint32_t cj = (uint32_t) lds_list[j];
+                    const uint32_t mj = (uint32_t) __shfl((int) maj_mine, (int) cj, 64);
+                    const unsigned inf = (unsigned) __shfl((int) info, (int) cj, 64);
+                    if (valid) {
+                        if (b < nb1) smp.fill_first(cj, b, mj, chain_base + cj, inf != 0u);
+                        else {
+                            const u4 coins = philox4x32_10(P.key0, P.key1, 0u, mj + 1u, chain_base + cj, TAG_COIN);
+                            float *dst = &lds_x[L.coin_off + cj];
+                            dst[0] = u32_to_unit(coins.x); dst[S] = u32_to_unit(coins.y); dst[2u * S] = u32_to_unit(coins.z); dst[3u * S] = u32_to_unit(coins.w);
+                        }
+                    }
+                }
+            }
+            const uint32_t f2mask = (uint32_t) __ballot(kind == 2);
+            if (f2mask) { // second-stage proposals (rare: rejected bold steps)
+                if (kind == 2) lds_list[__builtin_amdgcn_mbcnt_lo(f2mask, 0u)] = (int) sub;
+                // blocks per chain: uniforms for a large step (one per dim), the orbital angles (one per pair), Gaussian pairs otherwise
+                const uint32_t nb2 = P.type == 2 ? (P.timid_after_large ? D4 / 4u : (D4 / 2u + 3u) / 4u) : D4 / 2u;
+                const uint32_t n = (uint32_t) __popc(f2mask), total = n * nb2;
+                const float rcp_n = 1.f / (float) n;
+                for (uint32_t base = 0u; base < total; base += 64u) {
+                    const uint32_t i = base + lane;
+                    const bool valid = i < total;
+                    const uint32_t ii = valid ? i : 0u;
+                    const uint32_t b = (uint32_t) (((float) ii + 0.5f) * rcp_n), j = ii - b * n;
+                    const uint32_t cj = (uint32_t) lds_list[j];
+                    const uint32_t mj = (uint32_t) __shfl((int) maj_mine, (int) cj, 64);
+                    const unsigned inf = (unsigned) __shfl((int) info, (int) cj, 64);
+                    if (valid) smp.fill_second(cj, b, D4, mj, chain_base + cj, inf != 0u);
+                }
+            }
+            const unsigned long long m4 = STAMP();
+
+            // ---- begin the evaluation (parked chain lanes): film position and camera ray from the first two components
+            if (parked) {
+                if (kind == 0) ps.phase = PH_IDLE;
+                else {
+                    smp.mode = cs.stage == 0 ? SM_STAGE1 : (cs.stage == 1 ? SM_STAGE2 : SM_REVERSE);
+                    path_init(P, ps);
+                    const float v0 = smp.next(0u), v1 = smp.next(1u);
+                    path_begin(P, ps, v0, v1);
+                }
+            }
+            const unsigned long long m5 = STAMP();
+            t_decide += m1 - s0; t_commit += m2 - m1; t_fill += m4 - m3; t_start += (m3 - m2) + (m5 - m4);
+        }
+        // one ray per lane: chain lanes their camera / bounce ray, helpers the shadow ray they were handed
+        const unsigned long long s1 = STAMP();
+        const bool tracing = helper ? helper_has_ray : ps.phase == PH_CLOSEST;
+        if (stamps) n_busy += __popcll(__ballot(tracing));
+        if (stamps) { const int nl = __popcll(__ballot(tracing && !helper)); hist[nl == 0 ? 0 : (nl <= 4 ? 1 : (nl <= 8 ? 2 : (nl <= 16 ? 3 : (nl <= 24 ? 4 : 5))))]++; }
+        if (prio) __builtin_amdgcn_s_setprio(0);
+        if (tracing) h = trace<FEAT>(P, ps.o, ps.d, ps.tmin, ps.tmax, helper);
+        if (prio) __builtin_amdgcn_s_setprio(3);
+        const unsigned long long s2 = STAMP();
+        const unsigned occluded = from_upper_u((helper_has_ray && h.prim >= 0) ? 1u : 0u);
+        helper_has_ray = false;
+        ShadowRay sr;
+        sr.o = ps.o; sr.d = ps.d; sr.tmin = 0.f; sr.tmax = 0.f; sr.valid = false;
+        if (!helper && ps.phase != PH_DONE && ps.phase != PH_IDLE) {
+            if (LDS_TABLES) path_step<true, FEAT, RowSampler, LdsTables, false>(P, LT, ps, smp, h, occluded == 0u, sr);
+            else path_step<true, FEAT, RowSampler, GlobalTables, false>(P, GT, ps, smp, h, occluded == 0u, sr);
+        }
+        // hand the shadow ray of this vertex to the helper lane
+        const float ox = from_lower(sr.o.x), oy = from_lower(sr.o.y), oz = from_lower(sr.o.z);
+        const float dx = from_lower(sr.d.x), dy = from_lower(sr.d.y), dz = from_lower(sr.d.z);
+        const float t0 = from_lower(sr.tmin), t1 = from_lower(sr.tmax);
+        const float vf = from_lower(sr.valid ? 1.f : 0.f);
+        if (helper) {
+            ps.o = mk3(ox, oy, oz); ps.d = mk3(dx, dy, dz); ps.tmin = t0; ps.tmax = t1;
+            helper_has_ray = vf != 0.f;
+        }
+        const unsigned long long s3 = STAMP();
+        t_mh += s1 - s0; t_trace += s2 - s1; t_step += s3 - s2; n_iter++;
+    }
+#undef STAMP
+    // "Perform the last splat": the current states with what they have accumulated since they were adopted
+    v4_enqueue(L, qn, live && cum > 0.f, cs.cur.px, cs.cur.py, cs.cur.r * cum, cs.cur.g * cum, cs.cur.b * cum);
+    v4_flush(P, L, qn, lane);
+    if (stamps && lane == 0) {
+        atomicAdd(P.stats + 16, t_mh); atomicAdd(P.stats + 17, t_trace); atomicAdd(P.stats + 18, t_step);
+        atomicAdd(P.stats + 19, n_iter); atomicAdd(P.stats + 20, n_mh); atomicAdd(P.stats + 21, n_busy);
+        for (int q = 0; q < 6; ++q) atomicAdd(P.stats + 26 + q, hist[q]);
+        atomicAdd(P.stats + 22, t_decide); atomicAdd(P.stats + 23, t_commit); atomicAdd(P.stats + 24, t_start); atomicAdd(P.stats + 25, t_fill);
+    }
+
+    if (live) {
+        for (int k = 0; k < D; ++k) P.x[(size_t) k * P.n_chains + c] = lds_x[(uint32_t) k * S + sub];
+        P.cur_lum[c] = cs.cur.lum; P.cur_px[c] = cs.cur.px; P.cur_py[c] = cs.cur.py;
+        P.cur_r[c] = cs.cur.r; P.cur_g[c] = cs.cur.g; P.cur_b[c] = cs.cur.b;
+    }
+    unsigned long long v[9];
+    v[0] = wave_sum(ct.large_acc1l & 0xffffu); v[1] = wave_sum(ct.large_acc1l >> 16);
+    v[2] = wave_sum(ct.acc1b_secl & 0xffffu);  v[3] = wave_sum(ct.acc1b_secl >> 16);
+    v[4] = wave_sum(ct.secb_acc2l & 0xffffu);  v[5] = wave_sum(ct.secb_acc2l >> 16);
+    v[6] = wave_sum(ct.acc2b_rev & 0xffffu);   v[7] = wave_sum(ct.acc2b_rev >> 16);
+    v[8] = wave_sum(ct.rays);
+    if (lane == 0)
+        for (int i = 0; i < 9; ++i) atomicAdd(P.stats + i, v[i]);
+}
+
 __global__ void __launch_bounds__(64) k_eval_paths(DParams P, const float *u, uint32_t n, uint32_t dim, float *out8) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -792,6 +1135,19 @@ void launch_mutate(const DParams &P, uint32_t n_mut, uint32_t mut_base, hipStrea
     dim3 grid((P.n_chains + CHAIN_BLOCK - 1) / CHAIN_BLOCK), block(CHAIN_BLOCK);
     if (P.kernel_variant == 1) {
         hipLaunchKernelGGL(k_mutate, grid, block, D * 64 * sizeof(float), st, P, n_mut, mut_base);
+    } else if (P.kernel_variant == 4) { // free-running chains, flattened bookkeeping, queued splats (rows of 33 floats)
+        size_t lds = ((D + 2 * D4 + 4) * V4_STRIDE + 32 + 5 * V4_QCAP + 3) / 4 * 4 * sizeof(float);
+        if (P.tables_in_lds) lds += (size_t) P.n_shade * 64 + (size_t) P.n_bsdfs * 48 + (size_t) P.n_emitters * 32;
+        if (getenv("DRMLT_VERBOSE")) fprintf(stderr, "[drmlt] k_mutate_v4: %zu B of LDS per wave\n", lds);
+        const dim3 g4((P.n_chains + 31) / 32);
+        if (P.tables_in_lds) {
+            if (P.features == 0) hipLaunchKernelGGL((k_mutate_v4<0, true>), g4, block, lds, st, P, n_mut, mut_base);
+            else if ((P.features & ~3) == 0) hipLaunchKernelGGL((k_mutate_v4<3, true>), g4, block, lds, st, P, n_mut, mut_base);
+            else if ((P.features & 8) == 0) hipLaunchKernelGGL((k_mutate_v4<7, true>), g4, block, lds, st, P, n_mut, mut_base);
+            else hipLaunchKernelGGL((k_mutate_v4<15, true>), g4, block, lds, st, P, n_mut, mut_base);
+        } else {
+            hipLaunchKernelGGL((k_mutate_v4<15, false>), g4, block, lds, st, P, n_mut, mut_base);
+        }
     } else if (P.kernel_variant == 3) { // 32 chains per wave, rows of 32 floats
         size_t lds = (D + 2 * D4) * 32 * sizeof(float);
         if (P.tables_in_lds) lds += (size_t) P.n_shade * 64 + (size_t) P.n_bsdfs * 48 + (size_t) P.n_emitters * 32;
