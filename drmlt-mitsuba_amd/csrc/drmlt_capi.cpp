@@ -659,9 +659,12 @@ int drmlt_set_importance_map(drmlt_ctx *ctx, const float *lum_map_or_null) {
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     if (!lum_map_or_null) { ctx->P.importance = nullptr; return DRMLT_OK; }
     const size_t n = (size_t) ctx->P.width * ctx->P.height;
+    // Zero entries are legal: a first-stage image with an unlit region has them (mltLuminancePass applies no floor,
+    // util.cpp:190-196). SplatList::normalize then divides by zero, the list luminance becomes inf and the chain loop
+    // rejects the proposal (isInvalid, drmlt_proc.cpp:428) -- the kernels do the same (normalize_splat, lum_invalid).
     for (size_t i = 0; i < n; ++i)
-        if (!(lum_map_or_null[i] > 0.f) || !std::isfinite(lum_map_or_null[i]))
-            return ctx->fail(DRMLT_E_INVALID, "importance map must be positive and finite (pixel %zu)", i);
+        if (!(lum_map_or_null[i] >= 0.f) || !std::isfinite(lum_map_or_null[i]))
+            return ctx->fail(DRMLT_E_INVALID, "importance map must be non-negative and finite (pixel %zu)", i);
     HIP_TRY(ctx, ctx->d_importance.alloc(n * sizeof(float)));
     HIP_TRY(ctx, hipMemcpy(ctx->d_importance.p, lum_map_or_null, n * sizeof(float), hipMemcpyHostToDevice));
     ctx->P.importance = ctx->d_importance.as<float>();

@@ -235,7 +235,7 @@ __global__ void __launch_bounds__(CHAIN_BLOCK) k_mutate_pssmlt(DParams P, uint32
         bool accept = false;
         float wc, wp = 0.f;
         if (a > 0.f) {
-            if (P.kelemen_weights) { // :197-203
+            if (P.kelemen_weights && !P.importance) { // :197-203: "Kelemen-style weights don't work for 2-stage MLT" (the a <= 0 branch keeps them)
                 wc = (1.f - a) * cur.lum / (cur.lum / b + pLarge);
                 wp = (a + (large ? 1.f : 0.f)) * y.lum / (y.lum / b + pLarge);
             } else {
@@ -766,6 +766,17 @@ __global__ void __launch_bounds__(CHAIN_BLOCK) k_mutate_v3(DParams P, uint32_t n
 #define V4_STRIDE 33u // row stride of the sampler rows: (row + chain) mod 32 banks serve per-chain AND per-dimension access patterns
 #define V4_QCAP 160u  // splat queue entries: flushed at >= 63, one bookkeeping branch adds at most 3 x 32
 
+// field-by-field copy of the parameter block out of the kernarg segment (constant address space: scalar loads)
+typedef const DParams __attribute__((address_space(4))) *KArgPtr;
+DEV void load_params(DParams &dst, KArgPtr src) {
+    static_assert(sizeof(DParams) % 8 == 0, "DParams is copied in 8-byte words");
+    typedef const unsigned long long __attribute__((address_space(4))) *KWords;
+    const KWords q = (KWords) src;
+    unsigned long long *d = reinterpret_cast<unsigned long long *>(&dst);
+#pragma unroll
+    for (unsigned i = 0; i < sizeof(DParams) / 8u; ++i) d[i] = q[i];
+}
+
 struct V4Lds {
     uint32_t coin_off, list_off, q_off; // float offsets into lds_x
 };
@@ -811,8 +822,22 @@ DEV void v4_flush(const DParams &P, const V4Lds &L, uint32_t &qn, uint32_t lane)
     qn = 0u;
 }
 
-template <int FEAT, bool LDS_TABLES>
+// STAMPS: the diagnostic build (DRMLT_DEBUG bit 128) with s_memtime section stamps; a compile-time switch because its
+// sixteen 64-bit wave-uniform accumulators would otherwise sit in (and spill from) the scalar registers of the real kernel.
+template <int FEAT, bool LDS_TABLES, bool STAMPS>
 __global__ void __launch_bounds__(CHAIN_BLOCK) k_mutate_v4(DParams P, uint32_t n_mut, uint32_t mut_base) {
+    // The parameter block is ~80 dwords, most of it used by one loop section only. Left to itself the compiler loads every
+    // field it will ever need before the loop and then spills scalar registers into vector lanes all through the loop
+    // (a sixth of the kernel's VALU instructions were v_readlane / v_writelane). Each loop section therefore works on its
+    // own copy of the block, read through a kernarg pointer the compiler cannot see through: the fields a section uses
+    // are scalar loads at its head (scalar cache hits) and dead at its end.
+    typedef const DParams __attribute__((address_space(4))) *KArg;
+    const KArg kp = (KArg) __builtin_amdgcn_kernarg_segment_ptr();
+#define SECTION_PARAMS(name)                                               \
+    KArg name##_q = kp;                                                    \
+    asm volatile("" : "+s"(name##_q));                                     \
+    DParams name;                                                          \
+    load_params(name, name##_q)
     const uint32_t lane = threadIdx.x;
     const uint32_t sub = lane & 31u;
     const bool helper = lane >= 32u;
@@ -869,7 +894,7 @@ __global__ void __launch_bounds__(CHAIN_BLOCK) k_mutate_v4(DParams P, uint32_t n
     }
 
     const bool prio = (P.debug & 1024) == 0;
-    const bool stamps = (P.debug & 128) != 0;
+    constexpr bool stamps = STAMPS;
     unsigned long long t_mh = 0, t_trace = 0, t_step = 0, n_iter = 0, n_mh = 0, n_busy = 0;
     unsigned long long t_decide = 0, t_commit = 0, t_start = 0, t_fill = 0;
     unsigned long long hist[6] = {0, 0, 0, 0, 0, 0};
@@ -882,8 +907,9 @@ __global__ void __launch_bounds__(CHAIN_BLOCK) k_mutate_v4(DParams P, uint32_t n
         const unsigned long long s0 = STAMP();
         if (pmask && (__popcll(pmask) >= batch || !rmask)) {
             n_mh++;
+            SECTION_PARAMS(Pm);
             if (prio) __builtin_amdgcn_s_setprio(2);
-            if (qn >= 63u) v4_flush(P, L, qn, lane);
+            if (qn >= 63u) v4_flush(Pm, L, qn, lane);
             // ---- decide (parked chain lanes): weights, commit mode, what the chain does next
             int commit = 0, kind = 0; // kind: 0 nothing / finished, 1 next mutation, 2 second stage, 3 Green's reverse
             bool want0 = false, want1 = false, want2 = false;
@@ -891,7 +917,7 @@ __global__ void __launch_bounds__(CHAIN_BLOCK) k_mutate_v4(DParams P, uint32_t n
             float e1x = 0.f, e1y = 0.f, e1r = 0.f, e1g = 0.f, e1b = 0.f;
             float e2x = 0.f, e2y = 0.f, e2r = 0.f, e2g = 0.f, e2b = 0.f;
             if (parked) {
-                const MhOutcome o = mh_decide(P, cs, smp, ps, ct);
+                const MhOutcome o = mh_decide(Pm, cs, smp, ps, ct);
                 if (o.decided) {
                     cum += o.w0;
                     const bool a1st = o.commit == SM_STAGE1, a2nd = o.commit == SM_STAGE2;
@@ -947,7 +973,7 @@ __global__ void __launch_bounds__(CHAIN_BLOCK) k_mutate_v4(DParams P, uint32_t n
             // ---- start (parked chain lanes): the coins of the mutation that begins were drawn with the previous one
             if (parked && kind == 1) {
                 const float *cn = &lds_x[L.coin_off + sub];
-                cs.large = cn[0] < P.p_large;
+                cs.large = cn[0] < Pm.p_large;
                 cs.coin_acc1 = cn[S]; cs.coin_acc2 = cn[2u * S]; cs.coin_mix = cn[3u * S];
                 cs.stage = 0;
                 cs.do_second = false;
@@ -975,7 +1001,7 @@ __global__ void __launch_bounds__(CHAIN_BLOCK) k_mutate_v4(DParams P, uint32_t n
                     if (valid) {
                         if (b < nb1) smp.fill_first(cj, b, mj, chain_base + cj, inf != 0u);
                         else {
-                            const u4 coins = philox4x32_10(P.key0, P.key1, 0u, mj + 1u, chain_base + cj, TAG_COIN);
+                            const u4 coins = philox4x32_10(Pm.key0, Pm.key1, 0u, mj + 1u, chain_base + cj, TAG_COIN);
                             float *dst = &lds_x[L.coin_off + cj];
                             dst[0] = u32_to_unit(coins.x); dst[S] = u32_to_unit(coins.y); dst[2u * S] = u32_to_unit(coins.z); dst[3u * S] = u32_to_unit(coins.w);
                         }
@@ -986,7 +1012,7 @@ __global__ void __launch_bounds__(CHAIN_BLOCK) k_mutate_v4(DParams P, uint32_t n
             if (f2mask) { // second-stage proposals (rare: rejected bold steps)
                 if (kind == 2) lds_list[__builtin_amdgcn_mbcnt_lo(f2mask, 0u)] = (int) sub;
                 // blocks per chain: uniforms for a large step (one per dim), the orbital angles (one per pair), Gaussian pairs otherwise
-                const uint32_t nb2 = P.type == 2 ? (P.timid_after_large ? D4 / 4u : (D4 / 2u + 3u) / 4u) : D4 / 2u;
+                const uint32_t nb2 = Pm.type == 2 ? (Pm.timid_after_large ? D4 / 4u : (D4 / 2u + 3u) / 4u) : D4 / 2u;
                 const uint32_t n = (uint32_t) __popc(f2mask), total = n * nb2;
                 const float rcp_n = 1.f / (float) n;
                 for (uint32_t base = 0u; base < total; base += 64u) {
@@ -1007,9 +1033,9 @@ __global__ void __launch_bounds__(CHAIN_BLOCK) k_mutate_v4(DParams P, uint32_t n
                 if (kind == 0) ps.phase = PH_IDLE;
                 else {
                     smp.mode = cs.stage == 0 ? SM_STAGE1 : (cs.stage == 1 ? SM_STAGE2 : SM_REVERSE);
-                    path_init(P, ps);
+                    path_init(Pm, ps);
                     const float v0 = smp.next(0u), v1 = smp.next(1u);
-                    path_begin(P, ps, v0, v1);
+                    path_begin(Pm, ps, v0, v1);
                 }
             }
             const unsigned long long m5 = STAMP();
@@ -1021,16 +1047,22 @@ __global__ void __launch_bounds__(CHAIN_BLOCK) k_mutate_v4(DParams P, uint32_t n
         if (stamps) n_busy += __popcll(__ballot(tracing));
         if (stamps) { const int nl = __popcll(__ballot(tracing && !helper)); hist[nl == 0 ? 0 : (nl <= 4 ? 1 : (nl <= 8 ? 2 : (nl <= 16 ? 3 : (nl <= 24 ? 4 : 5))))]++; }
         if (prio) __builtin_amdgcn_s_setprio(0);
-        if (tracing) h = trace<FEAT>(P, ps.o, ps.d, ps.tmin, ps.tmax, helper);
+        {
+            SECTION_PARAMS(Pt);
+            if (tracing) h = trace<FEAT>(Pt, ps.o, ps.d, ps.tmin, ps.tmax, helper);
+        }
         if (prio) __builtin_amdgcn_s_setprio(3);
         const unsigned long long s2 = STAMP();
         const unsigned occluded = from_upper_u((helper_has_ray && h.prim >= 0) ? 1u : 0u);
         helper_has_ray = false;
         ShadowRay sr;
         sr.o = ps.o; sr.d = ps.d; sr.tmin = 0.f; sr.tmax = 0.f; sr.valid = false;
-        if (!helper && ps.phase != PH_DONE && ps.phase != PH_IDLE) {
-            if (LDS_TABLES) path_step<true, FEAT, RowSampler, LdsTables, false>(P, LT, ps, smp, h, occluded == 0u, sr);
-            else path_step<true, FEAT, RowSampler, GlobalTables, false>(P, GT, ps, smp, h, occluded == 0u, sr);
+        {
+            SECTION_PARAMS(Ps);
+            if (!helper && ps.phase != PH_DONE && ps.phase != PH_IDLE) {
+                if (LDS_TABLES) path_step<true, FEAT, RowSampler, LdsTables, false>(Ps, LT, ps, smp, h, occluded == 0u, sr);
+                else path_step<true, FEAT, RowSampler, GlobalTables, false>(Ps, GT, ps, smp, h, occluded == 0u, sr);
+            }
         }
         // hand the shadow ray of this vertex to the helper lane
         const float ox = from_lower(sr.o.x), oy = from_lower(sr.o.y), oz = from_lower(sr.o.z);
@@ -1045,6 +1077,7 @@ __global__ void __launch_bounds__(CHAIN_BLOCK) k_mutate_v4(DParams P, uint32_t n
         t_mh += s1 - s0; t_trace += s2 - s1; t_step += s3 - s2; n_iter++;
     }
 #undef STAMP
+#undef SECTION_PARAMS
     // "Perform the last splat": the current states with what they have accumulated since they were adopted
     v4_enqueue(L, qn, live && cum > 0.f, cs.cur.px, cs.cur.py, cs.cur.r * cum, cs.cur.g * cum, cs.cur.b * cum);
     v4_flush(P, L, qn, lane);
@@ -1141,12 +1174,13 @@ void launch_mutate(const DParams &P, uint32_t n_mut, uint32_t mut_base, hipStrea
         if (getenv("DRMLT_VERBOSE")) fprintf(stderr, "[drmlt] k_mutate_v4: %zu B of LDS per wave\n", lds);
         const dim3 g4((P.n_chains + 31) / 32);
         if (P.tables_in_lds) {
-            if (P.features == 0) hipLaunchKernelGGL((k_mutate_v4<0, true>), g4, block, lds, st, P, n_mut, mut_base);
-            else if ((P.features & ~3) == 0) hipLaunchKernelGGL((k_mutate_v4<3, true>), g4, block, lds, st, P, n_mut, mut_base);
-            else if ((P.features & 8) == 0) hipLaunchKernelGGL((k_mutate_v4<7, true>), g4, block, lds, st, P, n_mut, mut_base);
-            else hipLaunchKernelGGL((k_mutate_v4<15, true>), g4, block, lds, st, P, n_mut, mut_base);
+            if (P.features == 0 && (P.debug & 128)) hipLaunchKernelGGL((k_mutate_v4<0, true, true>), g4, block, lds, st, P, n_mut, mut_base);
+            else if (P.features == 0) hipLaunchKernelGGL((k_mutate_v4<0, true, false>), g4, block, lds, st, P, n_mut, mut_base);
+            else if ((P.features & ~3) == 0) hipLaunchKernelGGL((k_mutate_v4<3, true, false>), g4, block, lds, st, P, n_mut, mut_base);
+            else if ((P.features & 8) == 0) hipLaunchKernelGGL((k_mutate_v4<7, true, false>), g4, block, lds, st, P, n_mut, mut_base);
+            else hipLaunchKernelGGL((k_mutate_v4<15, true, false>), g4, block, lds, st, P, n_mut, mut_base);
         } else {
-            hipLaunchKernelGGL((k_mutate_v4<15, false>), g4, block, lds, st, P, n_mut, mut_base);
+            hipLaunchKernelGGL((k_mutate_v4<15, false, false>), g4, block, lds, st, P, n_mut, mut_base);
         }
     } else if (P.kernel_variant == 3) { // 32 chains per wave, rows of 32 floats
         size_t lds = (D + 2 * D4) * 32 * sizeof(float);

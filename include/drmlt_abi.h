@@ -62,8 +62,7 @@ enum { DRMLT_SHAPE_TRIANGLE = 0, DRMLT_SHAPE_RECTANGLE = 1, DRMLT_SHAPE_SPHERE =
 enum {
     DRMLT_BSDF_DIFFUSE = 0,        /* src/bsdfs/diffuse.cpp        */
     DRMLT_BSDF_DIELECTRIC = 1,     /* src/bsdfs/dielectric.cpp     */
-    DRMLT_BSDF_ROUGHCONDUCTOR = 2, /* src/bsdfs/roughconductor.cpp */
-    DRMLT_BSDF_CONDUCTOR = 3       /* src/bsdfs/conductor.cpp      */
+    DRMLT_BSDF_ROUGHCONDUCTOR = 2  /* src/bsdfs/roughconductor.cpp */
 };
 
 enum { DRMLT_EMITTER_AREA = 0 };   /* src/emitters/area.cpp */
@@ -131,7 +130,8 @@ typedef struct drmlt_shape {
  * DIELECTRIC: p[0]=intIOR p[1]=extIOR, rgb unused (specular refl/trans = 1).
  * ROUGHCONDUCTOR: rgb = specularReflectance, p[0]=alpha, p[1..3]=eta rgb,
  *                 p[4..6]=k rgb, p[7]: 0=beckmann 1=ggx.
- * CONDUCTOR: rgb = specularReflectance, p[1..3]=eta, p[4..6]=k. */
+ * Any other BSDF plugin (smooth conductor, plastic, ...) is refused by
+ * drmlt_create, never approximated. */
 typedef struct drmlt_bsdf {
     int32_t type;
     float   rgb[3];

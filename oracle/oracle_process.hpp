@@ -463,7 +463,7 @@ public:
             bool accept;
             F currentWeight, proposedWeight;
             if (a > 0) {
-                if (m_cfg.kelemenWeights) {
+                if (m_cfg.kelemenWeights && !m_cfg.importance) { // pssmlt_proc.cpp:203: "Kelemen-style weights don't work for 2-stage MLT"
                     currentWeight = (1 - a) * m_current.luminance / (m_current.luminance / b + pLarge);
                     proposedWeight = (a + (largeStep ? 1 : 0)) * proposed.luminance / (proposed.luminance / b + pLarge);
                 } else {

@@ -52,6 +52,73 @@ def test_weighted_chains_track_the_oracle(pkg, ob, tech, native_lib):
         ctx.set_importance_map(imp)
 
 
+@pytest.mark.parametrize("scene", ["caustic_c5", "door_c3"])
+def test_importance_map_with_unlit_regions_matches_oracle(pkg, ob, scene, native_lib):
+    """A first-stage image with black regions gives exact zeros in the map (mltLuminancePass applies no floor,
+    util.cpp:190-196): SplatList::normalize divides by them, the list luminance is inf and the proposal is rejected
+    (drmlt_proc.cpp:428). No 1e-3 floor here; part of the map is forced to zero so that chains do propose into it."""
+    sd = pkg.scenes.SCENES[scene](res=32)
+    abi = pkg.abi
+    ref = pkg.Context(abi.make_config(max_depth=6, rr_depth=100, direct_samples=-1, work_units=64), sd).render_pt(256, seed=3)
+    imp = pkg.binding.luminance_map(ref.reshape(4, 8, 4, 8, 3).mean((1, 3)), 32, 32)
+    imp[:, :6] = 0.0                                           # an unlit band that the image plane does cover
+    assert (imp == 0).any() and (imp > 0).any()
+    n_chains, n_mut = 2048, 40
+    cfg = abi.make_config(technique="path", type="orbital", max_depth=6, direct_samples=-1, work_units=n_chains,
+                          sample_count=1, luminance_samples=20000)
+    ctx, orc = pkg.Context(cfg, sd), ob.Oracle(abi, cfg, sd, 64)
+    ctx.set_importance_map(imp); orc.set_importance_map(imp)   # zeros accepted; only NaN / negative values are refused
+    bg, bo = ctx.seed(0xABCD), orc.seed(0xABCD)
+    assert bg == pytest.approx(bo, rel=1e-3)
+    (c0g, _), (c0o, _) = ctx.chain_state(34), orc.chain_state(34)
+    # seeds that fall into the zero band have infinite weighted luminance on both sides and never move
+    assert np.array_equal(np.isinf(c0g["luminance"]), np.isinf(c0o["luminance"])) or \
+        (np.isinf(c0g["luminance"]) == np.isinf(c0o["luminance"])).mean() > 0.995
+    fin = np.isfinite(c0g["luminance"]) & np.isfinite(c0o["luminance"])
+    same0 = fin & (np.abs(c0g["luminance"] - c0o["luminance"]) <= 1e-3 * np.where(fin, c0o["luminance"], 1.0))
+    assert same0.sum() > 0.4 * fin.sum()
+    ctx.run(n_chains * n_mut); orc.run(n_chains * n_mut, 8)
+    (cg, _), (co, _) = ctx.chain_state(34), orc.chain_state(34)
+    tracked = same0 & (np.abs(cg["luminance"] - co["luminance"]) <= 2e-3 * np.where(fin, co["luminance"], 1.0)) & \
+        (np.abs(cg["x"] - co["x"]) < 1e-2) & (np.abs(cg["y"] - co["y"]) < 1e-2)
+    assert tracked.sum() / same0.sum() > 0.95, tracked.sum() / same0.sum()
+    sg, so = ctx.stats(), orc.stats()
+    for k in ("first", "second", "overall"):
+        bg_, bo_ = getattr(sg, k + "_base"), getattr(so, k + "_base")
+        pg, po = getattr(sg, k + "_acc") / bg_, getattr(so, k + "_acc") / bo_
+        assert abs(pg - po) < 4 * np.sqrt(po * (1 - po) / bo_) + 0.015, (k, pg, po)
+    ig, io = ctx.develop(), orc.develop()
+    assert np.isfinite(ig).all() and np.all(ig[:, :6] == 0) and np.all(io[:, :6] == 0)   # develop multiplies the map back
+    assert (ig @ LUMW).mean() == pytest.approx((io @ LUMW).mean(), rel=1e-2)
+    with pytest.raises(pkg.DrmltError, match="non-negative"):
+        bad = imp.copy(); bad[3, 3] = -1.0
+        pkg.Context(cfg, sd).set_importance_map(bad)
+
+
+def test_pssmlt_with_importance_map_uses_veach_weights(pkg, ob, native_lib):
+    """pssmlt_proc.cpp:203: with an importance map the accepted-branch weights are Veach's expectations even when
+    kelemenStyleWeights is set ("these don't work for 2-stage MLT"); the a <= 0 branch keeps the Kelemen form."""
+    sd = pkg.scenes.cornell_c1(32)
+    abi = pkg.abi
+    ref = pkg.Context(abi.make_config(max_depth=6, rr_depth=100, direct_samples=-1, work_units=64), sd).render_pt(256, seed=3)
+    imp = np.maximum(pkg.binding.luminance_map(ref.reshape(4, 8, 4, 8, 3).mean((1, 3)), 32, 32), 1e-3)
+    n_chains, n_mut = 2048, 48
+    cfg = abi.make_config(algo=abi.ALGO_PSSMLT, technique="path", type="orbital", max_depth=8, rr_depth=5, direct_samples=-1,
+                          luminance_samples=20000, work_units=n_chains, sample_count=1, kelemen_style_weights=1)
+    ctx, orc = pkg.Context(cfg, sd), ob.Oracle(abi, cfg, sd, 64)
+    ctx.set_importance_map(imp); orc.set_importance_map(imp)
+    bg, bo = ctx.seed(0xABCD), orc.seed(0xABCD)
+    assert bg == pytest.approx(bo, rel=1e-3)
+    ctx.run(n_chains * n_mut); orc.run(n_chains * n_mut, 8)
+    fg, fo = ctx.film(), orc.film()
+    # the Kelemen weights would put b-scaled sums into the film: an order-of-magnitude difference, not a tolerance question
+    assert (fg @ LUMW).sum() == pytest.approx((fo @ LUMW).sum(), rel=1e-2)
+    blk = lambda a: (a @ LUMW).reshape(8, 4, 8, 4).sum((1, 3))
+    assert np.abs(blk(fg) - blk(fo)).sum() / blk(fo).sum() < 0.1
+    ig, io = ctx.develop(), orc.develop()
+    assert (ig @ LUMW).mean() == pytest.approx((io @ LUMW).mean(), rel=5e-3)
+
+
 def test_two_stage_render_is_unbiased_and_flatter(pkg, native_lib):
     sd = pkg.scenes.glass_sphere(64)
     abi = pkg.abi
