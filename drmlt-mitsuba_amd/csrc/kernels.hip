@@ -824,6 +824,33 @@ DEV void v4_flush(const DParams &P, const V4Lds &L, uint32_t &qn, uint32_t lane)
 
 // STAMPS: the diagnostic build (DRMLT_DEBUG bit 128) with s_memtime section stamps; a compile-time switch because its
 // sixteen 64-bit wave-uniform accumulators would otherwise sit in (and spill from) the scalar registers of the real kernel.
+// Everything wave-uniform that k_mutate_v4 derives from the parameter block: recomputed (a handful of scalar ops) by each
+// loop section from its own copy of the block, so that none of it occupies scalar registers across sections.
+struct V4Layout {
+    RowSampler smp;  // uniform fields only; `mode` and `lane` are per lane
+    V4Lds L;
+    LdsTables LT;
+    uint32_t D, D4, nb1;
+};
+DEV V4Layout v4_layout(const DParams &P) {
+    V4Layout Y;
+    Y.D = (uint32_t) P.eff_dim;
+    Y.D4 = (Y.D + 3u) & ~3u;
+    Y.nb1 = Y.D4 / 4u; // first-stage Philox blocks of a mutation; item nb1 of a chain = the coins of its NEXT mutation
+    Y.smp.key0 = P.key0; Y.smp.key1 = P.key1;
+    Y.smp.mode = SM_STAGE1; Y.smp.type = P.type; Y.smp.sigma2 = P.sigma2; Y.smp.lane = 0u;
+    Y.smp.stride = V4_STRIDE;
+    Y.smp.y_off = Y.D * V4_STRIDE;
+    Y.smp.z_off = Y.smp.y_off + Y.D4 * V4_STRIDE;
+    Y.L.coin_off = Y.smp.z_off + Y.D4 * V4_STRIDE;
+    Y.L.list_off = Y.L.coin_off + 4u * V4_STRIDE;
+    Y.L.q_off = Y.L.list_off + 32u;
+    Y.LT.shade_off = (Y.L.q_off + 5u * V4_QCAP + 3u) & ~3u;
+    Y.LT.bsdf_off = Y.LT.shade_off + (uint32_t) P.n_shade * 16u;
+    Y.LT.emit_off = Y.LT.bsdf_off + (uint32_t) P.n_bsdfs * 12u;
+    return Y;
+}
+
 template <int FEAT, bool LDS_TABLES, bool STAMPS>
 __global__ void __launch_bounds__(CHAIN_BLOCK) k_mutate_v4(DParams P, uint32_t n_mut, uint32_t mut_base) {
     // The parameter block is ~80 dwords, most of it used by one loop section only. Left to itself the compiler loads every
@@ -844,56 +871,39 @@ __global__ void __launch_bounds__(CHAIN_BLOCK) k_mutate_v4(DParams P, uint32_t n
     const uint32_t c = blockIdx.x * 32u + sub;
     const bool live = !helper && c < P.n_chains;
     const uint32_t cc = c < P.n_chains ? c : P.n_chains - 1;
-    const int D = P.eff_dim;
-    const uint32_t D4 = ((uint32_t) D + 3u) & ~3u;
     const uint32_t S = V4_STRIDE;
-    if (!helper)
-        for (int k = 0; k < D; ++k) lds_x[(uint32_t) k * S + sub] = P.x[(size_t) k * P.n_chains + cc];
-
-    ChainState cs;
-    cs.cur.lum = P.cur_lum[cc]; cs.cur.px = P.cur_px[cc]; cs.cur.py = P.cur_py[cc];
-    cs.cur.r = P.cur_r[cc]; cs.cur.g = P.cur_g[cc]; cs.cur.b = P.cur_b[cc];
-    cs.y = cs.cur; cs.z = cs.cur;
-    cs.a1 = 0.f; cs.coin_acc1 = cs.coin_acc2 = cs.coin_mix = 0.f;
-    cs.it = 0u; cs.nd1 = cs.nd2 = 0u; cs.stage = -1; cs.large = false; cs.do_second = false;
-    float cum = 0.f; // cumulative weight of the current state since it was adopted
-
-    RowSampler smp;
-    smp.key0 = P.key0; smp.key1 = P.key1;
-    smp.mode = SM_STAGE1; smp.type = P.type; smp.sigma2 = P.sigma2; smp.lane = sub;
-    smp.stride = S;
-    smp.y_off = (uint32_t) D * S;
-    smp.z_off = smp.y_off + D4 * S;
-    V4Lds L;
-    L.coin_off = smp.z_off + D4 * S;
-    L.list_off = L.coin_off + 4u * S;
-    L.q_off = L.list_off + 32u;
+    int smp_mode = SM_STAGE1; // per-lane part of the sampler (which proposal the path in flight reads)
     uint32_t qn = 0u;
+    ChainState cs;
+    float cum = 0.f; // cumulative weight of the current state since it was adopted
     Counters ct = {0u, 0u, 0u, 0u, 0u};
     PathState ps;
-    path_init(P, ps);
-    ps.phase = (live && n_mut > 0u) ? PH_DONE : PH_IDLE; // helpers stay PH_IDLE for good
-    ps.o = mk3(0.f, 0.f, 0.f); ps.d = mk3(0.f, 0.f, 1.f); ps.tmin = 0.f; ps.tmax = 0.f;
     bool helper_has_ray = false;
     Hit h{-1, 0.f, 0.f, 0.f};
-    const int batch = P.mh_batch > 32 ? 32 : P.mh_batch;
-    LdsTables LT;
-    LT.shade_off = (L.q_off + 5u * V4_QCAP + 3u) & ~3u;
-    LT.bsdf_off = LT.shade_off + (uint32_t) P.n_shade * 16u;
-    LT.emit_off = LT.bsdf_off + (uint32_t) P.n_bsdfs * 12u;
-    const GlobalTables GT{P.shade, P.bsdfs, P.emitters};
-    if (LDS_TABLES) stage_tables(P, LT, lane);
-    int *const lds_list = reinterpret_cast<int *>(&lds_x[L.list_off]);
-    const uint32_t nb1 = D4 / 4u; // first-stage Philox blocks of a mutation; item nb1 of a chain = the coins of its NEXT mutation
-    const uint32_t chain_base = P.chain_offset + blockIdx.x * 32u; // chain ids of a wave are consecutive
-    // coins of every chain's first mutation of this launch (afterwards they are drawn one mutation ahead, beside the proposal)
-    if (!helper) {
-        const u4 coins = philox4x32_10(P.key0, P.key1, 0u, mut_base, chain_base + sub, TAG_COIN);
-        float *dst = &lds_x[L.coin_off + sub];
-        dst[0] = u32_to_unit(coins.x); dst[S] = u32_to_unit(coins.y); dst[2u * S] = u32_to_unit(coins.z); dst[3u * S] = u32_to_unit(coins.w);
+    int batch;
+    {
+        const V4Layout Y = v4_layout(P);
+        if (!helper)
+            for (uint32_t k = 0; k < Y.D; ++k) lds_x[k * S + sub] = P.x[(size_t) k * P.n_chains + cc];
+        cs.cur.lum = P.cur_lum[cc]; cs.cur.px = P.cur_px[cc]; cs.cur.py = P.cur_py[cc];
+        cs.cur.r = P.cur_r[cc]; cs.cur.g = P.cur_g[cc]; cs.cur.b = P.cur_b[cc];
+        cs.y = cs.cur; cs.z = cs.cur;
+        cs.a1 = 0.f; cs.coin_acc1 = cs.coin_acc2 = cs.coin_mix = 0.f;
+        cs.it = 0u; cs.nd1 = cs.nd2 = 0u; cs.stage = -1; cs.large = false; cs.do_second = false;
+        path_init(P, ps);
+        ps.phase = (live && n_mut > 0u) ? PH_DONE : PH_IDLE; // helpers stay PH_IDLE for good
+        ps.o = mk3(0.f, 0.f, 0.f); ps.d = mk3(0.f, 0.f, 1.f); ps.tmin = 0.f; ps.tmax = 0.f;
+        batch = P.mh_batch > 32 ? 32 : P.mh_batch;
+        if (LDS_TABLES) stage_tables(P, Y.LT, lane);
+        // coins of every chain's first mutation of this launch (afterwards they are drawn one mutation ahead, beside the proposal)
+        if (!helper) {
+            const u4 coins = philox4x32_10(P.key0, P.key1, 0u, mut_base, P.chain_offset + blockIdx.x * 32u + sub, TAG_COIN);
+            float *dst = &lds_x[Y.L.coin_off + sub];
+            dst[0] = u32_to_unit(coins.x); dst[S] = u32_to_unit(coins.y); dst[2u * S] = u32_to_unit(coins.z); dst[3u * S] = u32_to_unit(coins.w);
+        }
     }
 
-    const bool prio = (P.debug & 1024) == 0;
+    constexpr bool prio = true; // wave priority by loop section (see k_mutate_v3)
     constexpr bool stamps = STAMPS;
     unsigned long long t_mh = 0, t_trace = 0, t_step = 0, n_iter = 0, n_mh = 0, n_busy = 0;
     unsigned long long t_decide = 0, t_commit = 0, t_start = 0, t_fill = 0;
@@ -908,8 +918,14 @@ __global__ void __launch_bounds__(CHAIN_BLOCK) k_mutate_v4(DParams P, uint32_t n
         if (pmask && (__popcll(pmask) >= batch || !rmask)) {
             n_mh++;
             SECTION_PARAMS(Pm);
+            const V4Layout Y = v4_layout(Pm);
+            const V4Lds &L = Y.L;
+            RowSampler smp = Y.smp;
+            smp.lane = sub; smp.mode = smp_mode;
+            const uint32_t nb1 = Y.nb1, D4 = Y.D4, D = Y.D;
+            int *const lds_list = reinterpret_cast<int *>(&lds_x[L.list_off]);
             if (prio) __builtin_amdgcn_s_setprio(2);
-            if (qn >= 63u) v4_flush(Pm, L, qn, lane);
+            if (qn >= 63u) { SECTION_PARAMS(Pf); v4_flush(Pf, L, qn, lane); }
             // ---- decide (parked chain lanes): weights, commit mode, what the chain does next
             int commit = 0, kind = 0; // kind: 0 nothing / finished, 1 next mutation, 2 second stage, 3 Green's reverse
             bool want0 = false, want1 = false, want2 = false;
@@ -964,7 +980,7 @@ __global__ void __launch_bounds__(CHAIN_BLOCK) k_mutate_v4(DParams P, uint32_t n
                         float *dst = &lds_x[4u * q * S + cj];
 #pragma unroll
                         for (uint32_t r = 0; r < 4u; ++r)
-                            if (4u * q + r < (uint32_t) D) dst[r * S] = wrap01(src[r * S]);
+                            if (4u * q + r < D) dst[r * S] = wrap01(src[r * S]);
                     }
                 }
             }
@@ -983,6 +999,10 @@ __global__ void __launch_bounds__(CHAIN_BLOCK) k_mutate_v4(DParams P, uint32_t n
 
             // ---- proposals of the chains that start a mutation, flattened: items (chain j, Philox block b) -> dimensions
             // 4b..4b+3 of y; block nb1 = the four coins (large step, first / second acceptance, mixture) of the NEXT mutation
+            SECTION_PARAMS(Pg);
+            const V4Layout Yg = v4_layout(Pg);
+            RowSampler smg = Yg.smp;
+            const uint32_t chain_base_g = Pg.chain_offset + blockIdx.x * 32u;
             const uint32_t maj_mine = mut_base + cs.it; // the mutation in flight (cs.it counts decided mutations)
             const unsigned info = cs.large ? 1u : 0u;
             const uint32_t f1mask = (uint32_t) __ballot(kind == 1);
@@ -999,9 +1019,9 @@ __global__ void __launch_bounds__(CHAIN_BLOCK) k_mutate_v4(DParams P, uint32_t n
                     const uint32_t mj = (uint32_t) __shfl((int) maj_mine, (int) cj, 64);
                     const unsigned inf = (unsigned) __shfl((int) info, (int) cj, 64);
                     if (valid) {
-                        if (b < nb1) smp.fill_first(cj, b, mj, chain_base + cj, inf != 0u);
+                        if (b < nb1) smg.fill_first(cj, b, mj, chain_base_g + cj, inf != 0u);
                         else {
-                            const u4 coins = philox4x32_10(Pm.key0, Pm.key1, 0u, mj + 1u, chain_base + cj, TAG_COIN);
+                            const u4 coins = philox4x32_10(Pg.key0, Pg.key1, 0u, mj + 1u, chain_base_g + cj, TAG_COIN);
                             float *dst = &lds_x[L.coin_off + cj];
                             dst[0] = u32_to_unit(coins.x); dst[S] = u32_to_unit(coins.y); dst[2u * S] = u32_to_unit(coins.z); dst[3u * S] = u32_to_unit(coins.w);
                         }
@@ -1012,7 +1032,7 @@ __global__ void __launch_bounds__(CHAIN_BLOCK) k_mutate_v4(DParams P, uint32_t n
             if (f2mask) { // second-stage proposals (rare: rejected bold steps)
                 if (kind == 2) lds_list[__builtin_amdgcn_mbcnt_lo(f2mask, 0u)] = (int) sub;
                 // blocks per chain: uniforms for a large step (one per dim), the orbital angles (one per pair), Gaussian pairs otherwise
-                const uint32_t nb2 = Pm.type == 2 ? (Pm.timid_after_large ? D4 / 4u : (D4 / 2u + 3u) / 4u) : D4 / 2u;
+                const uint32_t nb2 = Pg.type == 2 ? (Pg.timid_after_large ? D4 / 4u : (D4 / 2u + 3u) / 4u) : D4 / 2u;
                 const uint32_t n = (uint32_t) __popc(f2mask), total = n * nb2;
                 const float rcp_n = 1.f / (float) n;
                 for (uint32_t base = 0u; base < total; base += 64u) {
@@ -1023,7 +1043,7 @@ __global__ void __launch_bounds__(CHAIN_BLOCK) k_mutate_v4(DParams P, uint32_t n
                     const uint32_t cj = (uint32_t) lds_list[j];
                     const uint32_t mj = (uint32_t) __shfl((int) maj_mine, (int) cj, 64);
                     const unsigned inf = (unsigned) __shfl((int) info, (int) cj, 64);
-                    if (valid) smp.fill_second(cj, b, D4, mj, chain_base + cj, inf != 0u);
+                    if (valid) smg.fill_second(cj, b, D4, mj, chain_base_g + cj, inf != 0u);
                 }
             }
             const unsigned long long m4 = STAMP();
@@ -1032,10 +1052,11 @@ __global__ void __launch_bounds__(CHAIN_BLOCK) k_mutate_v4(DParams P, uint32_t n
             if (parked) {
                 if (kind == 0) ps.phase = PH_IDLE;
                 else {
-                    smp.mode = cs.stage == 0 ? SM_STAGE1 : (cs.stage == 1 ? SM_STAGE2 : SM_REVERSE);
-                    path_init(Pm, ps);
+                    SECTION_PARAMS(Pb);
+                    smp_mode = smp.mode = cs.stage == 0 ? SM_STAGE1 : (cs.stage == 1 ? SM_STAGE2 : SM_REVERSE);
+                    path_init(Pb, ps);
                     const float v0 = smp.next(0u), v1 = smp.next(1u);
-                    path_begin(Pm, ps, v0, v1);
+                    path_begin(Pb, ps, v0, v1);
                 }
             }
             const unsigned long long m5 = STAMP();
@@ -1060,8 +1081,11 @@ __global__ void __launch_bounds__(CHAIN_BLOCK) k_mutate_v4(DParams P, uint32_t n
         {
             SECTION_PARAMS(Ps);
             if (!helper && ps.phase != PH_DONE && ps.phase != PH_IDLE) {
-                if (LDS_TABLES) path_step<true, FEAT, RowSampler, LdsTables, false>(Ps, LT, ps, smp, h, occluded == 0u, sr);
-                else path_step<true, FEAT, RowSampler, GlobalTables, false>(Ps, GT, ps, smp, h, occluded == 0u, sr);
+                const V4Layout Y = v4_layout(Ps);
+                RowSampler smp = Y.smp;
+                smp.lane = sub; smp.mode = smp_mode;
+                if (LDS_TABLES) path_step<true, FEAT, RowSampler, LdsTables, false>(Ps, Y.LT, ps, smp, h, occluded == 0u, sr);
+                else path_step<true, FEAT, RowSampler, GlobalTables, false>(Ps, GlobalTables{Ps.shade, Ps.bsdfs, Ps.emitters}, ps, smp, h, occluded == 0u, sr);
             }
         }
         // hand the shadow ray of this vertex to the helper lane
@@ -1079,8 +1103,9 @@ __global__ void __launch_bounds__(CHAIN_BLOCK) k_mutate_v4(DParams P, uint32_t n
 #undef STAMP
 #undef SECTION_PARAMS
     // "Perform the last splat": the current states with what they have accumulated since they were adopted
-    v4_enqueue(L, qn, live && cum > 0.f, cs.cur.px, cs.cur.py, cs.cur.r * cum, cs.cur.g * cum, cs.cur.b * cum);
-    v4_flush(P, L, qn, lane);
+    const V4Layout Y = v4_layout(P);
+    v4_enqueue(Y.L, qn, live && cum > 0.f, cs.cur.px, cs.cur.py, cs.cur.r * cum, cs.cur.g * cum, cs.cur.b * cum);
+    v4_flush(P, Y.L, qn, lane);
     if (stamps && lane == 0) {
         atomicAdd(P.stats + 16, t_mh); atomicAdd(P.stats + 17, t_trace); atomicAdd(P.stats + 18, t_step);
         atomicAdd(P.stats + 19, n_iter); atomicAdd(P.stats + 20, n_mh); atomicAdd(P.stats + 21, n_busy);
@@ -1089,7 +1114,7 @@ __global__ void __launch_bounds__(CHAIN_BLOCK) k_mutate_v4(DParams P, uint32_t n
     }
 
     if (live) {
-        for (int k = 0; k < D; ++k) P.x[(size_t) k * P.n_chains + c] = lds_x[(uint32_t) k * S + sub];
+        for (uint32_t k = 0; k < Y.D; ++k) P.x[(size_t) k * P.n_chains + c] = lds_x[k * S + sub];
         P.cur_lum[c] = cs.cur.lum; P.cur_px[c] = cs.cur.px; P.cur_py[c] = cs.cur.py;
         P.cur_r[c] = cs.cur.r; P.cur_g[c] = cs.cur.g; P.cur_b[c] = cs.cur.b;
     }
