@@ -4,4 +4,4 @@ The directory name is not a valid Python identifier; load it with
 `__graft_entry__.load_package()` (registers it as module `drmlt_mitsuba_amd`).
 """
 from . import abi, exchange, heatmap, scenes  # noqa: F401
-from .binding import Context, DrmltError, build_native, library_path  # noqa: F401
+from .binding import Context, DrmltError, Node, build_native, comm_unique_id, library_path  # noqa: F401

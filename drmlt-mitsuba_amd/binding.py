@@ -25,6 +25,10 @@ ABI_SYMBOLS = (
     "drmlt_film_read", "drmlt_film_clear", "drmlt_film_device_ptr", "drmlt_set_luminance", "drmlt_set_stream",
     "drmlt_kernel_time", "drmlt_render_pt", "drmlt_chain_state", "drmlt_last_error", "drmlt_abi_version",
     "drmlt_destroy", "drmlt_set_importance_map", "drmlt_luminance_map", "drmlt_eval_lists",
+    "drmlt_seed_pool", "drmlt_comm_unique_id", "drmlt_comm_init", "drmlt_exchange_tiled",
+    "drmlt_node_create", "drmlt_node_seed", "drmlt_node_run", "drmlt_node_develop", "drmlt_node_stats_get",
+    "drmlt_node_set_importance_map", "drmlt_node_device_count", "drmlt_node_context", "drmlt_node_last_error",
+    "drmlt_node_destroy",
 )
 
 
@@ -79,6 +83,23 @@ def load_library():
     L.drmlt_last_error.argtypes = [C.c_void_p]
     L.drmlt_abi_version.restype = C.c_uint32
     L.drmlt_destroy.argtypes = [C.c_void_p]
+    L.drmlt_seed_pool.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.POINTER(C.c_double)]
+    L.drmlt_comm_unique_id.argtypes = [C.c_char_p]
+    L.drmlt_comm_init.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.c_int]
+    L.drmlt_exchange_tiled.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.drmlt_node_create.restype = C.c_void_p
+    L.drmlt_node_create.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_char_p, C.c_size_t]
+    L.drmlt_node_seed.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(C.c_double)]
+    L.drmlt_node_run.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.drmlt_node_develop.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    L.drmlt_node_stats_get.argtypes = [C.c_void_p, C.c_void_p]
+    L.drmlt_node_set_importance_map.argtypes = [C.c_void_p, C.c_void_p]
+    L.drmlt_node_device_count.argtypes = [C.c_void_p]
+    L.drmlt_node_context.restype = C.c_void_p
+    L.drmlt_node_context.argtypes = [C.c_void_p, C.c_int]
+    L.drmlt_node_last_error.restype = C.c_char_p
+    L.drmlt_node_last_error.argtypes = [C.c_void_p]
+    L.drmlt_node_destroy.argtypes = [C.c_void_p]
     _lib = L
     return L
 
@@ -119,6 +140,26 @@ class Context:
         b = C.c_double()
         self._chk(self.L.drmlt_seed(self.h, seed, chain_offset, C.byref(b)))
         return b.value
+
+    def seed_pool(self, seed, first_chain, pool_chains):
+        """Seeds [first_chain, first_chain + work_units) of ONE pool drawn for `pool_chains` chains."""
+        b = C.c_double()
+        self._chk(self.L.drmlt_seed_pool(self.h, seed, first_chain, pool_chains, C.byref(b)))
+        return b.value
+
+    # -- film exchange over RCCL, called from C++ inside the library (one process per GPU)
+    def comm_init(self, unique_id, rank, world):
+        self._chk(self.L.drmlt_comm_init(self.h, unique_id, rank, world))
+
+    def exchange_tiled(self, b, want_tile=True):
+        """reduce-scatter(sum) of the film + scalar all-reduce + develop of this rank's tile.
+        Returns (tile [rows, W, 3] or None, (row_lo, row_hi), mean b)."""
+        bb, lo, hi = C.c_double(b), C.c_int(), C.c_int()
+        buf = np.zeros((self.height, self.width, 3), dtype=np.float32) if want_tile else None
+        self._chk(self.L.drmlt_exchange_tiled(self.h, C.byref(bb), buf.ctypes.data if want_tile else None,
+                                              C.byref(lo), C.byref(hi)))
+        tile = buf[:hi.value - lo.value] if want_tile else None
+        return tile, (lo.value, hi.value), bb.value
 
     def run(self, total_mutations, stop=None, progress=None):
         cb = abi.PROGRESS_CB(lambda d, t, u: progress(d, t)) if progress else None
@@ -255,3 +296,80 @@ def render_two_stage(cfg, scene_data, seed, size_reduction=16, device=0):
     b = ctx.seed(seed)
     ctx.run(cam.width * cam.height * cfg.sample_count)
     return ctx.develop(), lum, b
+
+
+def comm_unique_id():
+    """ncclUniqueId of a new communicator (rank 0 creates it and hands it to the other ranks)."""
+    L = load_library()
+    buf = C.create_string_buffer(128)
+    rc = L.drmlt_comm_unique_id(buf)
+    if rc != 0:
+        raise DrmltError(rc, "RCCL is not available")
+    return buf.raw
+
+
+class Node:
+    """One process driving several GPUs (drmlt_node_*): what the Mitsuba plugin uses. `work_units` of the config is
+    per device; chains, seeds and the film exchange (RCCL, in C++) are handled inside the library."""
+
+    def __init__(self, cfg, scene_data, device_mask=1):
+        self.L = load_library()
+        self.cfg, self.scene_data = cfg, scene_data
+        self._scene = scene_data.struct()
+        err = C.create_string_buffer(512)
+        self.h = self.L.drmlt_node_create(C.byref(cfg), C.byref(self._scene), device_mask, err, 512)
+        if not self.h:
+            raise DrmltError(abi.E_INVALID, err.value.decode())
+        self.width, self.height = scene_data.camera.width, scene_data.camera.height
+        self._cb = None
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.drmlt_node_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise DrmltError(rc, self.L.drmlt_node_last_error(self.h).decode())
+
+    @property
+    def device_count(self):
+        return self.L.drmlt_node_device_count(self.h)
+
+    def seed(self, seed):
+        b = C.c_double()
+        self._chk(self.L.drmlt_node_seed(self.h, seed, C.byref(b)))
+        return b.value
+
+    def run(self, total_mutations, stop=None, progress=None):
+        cb = abi.PROGRESS_CB(lambda d, t, u: progress(d, t)) if progress else None
+        self._cb = cb
+        stop_p = C.cast(C.pointer(stop), C.c_void_p) if stop is not None else None
+        self._chk(self.L.drmlt_node_run(self.h, total_mutations, stop_p, C.cast(cb, C.c_void_p) if cb else None, None))
+
+    def develop(self, direct=None):
+        out = np.empty((self.height, self.width, 3), dtype=np.float32)
+        d = np.ascontiguousarray(direct, dtype=np.float32) if direct is not None else None
+        self._chk(self.L.drmlt_node_develop(self.h, d.ctypes.data if d is not None else None, out.ctypes.data))
+        return out
+
+    def set_importance_map(self, lum_map):
+        m = np.ascontiguousarray(lum_map, dtype=np.float32) if lum_map is not None else None
+        self._chk(self.L.drmlt_node_set_importance_map(self.h, m.ctypes.data if m is not None else None))
+
+    def stats(self):
+        st = abi.Stats()
+        self._chk(self.L.drmlt_node_stats_get(self.h, C.byref(st)))
+        return st
+
+    def film(self, rank):
+        """Raw film of one rank (test inspection)."""
+        out = np.empty((self.height, self.width, 3), dtype=np.float32)
+        h = self.L.drmlt_node_context(self.h, rank)
+        rc = self.L.drmlt_film_read(h, out.ctypes.data)
+        if rc != 0:
+            raise DrmltError(rc, self.L.drmlt_last_error(h).decode())
+        return out

@@ -4,6 +4,7 @@
 #include "../../include/drmlt_abi.h"
 #include "bvh_build.h"
 #include "device_types.h"
+#include "drmlt_ctx.h"
 
 #include <hip/hip_runtime.h>
 
@@ -34,8 +35,6 @@ void launch_init_chains_bdpt(const DParams &P, const uint32_t *seed_index, const
 void launch_mutate_bdpt(const DParams &P, uint32_t n_mut, uint32_t mut_base, hipStream_t st);
 void launch_eval_lists_bdpt(const DParams &P, const float *u, uint32_t n, uint32_t dim, float *out, uint32_t stride, hipStream_t st);
 void launch_render_pt(const DParams &P, uint64_t n_samples, uint32_t stream, float scale, hipStream_t st);
-void launch_lum_sum(const float *film, const float *importance, uint32_t n_pixels, double *sum, hipStream_t st);
-void launch_develop(const float *film, const float *direct, const float *importance, float factor, uint32_t n, float *out, hipStream_t st);
 
 namespace {
 
@@ -52,62 +51,12 @@ void philox_host(uint32_t k0, uint32_t k1, uint32_t c0, uint32_t c1, uint32_t c2
     out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
 
-struct DevBuf {
-    void *p = nullptr;
-    size_t bytes = 0;
-    ~DevBuf() { if (p) (void) hipFree(p); }
-    hipError_t alloc(size_t n) {
-        if (p) { (void) hipFree(p); p = nullptr; }
-        bytes = n;
-        return n ? hipMalloc(&p, n) : hipSuccess;
-    }
-    template <typename T> T *as() const { return static_cast<T *>(p); }
-};
-
 } // namespace
 
-struct drmlt_ctx {
-    drmlt_config cfg{};
-    int device = 0;
-    hipStream_t stream = nullptr;
-    bool own_stream = false;
-    DParams P{};
-    std::string error;
-
-    int bvh_depth = 0;
-    DevBuf d_prims, d_shade, d_bsdfs, d_emitters, d_bvh, d_lut, d_film, d_x, d_cur, d_stats, d_err, d_scratch, d_chain_i, d_importance, d_bd_verts, d_bd_lists, d_prims_flat;
-    std::vector<DPrim> prims;
-    std::vector<DShade> shade;
-
-    uint32_t n_chains = 0, mutation_base = 0, chain_offset = 0;
-    bool seeded = false;
-    double b = 0.0;
-    // accounting
-    uint64_t mutations = 0, launches = 0, accepted_dummy = 0;
-    double kernel_ms = 0.0, seed_ms = 0.0;
-    double kt_ms = 0.0; uint64_t kt_launches = 0; // drmlt_kernel_time window
-    uint64_t host_counters[9] = {0};
-    int slice = 1024; // mutations per chain per launch (<= 32768: the per-lane event counters are 16 bit)
-
-    ~drmlt_ctx() {
-        if (own_stream && stream) (void) hipStreamDestroy(stream);
-    }
-    int fail(int code, const char *fmt, ...) {
-        char buf[512];
-        va_list ap;
-        va_start(ap, fmt);
-        vsnprintf(buf, sizeof buf, fmt, ap);
-        va_end(ap);
-        error = buf;
-        return code;
-    }
-};
-
-#define HIP_TRY(ctx, expr)                                                                         \
-    do {                                                                                           \
-        hipError_t e_ = (expr);                                                                    \
-        if (e_ != hipSuccess) return (ctx)->fail(DRMLT_E_DEVICE, "%s: %s", #expr, hipGetErrorString(e_)); \
-    } while (0)
+drmlt_ctx::~drmlt_ctx() {
+    if (comm) drmlt_comm_release(comm);
+    if (own_stream && stream) (void) hipStreamDestroy(stream);
+}
 
 namespace {
 
@@ -500,12 +449,13 @@ drmlt_ctx *drmlt_create(const drmlt_config *cfg, const drmlt_scene *scene, int d
         P.eff_dim = P.mmlt_S + P.mmlt_E;
     }
 
-    const size_t film_bytes = (size_t) cam.width * cam.height * 3 * sizeof(float);
+    ctx->film_floats = (size_t) cam.width * cam.height * 3;
+    const size_t film_bytes = ((size_t) cam.height + FILM_PAD_ROWS) * cam.width * 3 * sizeof(float); // zero rows behind the film: see FILM_PAD_ROWS
     ok = ctx->d_film.alloc(film_bytes) == hipSuccess && ctx->d_x.alloc((size_t) P.eff_dim * ctx->n_chains * sizeof(float)) == hipSuccess &&
          ctx->d_cur.alloc((size_t) 6 * ctx->n_chains * sizeof(float)) == hipSuccess && ctx->d_stats.alloc(32 * sizeof(unsigned long long)) == hipSuccess &&
          ctx->d_err.alloc(64) == hipSuccess && ctx->d_chain_i.alloc((size_t) 2 * ctx->n_chains * sizeof(int32_t)) == hipSuccess;
     if (!ok) return bail(ctx, "device allocation of chain state / film failed");
-    (void) hipMemset(ctx->d_chain_i.p, 0, (size_t) 2 * ctx->n_chains * sizeof(int32_t));
+    if (hipMemset(ctx->d_chain_i.p, 0, (size_t) 2 * ctx->n_chains * sizeof(int32_t)) != hipSuccess) return bail(ctx, "hipMemset of the chain state failed");
     P.chain_depth = ctx->d_chain_i.as<int32_t>(); P.cur_t = P.chain_depth + ctx->n_chains;
     P.importance = nullptr;
     P.bd_verts = nullptr; P.bd_lists = nullptr; P.n_chains_alloc = ctx->n_chains;
@@ -514,12 +464,12 @@ drmlt_ctx *drmlt_create(const drmlt_config *cfg, const drmlt_scene *scene, int d
         if (ctx->d_bd_verts.alloc((size_t) 20 * nvs * ctx->n_chains * sizeof(float)) != hipSuccess ||
             ctx->d_bd_lists.alloc((size_t) 3 * rows * ctx->n_chains * sizeof(float)) != hipSuccess)
             return bail(ctx, "device allocation of the bdpt workspace failed");
-        (void) hipMemset(ctx->d_bd_lists.p, 0, (size_t) 3 * rows * ctx->n_chains * sizeof(float));
+        if (hipMemset(ctx->d_bd_lists.p, 0, (size_t) 3 * rows * ctx->n_chains * sizeof(float)) != hipSuccess) return bail(ctx, "hipMemset of the bdpt workspace failed");
         P.bd_verts = ctx->d_bd_verts.as<float>(); P.bd_lists = ctx->d_bd_lists.as<float>();
     }
-    (void) hipMemset(ctx->d_film.p, 0, film_bytes);
-    (void) hipMemset(ctx->d_stats.p, 0, 32 * sizeof(unsigned long long));
-    (void) hipMemset(ctx->d_err.p, 0, 64);
+    if (hipMemset(ctx->d_film.p, 0, film_bytes) != hipSuccess || hipMemset(ctx->d_stats.p, 0, 32 * sizeof(unsigned long long)) != hipSuccess ||
+        hipMemset(ctx->d_err.p, 0, 64) != hipSuccess)
+        return bail(ctx, "hipMemset of the film / counters failed");
     P.film = ctx->d_film.as<float>();
     P.x = ctx->d_x.as<float>();
     float *cur = ctx->d_cur.as<float>();
@@ -558,22 +508,30 @@ int drmlt_set_stream(drmlt_ctx *ctx, void *hip_stream) {
     return DRMLT_OK;
 }
 
-int drmlt_seed(drmlt_ctx *ctx, uint64_t seed, uint32_t chain_offset, double *b_out) {
+// Bootstrap + seed selection + replay. `pool_chains` = 0: this context draws its own seeds from its own bootstrap stream
+// (stream id = chain_offset; per-rank estimates of b are averaged by the caller, the reference's multi-threaded seeding,
+// drmlt.cpp:531-546). `pool_chains` > 0: SURVEY 8(e)'s global pool -- the bootstrap stream 0 is sized for, and
+// `pool_chains` seeds are drawn for, the whole job (every rank repeats this cheap step and gets the same list and the
+// same b); this context then takes seeds [chain_offset, chain_offset + work_units) of the sorted list. A job split over
+// several contexts runs exactly the chains one context with pool_chains work units would.
+static int seed_impl(drmlt_ctx *ctx, uint64_t seed, uint32_t chain_offset, uint32_t pool_chains, double *b_out) {
     if (!ctx) return DRMLT_E_INVALID;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     DParams &P = ctx->P;
-    hipEvent_t e0, e1;
-    HIP_TRY(ctx, hipEventCreate(&e0));
-    HIP_TRY(ctx, hipEventCreate(&e1));
-    HIP_TRY(ctx, hipEventRecord(e0, ctx->stream));
+    const bool pool = pool_chains > 0;
+    if (pool && (uint64_t) chain_offset + ctx->n_chains > pool_chains) return ctx->fail(DRMLT_E_INVALID, "seed pool of %u chains does not cover chains [%u, %u)", pool_chains, chain_offset, chain_offset + ctx->n_chains);
+    const uint32_t n_select = pool ? pool_chains : ctx->n_chains;
+    EventPair ev;
+    HIP_TRY(ctx, ev.create());
+    HIP_TRY(ctx, hipEventRecord(ev.a, ctx->stream));
     P.key0 = (uint32_t) seed; P.key1 = (uint32_t) (seed >> 32);
-    P.chain_offset = chain_offset; P.boot_stream = chain_offset;
+    P.chain_offset = chain_offset; P.boot_stream = pool ? 0u : chain_offset;
     ctx->chain_offset = chain_offset;
     // luminance sample floor: max(luminanceSamples, 10 * workUnits), drmlt.cpp:454-466
     // technique=mmlt: x50, and as many again per depth; b is scaled by maxDepth below (drmlt.cpp:456-473,
     // pathsampler.cpp:884-890,932-934). One bootstrap stream per GPU, as with nCores = 1 in the reference.
     const bool mmlt = ctx->cfg.technique == DRMLT_TECH_MMLT;
-    uint64_t n64 = (uint64_t) std::max<int64_t>(ctx->cfg.luminance_samples, (int64_t) ctx->n_chains * (mmlt ? 50 : 10));
+    uint64_t n64 = (uint64_t) std::max<int64_t>(ctx->cfg.luminance_samples, (int64_t) n_select * (mmlt ? 50 : 10));
     if (mmlt) n64 *= (uint64_t) ctx->cfg.max_depth;
     if (n64 > 0x7fffffffull) return ctx->fail(DRMLT_E_INVALID, "too many luminance samples");
     uint32_t n = (uint32_t) n64;
@@ -607,8 +565,8 @@ int drmlt_seed(drmlt_ctx *ctx, uint64_t seed, uint32_t chain_offset, double *b_o
     const double norm = 1.0 / cdf.back();
     for (size_t i = 1; i < cdf.size(); ++i) cdf[i] *= norm;
     cdf.back() = 1.0;
-    std::vector<uint32_t> seed_index(ctx->n_chains);
-    for (uint32_t j = 0; j < ctx->n_chains; ++j) {
+    std::vector<uint32_t> seed_index(n_select);
+    for (uint32_t j = 0; j < n_select; ++j) {
         uint32_t r[4];
         philox_host(P.key0, P.key1, 0u, j, P.boot_stream, TAG_SEEDSEL, r);
         double xi = (double) ((float) (r[0] >> 8) * (1.0f / 16777216.0f));
@@ -619,6 +577,10 @@ int drmlt_seed(drmlt_ctx *ctx, uint64_t seed, uint32_t chain_offset, double *b_o
         seed_index[j] = idx[index];
     }
     std::sort(seed_index.begin(), seed_index.end()); // PathSeedSortPredicate
+    if (pool) { // this context's slice of the job's seed list
+        std::vector<uint32_t> mine(seed_index.begin() + chain_offset, seed_index.begin() + chain_offset + ctx->n_chains);
+        seed_index.swap(mine);
+    }
     std::vector<float> seed_lum(ctx->n_chains);
     for (uint32_t j = 0; j < ctx->n_chains; ++j) seed_lum[j] = lum[seed_index[j]];
 
@@ -634,12 +596,9 @@ int drmlt_seed(drmlt_ctx *ctx, uint64_t seed, uint32_t chain_offset, double *b_o
     HIP_TRY(ctx, hipGetLastError());
     int32_t flag = 0;
     HIP_TRY(ctx, hipMemcpyAsync(&flag, ctx->d_err.p, sizeof flag, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipEventRecord(e1, ctx->stream));
+    HIP_TRY(ctx, hipEventRecord(ev.b, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    float ms = 0.f;
-    (void) hipEventElapsedTime(&ms, e0, e1);
-    ctx->seed_ms += ms;
-    (void) hipEventDestroy(e0); (void) hipEventDestroy(e1);
+    ctx->seed_ms += ev.elapsed_ms();
     if (flag) return ctx->fail(DRMLT_E_REPLAY, "Error when reconstructing a seed path: luminance mismatch");
 
     ctx->b = mean;
@@ -649,6 +608,14 @@ int drmlt_seed(drmlt_ctx *ctx, uint64_t seed, uint32_t chain_offset, double *b_o
     ctx->mutation_base = 0;
     if (b_out) *b_out = ctx->b;
     return DRMLT_OK;
+}
+
+int drmlt_seed(drmlt_ctx *ctx, uint64_t seed, uint32_t chain_offset, double *b_out) { return seed_impl(ctx, seed, chain_offset, 0u, b_out); }
+
+int drmlt_seed_pool(drmlt_ctx *ctx, uint64_t seed, uint32_t first_chain, uint32_t pool_chains, double *b_out) {
+    if (!ctx) return DRMLT_E_INVALID;
+    if (pool_chains == 0) return ctx->fail(DRMLT_E_INVALID, "drmlt_seed_pool: pool_chains must be positive");
+    return seed_impl(ctx, seed, first_chain, pool_chains, b_out);
 }
 
 // Two-stage MLT (drmlt.cpp:406-418): the luminance image of the first stage weights the second stage's splats.
@@ -722,7 +689,7 @@ int drmlt_run(drmlt_ctx *ctx, uint64_t total_mutations, volatile int *stop, drml
     if (!ctx->seeded) return ctx->fail(DRMLT_E_STATE, "drmlt_run called before drmlt_seed");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const uint64_t per_chain = total_mutations / ctx->n_chains; // nMutations, drmlt.cpp:475-476
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> evs;
+    std::vector<EventPair> evs; // destroyed on every return path
     uint64_t done = 0;
     int rc = DRMLT_OK;
     // "timeout" (drmlt.cpp:296, drmlt_proc.cpp:519-521,868-877): equal-time mode. All chains run concurrently here,
@@ -735,18 +702,17 @@ int drmlt_run(drmlt_ctx *ctx, uint64_t total_mutations, volatile int *stop, drml
         // shorter launches when somebody is watching (cancellation / progress / deadline latency ~ tens of ms)
         const uint64_t slice = (stop || cb || timed) ? std::min(ctx->slice, 256) : ctx->slice;
         uint32_t n = (uint32_t) std::min<uint64_t>(slice, per_chain - done);
-        hipEvent_t a, b;
-        HIP_TRY(ctx, hipEventCreate(&a));
-        HIP_TRY(ctx, hipEventCreate(&b));
-        HIP_TRY(ctx, hipEventRecord(a, ctx->stream));
+        evs.emplace_back();
+        EventPair &ev = evs.back();
+        HIP_TRY(ctx, ev.create());
+        HIP_TRY(ctx, hipEventRecord(ev.a, ctx->stream));
         ctx->P.luminance_b = (float) ctx->b;
         if (ctx->cfg.algo == DRMLT_ALGO_PSSMLT) launch_mutate_pssmlt(ctx->P, n, ctx->mutation_base, ctx->stream);
         else if (ctx->cfg.technique == DRMLT_TECH_MMLT) launch_mutate_mmlt(ctx->P, n, ctx->mutation_base, ctx->stream);
         else if (ctx->cfg.technique == DRMLT_TECH_BDPT) launch_mutate_bdpt(ctx->P, n, ctx->mutation_base, ctx->stream);
         else launch_mutate(ctx->P, n, ctx->mutation_base, ctx->stream);
         HIP_TRY(ctx, hipGetLastError());
-        HIP_TRY(ctx, hipEventRecord(b, ctx->stream));
-        evs.emplace_back(a, b);
+        HIP_TRY(ctx, hipEventRecord(ev.b, ctx->stream));
         ctx->mutation_base += n;
         done += n;
         ctx->launches++;
@@ -756,13 +722,11 @@ int drmlt_run(drmlt_ctx *ctx, uint64_t total_mutations, volatile int *stop, drml
         }
     }
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    for (auto &e : evs) {
-        float ms = 0.f;
-        (void) hipEventElapsedTime(&ms, e.first, e.second);
+    for (const EventPair &e : evs) {
+        const float ms = e.elapsed_ms();
         ctx->kernel_ms += ms;
         ctx->kt_ms += ms;
         ctx->kt_launches++;
-        (void) hipEventDestroy(e.first); (void) hipEventDestroy(e.second);
     }
     ctx->mutations += done * ctx->n_chains;
     if (rc == DRMLT_E_CANCELLED) return ctx->fail(rc, "cancelled");
@@ -882,7 +846,7 @@ int drmlt_eval_paths(drmlt_ctx *ctx, const float *u, uint32_t n, uint32_t dim, d
 int drmlt_film_read(drmlt_ctx *ctx, float *out_rgb) {
     if (!ctx || !out_rgb) return DRMLT_E_INVALID;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    HIP_TRY(ctx, hipMemcpyAsync(out_rgb, ctx->d_film.p, ctx->d_film.bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(out_rgb, ctx->d_film.p, ctx->film_floats * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return DRMLT_OK;
 }

@@ -6,6 +6,7 @@
 //   k_eval_paths    PathSampler::sampleSplats on caller-supplied PSS points (pathsampler.cpp:529-567)
 //   k_render_pt     independent samples of the same integrand (validation image)
 //   k_lum_sum / k_develop   DRMLTProcess::develop (drmlt_proc.cpp:824-849)
+#include <algorithm>
 #include <cstdlib>
 #include <cstdio>
 #include "device_path.h"
@@ -1175,6 +1176,14 @@ __global__ void __launch_bounds__(256) k_develop(const float *film, const float 
                                                  float *out) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = film[i] * (importance ? factor * importance[i / 3u] : factor) + (direct ? direct[i] : 0.f); // :841-847
+}
+
+// dst += src (film tiles of ranks that share a device: drmlt_node.cpp's loopback transport)
+__global__ void __launch_bounds__(256) k_accumulate(float *dst, const float *src, size_t n) {
+    for (size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t) gridDim.x * blockDim.x) dst[i] += src[i];
+}
+void launch_accumulate(float *dst, const float *src, size_t n, hipStream_t st) {
+    hipLaunchKernelGGL(k_accumulate, dim3((unsigned) std::min<size_t>((n + 255) / 256, 4096)), dim3(256), 0, st, dst, src, n);
 }
 
 // ---- host-callable launchers (C++ linkage, used by drmlt_capi.cpp) --------------------------

@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define DRMLT_ABI_VERSION 1
+#define DRMLT_ABI_VERSION 2
 
 /* ---- enums (values are ABI) ------------------------------------------- */
 
@@ -278,6 +278,54 @@ int drmlt_eval_lists(drmlt_ctx *ctx, const float *u, uint32_t n, uint32_t dim,
  * components are [sensor S | emitter E]; cur = main splat of the current list
  * (normalised), n_dims = 1 if it exists, n_rays = number of light-image splats. */
 int drmlt_chain_state(drmlt_ctx *ctx, drmlt_splat *cur, float *u, uint32_t dim);
+
+/* ---- several GPUs --------------------------------------------------------
+ * Chains are independent given their seeds (drmlt_proc.cpp:869-883): the chains
+ * of a render are partitioned over the GPUs, every GPU accumulates a full-frame
+ * film, and the films are summed once at the end, where the reference merges
+ * its work units' ImageBlocks (DRMLTProcess::processResult, drmlt_proc.cpp:856-867):
+ * ncclReduceScatter(sum) leaves rank r with rows [r * ceil(H / N), ...) of the
+ * summed film, a two-element ncclAllReduce shares the film's total luminance
+ * (and the ranks' b), every rank develops its own tile (develop, :813-854).
+ * RCCL is called from C++ inside the library (loaded at run time). */
+
+/* Seeds from ONE pool for the whole job: the bootstrap is sized for
+ * `pool_chains` chains, `pool_chains` seeds are drawn (sorted), and this
+ * context takes seeds and chain ids [first_chain, first_chain + work_units).
+ * Every rank computes the same list and the same b; a job split over several
+ * contexts runs exactly the chains of one context with pool_chains work units. */
+int drmlt_seed_pool(drmlt_ctx *ctx, uint64_t seed, uint32_t first_chain,
+                    uint32_t pool_chains, double *b_out);
+
+/* (a) one process per GPU (any launcher). Rank 0 calls drmlt_comm_unique_id and
+ * hands the id to the other ranks (it is ncclUniqueId); every rank then calls
+ * drmlt_comm_init on its context. drmlt_exchange_tiled runs the film exchange
+ * on the context's stream: *b_inout = this rank's b in, the ranks' mean out;
+ * the developed tile (rows [*row_lo, *row_hi), W * 3 floats each) is copied to
+ * tile_host_or_null when given. The local film is left untouched. */
+#define DRMLT_COMM_ID_BYTES 128
+int drmlt_comm_unique_id(char id[DRMLT_COMM_ID_BYTES]);
+int drmlt_comm_init(drmlt_ctx *ctx, const char id[DRMLT_COMM_ID_BYTES], int rank, int world);
+int drmlt_exchange_tiled(drmlt_ctx *ctx, double *b_inout, float *tile_host_or_null,
+                         int *row_lo, int *row_hi);
+
+/* (b) one process drives the GPUs of `device_mask` (bit d = HIP device d): what
+ * the Mitsuba plugin uses, so that `-D integrator=drmlt` renders on the whole
+ * node. cfg->work_units is PER DEVICE. Same call sequence as a context:
+ * create -> [set_importance_map] -> seed -> run -> develop (-> stats). */
+typedef struct drmlt_node drmlt_node;
+drmlt_node *drmlt_node_create(const drmlt_config *cfg, const drmlt_scene *scene,
+                              uint32_t device_mask, char *err, size_t errlen);
+int drmlt_node_seed(drmlt_node *node, uint64_t seed, double *b_out);
+int drmlt_node_run(drmlt_node *node, uint64_t total_mutations, volatile int *stop,
+                   drmlt_progress_cb cb, void *user);
+int drmlt_node_develop(drmlt_node *node, const float *direct_rgb_or_null, float *out_rgb);
+int drmlt_node_stats_get(drmlt_node *node, drmlt_stats *out);
+int drmlt_node_set_importance_map(drmlt_node *node, const float *lum_map_or_null);
+int drmlt_node_device_count(drmlt_node *node);
+drmlt_ctx *drmlt_node_context(drmlt_node *node, int rank); /* borrowed; for film / chain inspection */
+const char *drmlt_node_last_error(drmlt_node *node);
+void drmlt_node_destroy(drmlt_node *node);
 
 const char *drmlt_last_error(drmlt_ctx *ctx);
 uint32_t drmlt_abi_version(void);

@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol(pkg, native_lib):
     assert set(names) == set(pkg.binding.ABI_SYMBOLS)
     for n in names:
         assert hasattr(native_lib, n), n
-    assert native_lib.drmlt_abi_version() == 1
+    assert native_lib.drmlt_abi_version() == 2   # 2: + pool seeding, RCCL exchange, drmlt_node_*
 
 
 def test_struct_layouts_match_the_header(abi):

@@ -1,0 +1,115 @@
+"""Multi-GPU surface behind the C-ABI, exercised on ONE GPU (the box has one): pool seeding, two contexts / two node ranks
+whose chains are exactly those of one big context, and the RCCL film exchange called from C++ (world size 1; the N > 1
+arithmetic of the same code runs through the loopback transport and through the gloo test). The 1 -> 8 GPU curve itself is
+unmeasured on hardware."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+LUMW = np.array([0.212671, 0.715160, 0.072169])
+
+
+def _cfg(pkg, n, **kw):
+    base = dict(type="orbital", max_depth=8, rr_depth=5, direct_samples=-1, work_units=n, sample_count=4,
+                luminance_samples=1000)
+    base.update(kw)
+    return pkg.abi.make_config(**base)
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(type="green"), dict(technique="mmlt", max_depth=6)],
+                         ids=["orbital", "green", "mmlt"])
+def test_two_contexts_equal_one_context_with_twice_the_chains(pkg, kw, native_lib):
+    """Contexts A (chains [0, n)) and B (chains [n, 2n)) seeded from one pool run exactly the chains of one 2n-chain
+    context: their films, summed on the device, develop to the same image (up to the order of the float atomics)."""
+    sd = pkg.scenes.cornell_c2(64)
+    n, total = 2048, 64 * 64 * 4
+    big = pkg.Context(_cfg(pkg, 2 * n, **kw), sd)
+    b_big = big.seed_pool(0x5EED, 0, 2 * n)
+    big.run(total)
+    a, b = pkg.Context(_cfg(pkg, n, **kw), sd), pkg.Context(_cfg(pkg, n, **kw), sd)
+    ba, bb = a.seed_pool(0x5EED, 0, 2 * n), b.seed_pool(0x5EED, n, 2 * n)
+    assert ba == bb == b_big
+    a.run(total // 2); b.run(total // 2)
+    # same chains: same current states, chain by chain
+    dim = 27 if kw.get("technique") == "mmlt" else 34
+    (cb_, ub), (ca, ua), (cbb, ubb) = big.chain_state(dim), a.chain_state(dim), b.chain_state(dim)
+    assert np.array_equal(ub[:n], ua) and np.array_equal(ub[n:], ubb)
+    assert np.array_equal(cb_["luminance"][:n], ca["luminance"]) and np.array_equal(cb_["luminance"][n:], cbb["luminance"])
+    sa, sb, sbig = a.stats(), b.stats(), big.stats()
+    assert sa.accepted + sb.accepted == sbig.accepted and sa.rays + sb.rays == sbig.rays
+    # films summed ON THE DEVICE (torch view of the two film buffers), then developed by context A
+    import torch
+
+    class Dev:
+        def __init__(self, ptr, k):
+            self.__cuda_array_interface__ = {"shape": (k,), "typestr": "<f4", "data": (ptr, False), "version": 2}
+
+    fa = torch.as_tensor(Dev(a.film_device_ptr(), 64 * 64 * 3), device="cuda")
+    fb = torch.as_tensor(Dev(b.film_device_ptr(), 64 * 64 * 3), device="cuda")
+    torch.cuda.synchronize()
+    fa += fb
+    torch.cuda.synchronize()
+    img2, img1 = a.develop(), big.develop()
+    np.testing.assert_allclose(img2, img1, rtol=2e-4, atol=1e-6)
+    assert (img2 @ LUMW).mean() == pytest.approx(b_big, rel=1e-5)
+
+
+def test_node_with_two_ranks_on_one_gpu_equals_single_context(pkg, native_lib, monkeypatch):
+    """drmlt_node_* with two ranks (both on GPU 0: loopback transport for the reduce-scatter arithmetic): seed pool,
+    threaded run, tiled develop, summed stats == one context with twice the chains."""
+    sd = pkg.scenes.cornell_c2(64)
+    n, total = 2048, 64 * 64 * 4
+    monkeypatch.setenv("DRMLT_NODE_DEVICES", "0,0")
+    node = pkg.Node(_cfg(pkg, n), sd, device_mask=1)
+    monkeypatch.delenv("DRMLT_NODE_DEVICES")
+    assert node.device_count == 2
+    big = pkg.Context(_cfg(pkg, 2 * n), sd)
+    bn, bb = node.seed(0x5EED), big.seed_pool(0x5EED, 0, 2 * n)
+    assert bn == bb
+    seen = []
+    node.run(total, progress=lambda d, t: seen.append((d, t)))
+    big.run(total)
+    assert seen and seen[-1] == (total, total)
+    img_n, img_b = node.develop(), big.develop()
+    np.testing.assert_allclose(img_n, img_b, rtol=2e-4, atol=1e-6)
+    np.testing.assert_allclose(node.film(0) + node.film(1), big.film(), rtol=2e-4, atol=1e-6)
+    sn, sb = node.stats(), big.stats()
+    assert sn.mutations == sb.mutations == total and sn.accepted == sb.accepted and sn.rays == sb.rays
+    assert sn.n_chains == 2 * n and sn.first_base == sb.first_base and sn.second_acc == sb.second_acc
+    direct = np.random.default_rng(1).random((64, 64, 3), dtype=np.float32)
+    np.testing.assert_allclose(node.develop(direct), img_n + direct, rtol=1e-5, atol=1e-6)
+    with pytest.raises(pkg.DrmltError, match="empty device mask"):
+        pkg.Node(_cfg(pkg, n), sd, device_mask=0)
+    node.close(); big.close()
+
+
+def test_single_device_node_is_the_plain_context(pkg, native_lib):
+    sd = pkg.scenes.cornell_c2(32)
+    node, ctx = pkg.Node(_cfg(pkg, 1024), sd, device_mask=1), pkg.Context(_cfg(pkg, 1024), sd)
+    assert node.seed(3) == ctx.seed_pool(3, 0, 1024)
+    node.run(32 * 32 * 4); ctx.run(32 * 32 * 4)
+    np.testing.assert_allclose(node.develop(), ctx.develop(), rtol=2e-4, atol=1e-6)
+
+
+def test_rccl_exchange_from_cpp_world_size_one(pkg, native_lib):
+    """ncclCommInitRank / ncclReduceScatter / ncclAllReduce issued by libdrmlt_amd.so itself on the context's stream."""
+    sd = pkg.scenes.cornell_c2(50)          # 50 rows: not a multiple of anything convenient
+    ctx = pkg.Context(_cfg(pkg, 2048), sd)
+    b = ctx.seed(11)
+    ctx.run(50 * 50 * 4)
+    uid = pkg.comm_unique_id()
+    assert len(uid) == 128 and any(uid)
+    with pytest.raises(pkg.DrmltError, match="drmlt_comm_init"):
+        ctx.exchange_tiled(b)
+    ctx.comm_init(uid, 0, 1)
+    film_before = ctx.film()
+    tile, rows, b_mean = ctx.exchange_tiled(b)
+    assert rows == (0, 50) and b_mean == b
+    np.testing.assert_allclose(tile, ctx.develop(), rtol=2e-5, atol=1e-7)
+    np.testing.assert_array_equal(ctx.film(), film_before)          # the local film keeps accumulating untouched
+    _, rows2, _ = ctx.exchange_tiled(b, want_tile=False)             # the timed form: no host copy
+    assert rows2 == (0, 50)
+    with pytest.raises(pkg.DrmltError, match="bad rank"):
+        ctx.comm_init(uid, 2, 2)
