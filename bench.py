@@ -1,19 +1,21 @@
 #!/usr/bin/env python3
 """Benchmark of the DRMLT hot path on MI355X.
 
-Workload = BASELINE.json configs[1]: Cornell box 512x512, `integrator=drmlt technique=path type=orbital`,
+Default workload = BASELINE.json configs[1]: Cornell box 512x512, `integrator=drmlt technique=path type=orbital`,
 65 536 chains per GPU, sampleCount 256 => one step = one full mutation phase of that render
 (512*512*256 = 67 108 864 chain-loop iterations, 1 024 per chain), scene and chain state resident in HBM
 before the timed region. Metric = mutations/s (accepted + rejected; one mutation = one first-stage proposal,
 reference drmlt_proc.cpp:541).
 
   python bench.py --gpus 1 --steps 5 --warmup 1
+  python bench.py --config 3|5|bdpt|soup          # the other kernels, same JSON line (roofline of THAT kernel)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
       bench.py --gpus N --steps K --warmup W
 
-N > 1: one process per GPU, chains partitioned by chain id (no data-path collective); each step ends with the
-film exchange of the render it represents: one RCCL all-reduce (sum) of the W*H*3 fp32 film plus one scalar
-all-reduce of b (reference: DRMLTProcess::processResult / develop, drmlt_proc.cpp:813-867).
+N > 1: one process per GPU, chains partitioned by chain id out of ONE seed pool (no data-path collective); each step ends
+with the film exchange of the render it represents, issued from C++ inside libdrmlt_amd.so (drmlt_exchange_tiled):
+ncclReduceScatter(sum) of the W*H*3 fp32 film -- rank r keeps rows [r H/N, (r+1) H/N) -- plus one two-element
+ncclAllReduce, then every rank develops its tile (reference: DRMLTProcess::processResult / develop, drmlt_proc.cpp:813-867).
 """
 import argparse
 import json
@@ -29,13 +31,30 @@ import __graft_entry__ as entry  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X spec, /opt/skills/guides/MI355X_MICROARCH.md
 
-
-class _DevArray:
-    """Expose a raw device pointer to torch through __cuda_array_interface__ (zero copy)."""
-
-    def __init__(self, ptr, shape):
-        self.__cuda_array_interface__ = {"shape": shape, "typestr": "<f4", "data": (ptr, False), "version": 2,
-                                         "strides": None}
+# name -> (scene builder args, config kwargs, chains, sampleCount per step, kernel, description)
+CONFIGS = {
+    "2": dict(scene=("cornell_c2", {}), res=512, cfg=dict(technique="path", type="orbital", max_depth=8, rr_depth=5),
+              spp=256, kernel="k_mutate_v4", pmc="r02_c2_pmc.json",
+              what="Cornell box %(res)dx%(res)d, integrator=drmlt technique=path type=orbital, %(chains)d chains/GPU, "
+                   "sampleCount %(spp)d (BASELINE.json configs[1])"),
+    "3": dict(scene=("door_c3", {}), res=512, cfg=dict(technique="path", type="green", max_depth=8, rr_depth=5),
+              spp=64, kernel="k_mutate_v4", pmc="r02_c3_pmc.json",
+              what="door scene (occluded area light, rough-conductor floor) %(res)dx%(res)d, drmlt technique=path type=green, "
+                   "%(chains)d chains/GPU, sampleCount %(spp)d (BASELINE.json configs[2])"),
+    "5": dict(scene=("caustic_c5", {}), res=512,
+              cfg=dict(technique="mmlt", type="orbital", max_depth=6, fix_emitter_path=1, acceptance_map=1), spp=64,
+              kernel="k_mutate_mmlt", pmc="r02_c5_pmc.json",
+              what="glass caustic (dielectric sphere, small sphere light) %(res)dx%(res)d, drmlt technique=mmlt type=orbital "
+                   "fixEmitterPath acceptanceMap, %(chains)d chains/GPU, sampleCount %(spp)d (BASELINE.json configs[4])"),
+    "bdpt": dict(scene=("cornell_c2", {}), res=256, cfg=dict(technique="bdpt", type="orbital", max_depth=8, rr_depth=5, no_direct_sampling=1),
+                 spp=64, kernel="k_mutate_bdpt", pmc="r02_bdpt_pmc.json",
+                 what="Cornell box %(res)dx%(res)d, drmlt technique=bdpt type=orbital, %(chains)d chains/GPU, sampleCount %(spp)d"),
+    "soup": dict(scene=("triangle_soup", dict(n_tris=2000)), res=256,
+                 cfg=dict(technique="path", type="orbital", max_depth=8, rr_depth=5), spp=64, kernel="k_mutate_v4",
+                 pmc="r02_soup_pmc.json",
+                 what="closed room with 2000 random triangles (BVH in HBM) %(res)dx%(res)d, drmlt technique=path type=orbital, "
+                      "%(chains)d chains/GPU, sampleCount %(spp)d"),
+}
 
 
 def host_threads():
@@ -58,6 +77,16 @@ def host_threads():
     return min(n, 64)
 
 
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return "unknown"
+
+
 def _clean(o):
     """Strict JSON: NaN / inf become null."""
     if isinstance(o, float):
@@ -73,19 +102,24 @@ def lum(img):
     return img @ np.array([0.212671, 0.715160, 0.072169])
 
 
-def cpu_baseline(pkg, cfg_kw, res, target_seconds):
-    """Time the CPU restatement (oracle/, -O3 -march=native) on all host cores on a bounded sample of the same
-    workload: same scene/config, fewer chains x fewer mutations."""
+def build_scene(pkg, conf, res):
+    name, kw = conf["scene"]
+    return pkg.scenes.SCENES[name](res=res, **kw)
+
+
+def cpu_baseline(pkg, conf, res, cfg_kw, target_seconds):
+    """Time the CPU restatement (oracle/, -O3 -march=native, fp64 like the reference's CMake build) on all host cores on a
+    bounded sample of the same workload: same scene/config, fewer chains x fewer mutations."""
     ob = entry.load_oracle()
     ob.build(native=True)
     abi = pkg.abi
     cores = host_threads()
-    sd = pkg.scenes.cornell_c2(res)
+    sd = build_scene(pkg, conf, res)
     chains = 64 * cores
     cfg = abi.make_config(work_units=chains, luminance_samples=20000, **cfg_kw)
     orc = ob.Oracle(abi, cfg, sd, precision=64, native=True)
     orc.seed(0x5EED)
-    probe = chains * 2048
+    probe = chains * 256
     t = time.time()
     orc.run(probe, cores)
     rate = probe / max(time.time() - t, 1e-6)
@@ -95,9 +129,9 @@ def cpu_baseline(pkg, cfg_kw, res, target_seconds):
     orc.run(total, cores)
     dt = time.time() - t
     orc.close()
-    return {"value": total / dt, "unit": "mutations/s", "cores": cores, "kind": "port",
-            "sample": "oracle (fp64 CPU restatement) on %d threads: Cornell 512x512 orbital, %d chains x %d "
-                      "mutations = %d mutations in %.1f s" % (cores, chains, per_chain, total, dt),
+    return {"value": total / dt, "unit": "mutations/s", "cores": cores, "kind": "port", "cpu": cpu_model(),
+            "sample": "oracle (fp64 CPU restatement, one chain per work unit on a thread pool) on %d threads: same scene and "
+                      "config, %d chains x %d mutations = %d mutations in %.1f s" % (cores, chains, per_chain, total, dt),
             "per_core": total / dt / cores}
 
 
@@ -106,14 +140,18 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--res", type=int, default=512)
+    ap.add_argument("--config", default="2", choices=sorted(CONFIGS))
+    ap.add_argument("--res", type=int, default=0, help="film size (default: the configuration's)")
     ap.add_argument("--chains", type=int, default=65536)
-    ap.add_argument("--spp", type=int, default=256, help="mutations per pixel per step (sampleCount)")
-    ap.add_argument("--type", default="orbital")
+    ap.add_argument("--spp", type=int, default=0, help="mutations per pixel per step (sampleCount)")
+    ap.add_argument("--type", default="")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-quality", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args()
+    conf = CONFIGS[args.config]
+    res = args.res or conf["res"]
+    spp = args.spp or conf["spp"]
 
     # Libraries loaded below write to the process's stdout on their own (RCCL prints a version banner when its first
     # communicator comes up): keep file descriptor 1 pointed at stderr until the one JSON line is ready.
@@ -132,7 +170,7 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the DRMLT path has no CPU fallback")
     torch.cuda.set_device(local_rank)
-    # BENCH_FORCE_DIST=1 rehearses the RCCL path (process group, zero-copy film tensor, exchange) on one GPU
+    # BENCH_FORCE_DIST=1 rehearses the multi-GPU path (process group, RCCL communicator, tiled exchange) on one GPU
     use_dist = world > 1 or os.environ.get("BENCH_FORCE_DIST") == "1"
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -141,18 +179,25 @@ def main():
 
     pkg = entry.load_package()
     abi = pkg.abi
-    cfg_kw = dict(type=args.type, max_depth=8, rr_depth=5, direct_samples=-1, sample_count=args.spp)
-    sd = pkg.scenes.cornell_c2(args.res)
-    cfg = abi.make_config(work_units=args.chains, luminance_samples=10 * args.chains, **cfg_kw)
+    cfg_kw = dict(direct_samples=-1, sample_count=spp, **conf["cfg"])
+    if args.type:
+        cfg_kw["type"] = args.type
+    sd = build_scene(pkg, conf, res)
+    # luminanceSamples: the reference's floor max(100000, 10 workUnits) (50 x for mmlt), applied inside drmlt_seed
+    cfg = abi.make_config(work_units=args.chains, luminance_samples=100000, **cfg_kw)
     ctx = pkg.Context(cfg, sd, device=local_rank)
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
 
-    npix = args.res * args.res
-    film = torch.as_tensor(_DevArray(ctx.film_device_ptr(), (npix * 3,)), device="cuda")
-    b_local = ctx.seed(0x5EED, chain_offset=rank * args.chains)   # bootstrap + seed replay: outside the timed region
-    b_t = torch.tensor([b_local], dtype=torch.float64, device="cuda")
-    film_sum, b_sum = torch.empty_like(film), torch.empty_like(b_t)
-    step_mutations = npix * args.spp                                # per GPU
+    npix = res * res
+    # bootstrap + seed replay: outside the timed region. One seed pool for the job: every rank finds the same b
+    b = ctx.seed_pool(0x5EED, rank * args.chains, world * args.chains)
+    if use_dist:  # the library's own RCCL communicator: rank 0 creates the id, the process group only carries its 128 bytes
+        uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
+        if rank == 0:
+            uid.copy_(torch.frombuffer(bytearray(pkg.comm_unique_id()), dtype=torch.uint8))
+        dist.broadcast(uid, 0)
+        ctx.comm_init(bytes(uid.cpu().numpy().tobytes()), rank, world)
+    step_mutations = npix * spp                                # per GPU
 
     def barrier():
         if use_dist:
@@ -161,8 +206,8 @@ def main():
 
     def step():
         ctx.run(step_mutations)
-        if use_dist:  # the render's film exchange: sum of the per-GPU films, mean of the per-GPU b estimates
-            pkg.exchange.exchange_film(film, b_t, dist, out=film_sum, b_out=b_sum)
+        if use_dist:  # the render's film exchange: reduce-scatter + scalar all-reduce + tile develop, all in C++
+            ctx.exchange_tiled(b, want_tile=False)
 
     for _ in range(args.warmup):
         step()
@@ -190,73 +235,84 @@ def main():
 
     out = None
     if rank == 0:
-        # ---- roofline of the dominant kernel (k_mutate): algorithmic bytes per SURVEY 8(d) / DESIGN.md
+        # ---- roofline of the dominant kernel: algorithmic bytes per SURVEY 8(d) / DESIGN.md section 3
         D = st1.max_dim
         p_acc = accepted / muts
         n_splats = 2.0 + (st1.second_base - st0.second_base) / muts
         bytes_per_mut = (4 * D + 32) * (1.0 + p_acc) + 24.0 * n_splats
         muts_per_launch = muts / max(launches, 1)
         achieved = bytes_per_mut * muts_per_launch / (launch_ms * 1e-3) / 1e9 if launch_ms > 0 else 0.0
-        traffic = None
-        valu_frac = None
-        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        traffic = valu_frac = lane_util = None
+        traffic_source = None
+        pmc = os.path.join(ROOT, "profiles", conf["pmc"])
         if os.path.exists(pmc):
             try:
-                # PMC passes were taken on 1.68e7-mutation launches; traffic is proportional to the mutation count
+                # NOT measured in this run: counters cannot be read from inside the process. The committed summary holds
+                # rocprofv3 --pmc passes (one per counter group, gfx950 corrections applied) of this same command with a
+                # shorter launch; HBM traffic and instruction counts are proportional to the mutation count.
                 pj = json.load(open(pmc))
                 traffic = pj.get("hbm_bytes_per_mutation") * muts_per_launch
-                # wave-level VALU instructions per mutation (SQ_INSTS_VALU) against 1024 SIMDs issuing one per 4 cycles
-                valu_frac = pj["instructions_per_mutation"]["valu"] * muts_per_launch / (launch_ms * 1e-3) / (1024 * 2.4e9 / 4)
+                traffic_source = "scaled per mutation from profiles/%s (rocprofv3 --pmc, separate passes), not read in this run" % conf["pmc"]
+                # wave-level VALU instructions per mutation (SQ_INSTS_VALU) against 1024 SIMDs x one wave64 VALU op per 2 cycles
+                valu_frac = pj["instructions_per_mutation"]["valu"] * muts_per_launch / (launch_ms * 1e-3) / (1024 * 2.4e9 / 2)
+                lane_util = pj.get("valu_lane_utilisation")
             except Exception:
                 traffic = None
-        # SURVEY 8(d) asks for three separately labelled byte figures: (i) measured HBM traffic, (ii) algorithmic bytes
-        # (= roofline.achieved), (iii) bytes REQUESTED per lane including what the scalar cache / LDS serves (every ray
-        # tests every 64-byte primitive record of this BVH-less scene) -- (iii) is never used as the roofline figure
-        n_records = len(sd.shapes)   # rectangles stay one record each (quad test); no triangle meshes in this scene
-        requested = (rays / muts) * n_records * 64.0 + bytes_per_mut
         out = {
             "metric": "mutations/sec (accepted+rejected)", "value": value, "unit": "mutations/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "Cornell box %dx%d, integrator=drmlt technique=path type=%s, %d chains/GPU, "
-                                   "sampleCount %d (BASELINE.json configs[1])" % (args.res, args.res, args.type,
-                                                                                    args.chains, args.spp),
-                       "max_depth": 8, "rr_depth": 5, "p_large": 0.3, "filter": "box",
-                       "mutations_per_step_per_gpu": step_mutations, "parallelism": "chains partitioned x%d" % world},
+            "config": {"workload": conf["what"] % dict(res=res, chains=args.chains, spp=spp), "name": args.config,
+                       "max_depth": cfg_kw["max_depth"], "rr_depth": cfg_kw.get("rr_depth", 5), "p_large": 0.3, "filter": "box",
+                       "mutations_per_step_per_gpu": step_mutations,
+                       "parallelism": "chains partitioned x%d, one seed pool; film reduce-scatter + scalar all-reduce (RCCL from C++)" % world
+                       if use_dist else "1 GPU"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "k_mutate_v3", "avg_launch_ms": launch_ms, "launches": launches,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
+                         "kernel": conf["kernel"], "avg_launch_ms": launch_ms, "launches": launches,
                          "algorithmic_bytes_per_mutation": bytes_per_mut,
                          "mutations_per_launch": muts_per_launch,
                          "hbm_measured_gbs": (traffic / (launch_ms * 1e-3) / 1e9) if traffic and launch_ms > 0 else None,
-                         "requested_gbs_incl_cache_served": requested * muts_per_launch / (launch_ms * 1e-3) / 1e9
-                         if launch_ms > 0 else None,
-                         "valu_issue_frac_at_2.4GHz": valu_frac},
+                         "hbm_measured_frac": (traffic / (launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic and launch_ms > 0 else None,
+                         "valu_issue_frac_of_peak": valu_frac, "valu_lane_utilisation": lane_util,
+                         "note": "north_star's '>= 30 % of the HBM-read roofline' is not met and cannot be on this scene class: "
+                                 "scene (scalar cache / LDS) and chain state (LDS) are on chip, compulsory HBM traffic is the film "
+                                 "atomics (SURVEY 8d); the kernel is bound by VALU issue x lane utilisation"
+                         if args.config != "soup" else
+                         "BVH and primitive records live in HBM/L2 here: hbm_measured_frac is the meaningful figure"},
             "accepted_mutations_per_s": world * accepted / elapsed,
             "path_evals_per_s": world * evals / elapsed, "rays_per_s": world * rays / elapsed,
-            "acceptance": {k: round(v, 5) for k, v in st1.ratios().items()},
+            "acceptance": {k: (round(v, 5) if v is not None else None) for k, v in st1.ratios().items()},
         }
+        proto = os.path.join(ROOT, "profiles", "r02_parity_protocol.json")
+        if os.path.exists(proto):
+            try:
+                out["parity_protocol"] = json.load(open(proto)).get("summary")
+            except Exception:
+                pass
 
     # ---- image quality at the accumulated budget (outside the timed region)
-    if not args.no_quality:
-        b_mean = b_local
-        if use_dist:  # the local films hold `steps` renders each: combine them once and develop the sum
-            pkg.exchange.exchange_film(film, b_t, dist, out=film_sum, b_out=b_sum)
-            film.copy_(film_sum)
-            torch.cuda.synchronize()
-            b_mean = float(b_sum.item())
-        ctx.set_luminance(b_mean)
-        img = ctx.develop()
+    if not args.no_quality and not cfg_kw.get("acceptance_map"):
+        if use_dist:  # every rank develops its tile of the summed film; rank 0 collects them
+            tile, rows, b_mean = ctx.exchange_tiled(b)
+            parts = [None] * world
+            dist.all_gather_object(parts, (rows, tile))
+            img = np.zeros((res, res, 3), dtype=np.float32)
+            for (lo, hi), t in parts:
+                img[lo:hi] = t
+        else:
+            img, b_mean = ctx.develop(), b
         if rank == 0:
             ref = ctx.render_pt(2048, seed=4242)
             li, lr = lum(img), lum(ref)
             rmse = float(np.mean((li - lr) ** 2 / (lr ** 2 + 1e-2 * lr.mean() ** 2)))
-            out["quality"] = {"rel_mse_vs_pt_2048spp": rmse, "mutations_per_pixel": args.spp * args.steps * world,
-                              "b": b_mean, "mean_luminance": float(li.mean())}
+            out["quality"] = {"rel_mse_vs_pt_2048spp": rmse, "reference": "independent path tracing of the same integrand ON THE "
+                              "DEVICE, 2048 spp (its own noise is in the figure); device vs CPU-oracle protocol: parity_protocol",
+                              "mutations_per_pixel": spp * args.steps * world, "b": b_mean, "mean_luminance": float(li.mean())}
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(pkg, cfg_kw, args.res, args.cpu_seconds)
+        out["cpu_baseline"] = cpu_baseline(pkg, conf, res, cfg_kw, args.cpu_seconds)
     elif rank == 0:
         out["cpu_baseline"] = None
     if rank == 0:

@@ -9,6 +9,7 @@ BSDF_DIFFUSE, BSDF_DIELECTRIC, BSDF_ROUGHCONDUCTOR, BSDF_CONDUCTOR = 0, 1, 2, 3
 EMITTER_AREA = 0
 FILTER_BOX, FILTER_GAUSSIAN = 0, 1
 
+ABI_VERSION = 2  # include/drmlt_abi.h: DRMLT_ABI_VERSION
 OK, E_INVALID, E_DEVICE, E_STATE, E_ZERO_LUM, E_REPLAY, E_CANCELLED = 0, -1, -2, -3, -4, -5, -6
 
 TYPE_NAMES = {"green": TYPE_GREEN, "mira": TYPE_MIRA, "orbital": TYPE_ORBITAL, "mirasym": TYPE_ORBITAL}
@@ -62,7 +63,7 @@ class Stats(C.Structure):
         "second_bold_acc", "second_bold_base", "overall_acc", "overall_base",
         "mutations", "path_evals", "rays", "accepted")] + [
         ("kernel_ms", C.c_double), ("seed_ms", C.c_double), ("n_chains", C.c_uint32), ("max_dim", C.c_uint32),
-        ("launches", C.c_uint64)]
+        ("launches", C.c_uint64), ("bvh_node_visits", C.c_uint64), ("bvh_prim_tests", C.c_uint64)]
 
     RATIOS = ("first", "large", "bold", "second", "second_large", "second_bold", "overall")
 

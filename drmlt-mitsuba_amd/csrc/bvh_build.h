@@ -1,4 +1,4 @@
-// Host-side builder of the 2-wide BVH the kernels traverse (binned SAH, one primitive per leaf by default).
+// Host-side builder of the BVH the kernels traverse: a binary tree by binned SAH, collapsed into 4-wide nodes.
 // The reference uses a SAH kd-tree (src/librender/skdtree.cpp, sahkdtree3.h); a closest-hit
 // query returns the same primitive through either structure, so the builder is free to pick
 // the layout that suits the GPU: one 64 B node = both child boxes, fetched as one line.
@@ -31,7 +31,7 @@ struct Box {
     }
 };
 
-constexpr int kLeafMax = 1; // measured on the 2000-triangle soup: 1 -> 2.08e8, 2 or 3 -> 1.84e8, 4 -> 1.80e8 mutations/s (no leaf loop to diverge in)
+constexpr int kLeafMax = 1; // primitives per leaf (DRMLT_BVH_LEAF: 1..4). Measured on the 2000-triangle soup: 1 -> 1.12e8, 2 -> 0.97e8 mutations/s (no leaf loop to diverge in)
 constexpr int kLeafCap = 4; // DRMLT_BVH_LEAF may raise it to this (the leaf reference keeps 3 bits for the count)
 constexpr int kBins = 16;
 
@@ -161,4 +161,91 @@ inline int build_bvh(const std::vector<PrimBounds> &pb, std::vector<DBvhNode> &n
     }
     b.build(0, n);
     return b.median_splits; // nodes where the depth bound overrode the SAH split
+}
+
+
+// ---- 4-wide tree: every node takes the two children of a binary node and keeps replacing one inner child by its two
+// children until it has four (or only leaves are left). `by_height`: expand the child with the tallest subtree first
+// (then every root-to-leaf path loses at least two binary levels per 4-wide node: depth4 <= ceil(depth2 / 2));
+// otherwise the child with the largest box (better culling). Returns the 4-wide depth (inner nodes on the longest path).
+namespace bvh_detail {
+struct Ref4 {
+    int c, n; // c >= 0: binary inner node; c < 0: leaf ~first with n primitives
+    float lo[3], hi[3];
+    float area() const {
+        float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+        return 2.f * (dx * dy + dy * dz + dz * dx);
+    }
+};
+inline void child_refs(const DBvhNode &N, Ref4 &a, Ref4 &b) {
+    a.c = N.c0; a.n = N.n0; b.c = N.c1; b.n = N.n1;
+    for (int k = 0; k < 3; ++k) { a.lo[k] = N.lo0[k]; a.hi[k] = N.hi0[k]; b.lo[k] = N.lo1[k]; b.hi[k] = N.hi1[k]; }
+}
+inline int height2(const std::vector<DBvhNode> &bin, int node, std::vector<int> &memo) {
+    if (node < 0) return 0;
+    if (memo[node]) return memo[node];
+    return memo[node] = 1 + std::max(height2(bin, bin[node].c0, memo), height2(bin, bin[node].c1, memo));
+}
+inline int collapse4(const std::vector<DBvhNode> &bin, int node, std::vector<DBvh4Node> &out, bool by_height, std::vector<int> &memo, int leaf_shift) {
+    std::vector<Ref4> refs(2);
+    child_refs(bin[node], refs[0], refs[1]);
+    while (refs.size() < 4) {
+        int best = -1;
+        float key = -1.f;
+        for (size_t i = 0; i < refs.size(); ++i) {
+            if (refs[i].c < 0) continue;
+            const float k = by_height ? (float) height2(bin, refs[i].c, memo) + 1e-3f * std::min(refs[i].area(), 100.f) : refs[i].area();
+            if (k > key) { key = k; best = (int) i; }
+        }
+        if (best < 0) break;
+        Ref4 a, b;
+        child_refs(bin[refs[best].c], a, b);
+        refs[best] = a;
+        refs.push_back(b);
+    }
+    const int self = (int) out.size();
+    out.emplace_back();
+    DBvh4Node N4{};
+    int depth = 1;
+    for (int i = 0; i < 4; ++i) {
+        const bool used = i < (int) refs.size() && !(refs[i].c < 0 && refs[i].n == 0);
+        N4.pad[i] = 0;
+        if (!used) {
+            // a point at +FLT_MAX on every axis: on an axis the ray moves along, both slab distances are the same infinity, so
+            // near > far whatever the direction. (An INVERTED box does not do it: the slab test takes min / max of the two plane
+            // distances and would see the whole line.)
+            N4.lox[i] = N4.loy[i] = N4.loz[i] = FLT_MAX; N4.hix[i] = N4.hiy[i] = N4.hiz[i] = FLT_MAX;
+            N4.child[i] = ~0; // never read: no ray enters the box
+            continue;
+        }
+        const Ref4 &r = refs[i];
+        N4.lox[i] = r.lo[0]; N4.hix[i] = r.hi[0]; N4.loy[i] = r.lo[1]; N4.hiy[i] = r.hi[1]; N4.loz[i] = r.lo[2]; N4.hiz[i] = r.hi[2];
+        if (r.c >= 0) {
+            N4.child[i] = (int) out.size(); // the node the recursive call is about to append
+            depth = std::max(depth, 1 + collapse4(bin, r.c, out, by_height, memo, leaf_shift));
+        } else {
+            N4.child[i] = leaf_shift ? ~(((~r.c) << leaf_shift) | r.n) : ~(~r.c);
+        }
+    }
+    out[self] = N4;
+    return depth;
+}
+} // namespace bvh_detail
+
+// nodes4[0] is the root. The traversal pushes at most 3 entries per inner node on the current path, so the tree is usable
+// iff 3 * depth4 <= BVH_STACK; the caller checks the returned depth.
+// `leaf_shift` (out): 0 when every leaf holds one primitive, else 3 (see DBvh4Node).
+inline int build_bvh4(const std::vector<DBvhNode> &bin, std::vector<DBvh4Node> &nodes4, int *leaf_shift_out = nullptr) {
+    std::vector<int> memo(bin.size(), 0);
+    nodes4.clear();
+    bool single = true;
+    for (const DBvhNode &N : bin) single = single && (N.c0 >= 0 || N.n0 <= 1) && (N.c1 >= 0 || N.n1 <= 1);
+    const int leaf_shift = single ? 0 : 3;
+    if (leaf_shift_out) *leaf_shift_out = leaf_shift;
+    int depth = bvh_detail::collapse4(bin, 0, nodes4, false, memo, leaf_shift);
+    if (3 * depth > BVH_STACK) { // rare: a path the area-driven collapse left uncollapsed; collapse by subtree height instead
+        nodes4.clear();
+        depth = bvh_detail::collapse4(bin, 0, nodes4, true, memo, leaf_shift);
+    }
+    return depth;
 }

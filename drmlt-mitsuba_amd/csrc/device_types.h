@@ -62,7 +62,17 @@ struct DEmitter {
     float pad[2];
 };
 
-#define BVH_STACK 24 // per-lane traversal stack entries (LDS) = bound on the BVH depth (bvh_build.h)
+#define BVH_STACK 24 // per-lane traversal stack entries (LDS): a 4-wide node pushes at most 3, so the 4-wide depth is bounded by 8 (bvh_build.h)
+// 4-wide node, 128 B = one cache line: the four child boxes component by component (each row one 16 B load), then the
+// children. child >= 0: inner node index; child < 0: leaf, ~child = (first primitive slot << shift) | count, with
+// shift = DParams::bvh_leaf_shift (0 when every leaf holds exactly one primitive: then ~child is the slot itself);
+// empty slot: a point box at +FLT_MAX (no ray enters it).
+struct DBvh4Node {
+    float lox[4], hix[4], loy[4], hiy[4], loz[4], hiz[4];
+    int32_t child[4];
+    int32_t pad[4];
+};
+// binary SAH tree the 4-wide one is collapsed from (host only)
 struct DBvhNode {      // 64 B
     float lo0[3], hi0[3]; // child 0 box
     float lo1[3], hi1[3]; // child 1 box
@@ -76,7 +86,7 @@ struct DParams {
     const DShade *shade;
     const DBsdf *bsdfs;
     const DEmitter *emitters;
-    const DBvhNode *bvh;
+    const DBvh4Node *bvh; // 4-wide BVH (scenes above the brute-force threshold)
     const float *filter_lut; // 32 entries (MTS_FILTER_RESOLUTION + 1)
     int32_t n_prims, n_emitters, n_bvh_nodes, use_bvh, n_bsdfs, tables_in_lds;
     int32_t n_shade; // shading records (>= n_prims: a merged pair has two)
@@ -122,6 +132,9 @@ struct DParams {
     int32_t kelemen_weights, kelemen_mutation; // "kelemenStyleWeights" (pssmlt_proc.cpp:197-203), Kelemen (1) or Gaussian (0) mutation
     float pss_sigma, luminance_b;              // Gaussian mutation size; b of the Kelemen weights
     int32_t n_flat;              // records [0, n_flat) of `prims` are flat (and mirrored in prims_flat), [n_flat, n_prims) are spheres
+    int32_t bvh_leaf_shift;      // 0: one primitive per leaf, ~child = slot; 3: ~child = slot << 3 | count
+    int32_t bvh_stack16;         // every stack entry fits a short: k_mutate_v4 runs its 16-bit-stack variant
+    int32_t trace_yield;         // k_mutate_v4 on BVH scenes: a traversal slice ends once this many lanes have finished their ray
 };
 
 // result of one PSS evaluation, SoA-friendly

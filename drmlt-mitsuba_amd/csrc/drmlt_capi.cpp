@@ -341,26 +341,25 @@ drmlt_ctx *drmlt_create(const drmlt_config *cfg, const drmlt_scene *scene, int d
     DParams &P = ctx->P;
     int bvh_threshold = 48;
     if (const char *t = getenv("DRMLT_BVH_THRESHOLD")) bvh_threshold = atoi(t);
-    std::vector<DBvhNode> nodes;
+    std::vector<DBvhNode> nodes;   // binary SAH tree (host only)
+    std::vector<DBvh4Node> nodes4; // what the kernels traverse
     P.use_bvh = (int) ctx->prims.size() > bvh_threshold ? 1 : 0;
     if (P.use_bvh) {
         std::vector<int> order;
-        int max_depth = BVH_STACK;
-        if (const char *t = getenv("DRMLT_BVH_MAX_DEPTH")) max_depth = atoi(t); // tests: exercise the depth-bounded splits
+        // binary depth <= 16: collapsing by subtree height then gives a 4-wide depth <= 8 = BVH_STACK / 3 whatever the
+        // primitive distribution (bvh_build.h); the area-driven collapse is tried first
+        int max_depth = 2 * (BVH_STACK / 3);
+        if (const char *t = getenv("DRMLT_BVH_MAX_DEPTH")) max_depth = std::min(max_depth, atoi(t)); // tests: exercise the depth-bounded splits
         const int median_splits = build_bvh(bounds, nodes, order, max_depth);
-        // the kernels' per-lane stack holds BVH_STACK entries and does not check for overflow: verify the builder's bound
-        std::vector<std::pair<int, int>> todo{{0, 1}};
-        int depth = 0;
-        while (!todo.empty()) {
-            const auto [node, d] = todo.back();
-            todo.pop_back();
-            depth = std::max(depth, d);
-            if (nodes[node].c0 >= 0) todo.push_back({nodes[node].c0, d + 1});
-            if (nodes[node].c1 >= 0) todo.push_back({nodes[node].c1, d + 1});
-        }
-        if (depth > BVH_STACK) return bail(ctx, "internal error: BVH deeper than the traversal stack");
-        ctx->bvh_depth = depth;
-        if (getenv("DRMLT_VERBOSE")) fprintf(stderr, "[drmlt] BVH: %zu primitives, %zu nodes, depth %d (stack %d), %d median splits\n", order.size(), nodes.size(), depth, BVH_STACK, median_splits);
+        int leaf_shift = 0;
+        const int depth4 = build_bvh4(nodes, nodes4, &leaf_shift);
+        P.bvh_leaf_shift = leaf_shift;
+        // 16-bit stack entries when every node index and leaf reference fits (k_mutate_v4: 3 KB of LDS instead of 6)
+        P.bvh_stack16 = (nodes4.size() < 32768 && ((order.size() << leaf_shift) | 7u) < 32768 && !getenv("DRMLT_BVH_STACK32")) ? 1 : 0;
+        // the kernels' per-lane stack holds BVH_STACK entries and does not check for overflow: a 4-wide node pushes at most 3
+        if (3 * depth4 > BVH_STACK) return bail(ctx, "internal error: BVH deeper than the traversal stack");
+        ctx->bvh_depth = depth4;
+        if (getenv("DRMLT_VERBOSE")) fprintf(stderr, "[drmlt] BVH: %zu primitives, %zu binary / %zu 4-wide nodes, 4-wide depth %d (stack %d), %d median splits, %d-bit stack entries\n", order.size(), nodes.size(), nodes4.size(), depth4, BVH_STACK, median_splits, P.bvh_stack16 ? 16 : 32);
         // intersection records go into leaf order; shading records stay where the emitters expect them
         std::vector<DPrim> np(order.size());
         for (size_t i = 0; i < order.size(); ++i) np[i] = ctx->prims[order[i]];
@@ -381,7 +380,7 @@ drmlt_ctx *drmlt_create(const drmlt_config *cfg, const drmlt_scene *scene, int d
               up(ctx->d_bsdfs, bsdfs.data(), bsdfs.size() * sizeof(DBsdf)) &&
               up(ctx->d_emitters, emitters.data(), emitters.size() * sizeof(DEmitter)) &&
               up(ctx->d_lut, lut, sizeof lut);
-    if (ok && P.use_bvh) ok = up(ctx->d_bvh, nodes.data(), nodes.size() * sizeof(DBvhNode));
+    if (ok && P.use_bvh) ok = up(ctx->d_bvh, nodes4.data(), nodes4.size() * sizeof(DBvh4Node));
     // flat-primitive fast path of the brute-force loop: interleaved records + two sentinels no ray can hit
     // (ld.z = 0, lo.z = 1: t = -inf fails t >= tmin)
     P.prims_flat = nullptr; P.has_plain_tri = 0; P.n_flat = 0;
@@ -410,8 +409,8 @@ drmlt_ctx *drmlt_create(const drmlt_config *cfg, const drmlt_scene *scene, int d
     ctx->n_chains = (uint32_t) work_units;
 
     P.prims = ctx->d_prims.as<DPrim>(); P.shade = ctx->d_shade.as<DShade>(); P.bsdfs = ctx->d_bsdfs.as<DBsdf>();
-    P.emitters = ctx->d_emitters.as<DEmitter>(); P.bvh = ctx->d_bvh.as<DBvhNode>(); P.filter_lut = ctx->d_lut.as<float>();
-    P.n_prims = (int) ctx->prims.size(); P.n_shade = (int) ctx->shade.size(); P.n_emitters = (int) emitters.size(); P.n_bvh_nodes = (int) nodes.size();
+    P.emitters = ctx->d_emitters.as<DEmitter>(); P.bvh = ctx->d_bvh.as<DBvh4Node>(); P.filter_lut = ctx->d_lut.as<float>();
+    P.n_prims = (int) ctx->prims.size(); P.n_shade = (int) ctx->shade.size(); P.n_emitters = (int) emitters.size(); P.n_bvh_nodes = (int) nodes4.size();
     P.n_bsdfs = (int) bsdfs.size();
     // tables ride in LDS when they are small (Cornell class); 16 KB cap keeps 4+ waves per CU
     P.tables_in_lds = (ctx->shade.size() * 64 + bsdfs.size() * 48 + emitters.size() * 32 <= 16384) ? 1 : 0;
@@ -486,8 +485,10 @@ drmlt_ctx *drmlt_create(const drmlt_config *cfg, const drmlt_scene *scene, int d
     for (const DPrim &g : ctx->prims) if (g.type == PRIM_SPHERE) P.features |= 4;
     if (P.use_bvh) P.features |= 8;
     if (getenv("DRMLT_FEAT_ALL")) P.features = 15;
-    P.mh_batch = P.kernel_variant == 4 ? 8 : 32; // v4: chains run free, the bookkeeping branch fires as soon as a few are parked
+    P.mh_batch = P.kernel_variant == 4 ? (P.use_bvh ? 4 : 8) : 32; // v4: chains run free, the bookkeeping branch fires as soon as a few are parked
     if (const char *k = getenv("DRMLT_MH_BATCH")) P.mh_batch = std::max(1, std::min(64, atoi(k)));
+    P.trace_yield = 16;
+    if (const char *k = getenv("DRMLT_TRACE_YIELD")) P.trace_yield = std::max(0, std::min(64, atoi(k)));
     if (hipDeviceSynchronize() != hipSuccess) return bail(ctx, "device synchronisation failed after setup");
     return ctx;
 }
@@ -812,6 +813,7 @@ int drmlt_stats_get(drmlt_ctx *ctx, drmlt_stats *o) {
     o->n_chains = ctx->n_chains;
     o->max_dim = (uint32_t) ctx->P.max_dim;
     o->launches = ctx->launches;
+    o->bvh_node_visits = v[10]; o->bvh_prim_tests = v[11];
     return DRMLT_OK;
 }
 

@@ -392,6 +392,7 @@ int drmlt_node_stats_get(drmlt_node *node, drmlt_stats *out) {
         out->n_chains += s.n_chains;
         out->max_dim = s.max_dim;
         out->launches += s.launches;
+        out->bvh_node_visits += s.bvh_node_visits; out->bvh_prim_tests += s.bvh_prim_tests;
     }
     return DRMLT_OK;
 }

@@ -765,7 +765,8 @@ __global__ void __launch_bounds__(CHAIN_BLOCK) k_mutate_v3(DParams P, uint32_t n
 //
 // Chains are the same as k_mutate_v2/v3's (same addressed draws, same arithmetic per chain).
 #define V4_STRIDE 33u // row stride of the sampler rows: (row + chain) mod 32 banks serve per-chain AND per-dimension access patterns
-#define V4_QCAP 160u  // splat queue entries: flushed at >= 63, one bookkeeping branch adds at most 3 x 32
+#define V4_QCAP 160u  // splat queue entries: flushed when a bookkeeping branch (at most 3 x 32 new entries) might not fit
+#define V4_QCAP_BVH 100u // BVH scenes: their kernel also keeps the traversal stack in LDS (6 KB); flushes are a negligible part of it
 
 // field-by-field copy of the parameter block out of the kernarg segment (constant address space: scalar loads)
 typedef const DParams __attribute__((address_space(4))) *KArgPtr;
@@ -780,6 +781,7 @@ DEV void load_params(DParams &dst, KArgPtr src) {
 
 struct V4Lds {
     uint32_t coin_off, list_off, q_off; // float offsets into lds_x
+    uint32_t qcap;                      // queue entries (row length of the five queue rows)
 };
 
 // one colour channel of ImageBlock::put (see film_put): lanes 3s, 3s+1, 3s+2 carry the channels of splat s
@@ -807,7 +809,7 @@ DEV void v4_enqueue(const V4Lds &L, uint32_t &qn, bool want, float px, float py,
     if (want) {
         const uint32_t slot = qn + __builtin_amdgcn_mbcnt_hi((uint32_t) (m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) m, 0u));
         float *q = &lds_x[L.q_off + slot];
-        q[0] = px; q[V4_QCAP] = py; q[2u * V4_QCAP] = r; q[3u * V4_QCAP] = g; q[4u * V4_QCAP] = b;
+        q[0] = px; q[L.qcap] = py; q[2u * L.qcap] = r; q[3u * L.qcap] = g; q[4u * L.qcap] = b;
     }
     qn += (uint32_t) __popcll(m);
 }
@@ -817,7 +819,7 @@ DEV void v4_flush(const DParams &P, const V4Lds &L, uint32_t &qn, uint32_t lane)
         const uint32_t e = base + s;
         if (e < qn && s < 21u) {
             const float *q = &lds_x[L.q_off + e];
-            film_put_channel(P, q[0], q[V4_QCAP], q[(2u + ch) * V4_QCAP], (int) ch);
+            film_put_channel(P, q[0], q[L.qcap], q[(2u + ch) * L.qcap], (int) ch);
         }
     }
     qn = 0u;
@@ -833,8 +835,9 @@ struct V4Layout {
     LdsTables LT;
     uint32_t D, D4, nb1;
 };
-DEV V4Layout v4_layout(const DParams &P) {
+DEV V4Layout v4_layout(const DParams &P, uint32_t qcap) {
     V4Layout Y;
+    Y.L.qcap = qcap;
     Y.D = (uint32_t) P.eff_dim;
     Y.D4 = (Y.D + 3u) & ~3u;
     Y.nb1 = Y.D4 / 4u; // first-stage Philox blocks of a mutation; item nb1 of a chain = the coins of its NEXT mutation
@@ -846,13 +849,13 @@ DEV V4Layout v4_layout(const DParams &P) {
     Y.L.coin_off = Y.smp.z_off + Y.D4 * V4_STRIDE;
     Y.L.list_off = Y.L.coin_off + 4u * V4_STRIDE;
     Y.L.q_off = Y.L.list_off + 32u;
-    Y.LT.shade_off = (Y.L.q_off + 5u * V4_QCAP + 3u) & ~3u;
+    Y.LT.shade_off = (Y.L.q_off + 5u * qcap + 3u) & ~3u;
     Y.LT.bsdf_off = Y.LT.shade_off + (uint32_t) P.n_shade * 16u;
     Y.LT.emit_off = Y.LT.bsdf_off + (uint32_t) P.n_bsdfs * 12u;
     return Y;
 }
 
-template <int FEAT, bool LDS_TABLES, bool STAMPS>
+template <int FEAT, bool LDS_TABLES, bool STAMPS, bool STACK16 = false>
 __global__ void __launch_bounds__(CHAIN_BLOCK) k_mutate_v4(DParams P, uint32_t n_mut, uint32_t mut_base) {
     // The parameter block is ~80 dwords, most of it used by one loop section only. Left to itself the compiler loads every
     // field it will ever need before the loop and then spills scalar registers into vector lanes all through the loop
@@ -873,6 +876,7 @@ __global__ void __launch_bounds__(CHAIN_BLOCK) k_mutate_v4(DParams P, uint32_t n
     const bool live = !helper && c < P.n_chains;
     const uint32_t cc = c < P.n_chains ? c : P.n_chains - 1;
     const uint32_t S = V4_STRIDE;
+    constexpr uint32_t QCAP = (FEAT & 8) ? V4_QCAP_BVH : V4_QCAP;
     int smp_mode = SM_STAGE1; // per-lane part of the sampler (which proposal the path in flight reads)
     uint32_t qn = 0u;
     ChainState cs;
@@ -882,8 +886,14 @@ __global__ void __launch_bounds__(CHAIN_BLOCK) k_mutate_v4(DParams P, uint32_t n
     bool helper_has_ray = false;
     Hit h{-1, 0.f, 0.f, 0.f};
     int batch;
+    constexpr bool RESUMABLE = (FEAT & 8) != 0; // BVH scenes: traversals survive loop iterations (device_path.h: Trav)
+    Trav T;
+    T.active = false; T.cur = 0; T.sp = 0; T.any_hit = false; T.h = h; T.tmin = 0.f;
+    T.o = T.d = T.inv = T.oi = mk3(0.f, 0.f, 0.f);
+    trav_reset_counters(T);
+    int rstate = 0; // ray of this lane: 0 none, 1 issued, 2 being traversed, 3 result waiting to be consumed
     {
-        const V4Layout Y = v4_layout(P);
+        const V4Layout Y = v4_layout(P, QCAP);
         if (!helper)
             for (uint32_t k = 0; k < Y.D; ++k) lds_x[k * S + sub] = P.x[(size_t) k * P.n_chains + cc];
         cs.cur.lum = P.cur_lum[cc]; cs.cur.px = P.cur_px[cc]; cs.cur.py = P.cur_py[cc];
@@ -919,14 +929,14 @@ __global__ void __launch_bounds__(CHAIN_BLOCK) k_mutate_v4(DParams P, uint32_t n
         if (pmask && (__popcll(pmask) >= batch || !rmask)) {
             n_mh++;
             SECTION_PARAMS(Pm);
-            const V4Layout Y = v4_layout(Pm);
+            const V4Layout Y = v4_layout(Pm, QCAP);
             const V4Lds &L = Y.L;
             RowSampler smp = Y.smp;
             smp.lane = sub; smp.mode = smp_mode;
             const uint32_t nb1 = Y.nb1, D4 = Y.D4, D = Y.D;
             int *const lds_list = reinterpret_cast<int *>(&lds_x[L.list_off]);
             if (prio) __builtin_amdgcn_s_setprio(2);
-            if (qn >= 63u) { SECTION_PARAMS(Pf); v4_flush(Pf, L, qn, lane); }
+            if (qn + 96u > QCAP) { SECTION_PARAMS(Pf); v4_flush(Pf, L, qn, lane); } // room for this branch's splats (at most 3 per chain)
             // ---- decide (parked chain lanes): weights, commit mode, what the chain does next
             int commit = 0, kind = 0; // kind: 0 nothing / finished, 1 next mutation, 2 second stage, 3 Green's reverse
             bool want0 = false, want1 = false, want2 = false;
@@ -1001,7 +1011,7 @@ __global__ void __launch_bounds__(CHAIN_BLOCK) k_mutate_v4(DParams P, uint32_t n
             // ---- proposals of the chains that start a mutation, flattened: items (chain j, Philox block b) -> dimensions
             // 4b..4b+3 of y; block nb1 = the four coins (large step, first / second acceptance, mixture) of the NEXT mutation
             SECTION_PARAMS(Pg);
-            const V4Layout Yg = v4_layout(Pg);
+            const V4Layout Yg = v4_layout(Pg, QCAP);
             RowSampler smg = Yg.smp;
             const uint32_t chain_base_g = Pg.chain_offset + blockIdx.x * 32u;
             const uint32_t maj_mine = mut_base + cs.it; // the mutation in flight (cs.it counts decided mutations)
@@ -1058,45 +1068,91 @@ __global__ void __launch_bounds__(CHAIN_BLOCK) k_mutate_v4(DParams P, uint32_t n
                     path_init(Pb, ps);
                     const float v0 = smp.next(0u), v1 = smp.next(1u);
                     path_begin(Pb, ps, v0, v1);
+                    if (RESUMABLE) rstate = 1;
                 }
             }
             const unsigned long long m5 = STAMP();
             t_decide += m1 - s0; t_commit += m2 - m1; t_fill += m4 - m3; t_start += (m3 - m2) + (m5 - m4);
         }
-        // one ray per lane: chain lanes their camera / bounce ray, helpers the shadow ray they were handed
         const unsigned long long s1 = STAMP();
-        const bool tracing = helper ? helper_has_ray : ps.phase == PH_CLOSEST;
-        if (stamps) n_busy += __popcll(__ballot(tracing));
-        if (stamps) { const int nl = __popcll(__ballot(tracing && !helper)); hist[nl == 0 ? 0 : (nl <= 4 ? 1 : (nl <= 8 ? 2 : (nl <= 16 ? 3 : (nl <= 24 ? 4 : 5))))]++; }
-        if (prio) __builtin_amdgcn_s_setprio(0);
-        {
-            SECTION_PARAMS(Pt);
-            if (tracing) h = trace<FEAT>(Pt, ps.o, ps.d, ps.tmin, ps.tmax, helper);
-        }
-        if (prio) __builtin_amdgcn_s_setprio(3);
-        const unsigned long long s2 = STAMP();
-        const unsigned occluded = from_upper_u((helper_has_ray && h.prim >= 0) ? 1u : 0u);
-        helper_has_ray = false;
-        ShadowRay sr;
-        sr.o = ps.o; sr.d = ps.d; sr.tmin = 0.f; sr.tmax = 0.f; sr.valid = false;
-        {
-            SECTION_PARAMS(Ps);
-            if (!helper && ps.phase != PH_DONE && ps.phase != PH_IDLE) {
-                const V4Layout Y = v4_layout(Ps);
-                RowSampler smp = Y.smp;
-                smp.lane = sub; smp.mode = smp_mode;
-                if (LDS_TABLES) path_step<true, FEAT, RowSampler, LdsTables, false>(Ps, Y.LT, ps, smp, h, occluded == 0u, sr);
-                else path_step<true, FEAT, RowSampler, GlobalTables, false>(Ps, GlobalTables{Ps.shade, Ps.bsdfs, Ps.emitters}, ps, smp, h, occluded == 0u, sr);
+        unsigned long long s2 = s1;
+        if constexpr (!RESUMABLE) {
+            // one ray per lane: chain lanes their camera / bounce ray, helpers the shadow ray they were handed
+            const bool tracing = helper ? helper_has_ray : ps.phase == PH_CLOSEST;
+            if (stamps) n_busy += __popcll(__ballot(tracing));
+            if (stamps) { const int nl = __popcll(__ballot(tracing && !helper)); hist[nl == 0 ? 0 : (nl <= 4 ? 1 : (nl <= 8 ? 2 : (nl <= 16 ? 3 : (nl <= 24 ? 4 : 5))))]++; }
+            if (prio) __builtin_amdgcn_s_setprio(0);
+            {
+                SECTION_PARAMS(Pt);
+                if (tracing) h = trace<FEAT>(Pt, ps.o, ps.d, ps.tmin, ps.tmax, helper);
             }
-        }
-        // hand the shadow ray of this vertex to the helper lane
-        const float ox = from_lower(sr.o.x), oy = from_lower(sr.o.y), oz = from_lower(sr.o.z);
-        const float dx = from_lower(sr.d.x), dy = from_lower(sr.d.y), dz = from_lower(sr.d.z);
-        const float t0 = from_lower(sr.tmin), t1 = from_lower(sr.tmax);
-        const float vf = from_lower(sr.valid ? 1.f : 0.f);
-        if (helper) {
-            ps.o = mk3(ox, oy, oz); ps.d = mk3(dx, dy, dz); ps.tmin = t0; ps.tmax = t1;
-            helper_has_ray = vf != 0.f;
+            if (prio) __builtin_amdgcn_s_setprio(3);
+            s2 = STAMP();
+            const unsigned occluded = from_upper_u((helper_has_ray && h.prim >= 0) ? 1u : 0u);
+            helper_has_ray = false;
+            ShadowRay sr;
+            sr.o = ps.o; sr.d = ps.d; sr.tmin = 0.f; sr.tmax = 0.f; sr.valid = false;
+            {
+                SECTION_PARAMS(Ps);
+                if (!helper && ps.phase != PH_DONE && ps.phase != PH_IDLE) {
+                    const V4Layout Y = v4_layout(Ps, QCAP);
+                    RowSampler smp = Y.smp;
+                    smp.lane = sub; smp.mode = smp_mode;
+                    if (LDS_TABLES) path_step<true, FEAT, RowSampler, LdsTables, false>(Ps, Y.LT, ps, smp, h, occluded == 0u, sr);
+                    else path_step<true, FEAT, RowSampler, GlobalTables, false>(Ps, GlobalTables{Ps.shade, Ps.bsdfs, Ps.emitters}, ps, smp, h, occluded == 0u, sr);
+                }
+            }
+            // hand the shadow ray of this vertex to the helper lane
+            const float ox = from_lower(sr.o.x), oy = from_lower(sr.o.y), oz = from_lower(sr.o.z);
+            const float dx = from_lower(sr.d.x), dy = from_lower(sr.d.y), dz = from_lower(sr.d.z);
+            const float t0 = from_lower(sr.tmin), t1 = from_lower(sr.tmax);
+            const float vf = from_lower(sr.valid ? 1.f : 0.f);
+            if (helper) {
+                ps.o = mk3(ox, oy, oz); ps.d = mk3(dx, dy, dz); ps.tmin = t0; ps.tmax = t1;
+                helper_has_ray = vf != 0.f;
+            }
+        } else {
+            // ---- BVH scenes. A lane's traversal continues across iterations; a slice ends when every traversal is done
+            // or `trace_yield` lanes have finished theirs. A chain lane steps when its own ray AND its partner's shadow
+            // ray (of the previous vertex) are both done; everybody else just keeps traversing next time round.
+            if (prio) __builtin_amdgcn_s_setprio(0);
+            {
+                SECTION_PARAMS(Pt);
+                if (rstate == 1) { trav_begin(T, ps.o, ps.d, ps.tmin, ps.tmax, helper); rstate = 2; }
+                if (STACK16) trav_run<short>(Pt, T, rstate == 2, Pt.trace_yield);
+                else trav_run<int>(Pt, T, rstate == 2, Pt.trace_yield);
+                if (rstate == 2 && !T.active) rstate = 3;
+            }
+            if (prio) __builtin_amdgcn_s_setprio(3);
+            s2 = STAMP();
+            const unsigned partner_busy = from_upper_u((rstate == 1 || rstate == 2) ? 1u : 0u);
+            const unsigned occluded = from_upper_u((rstate == 3 && T.h.prim >= 0) ? 1u : 0u);
+            const bool ready = !helper && partner_busy == 0u && ((ps.phase == PH_CLOSEST && rstate == 3) || ps.phase == PH_FLUSH);
+            ShadowRay sr;
+            sr.o = ps.o; sr.d = ps.d; sr.tmin = 0.f; sr.tmax = 0.f; sr.valid = false;
+            {
+                SECTION_PARAMS(Ps);
+                if (ready) {
+                    h = T.h;
+                    rstate = 0;
+                    const V4Layout Y = v4_layout(Ps, QCAP);
+                    RowSampler smp = Y.smp;
+                    smp.lane = sub; smp.mode = smp_mode;
+                    if (LDS_TABLES) path_step<true, FEAT, RowSampler, LdsTables, false>(Ps, Y.LT, ps, smp, h, occluded == 0u, sr);
+                    else path_step<true, FEAT, RowSampler, GlobalTables, false>(Ps, GlobalTables{Ps.shade, Ps.bsdfs, Ps.emitters}, ps, smp, h, occluded == 0u, sr);
+                    if (ps.phase == PH_CLOSEST) rstate = 1;
+                }
+            }
+            // the partner's result has been consumed; hand it the shadow ray of this vertex, if any
+            const unsigned stepped = from_lower_u(ready ? 1u : 0u);
+            const float ox = from_lower(sr.o.x), oy = from_lower(sr.o.y), oz = from_lower(sr.o.z);
+            const float dx = from_lower(sr.d.x), dy = from_lower(sr.d.y), dz = from_lower(sr.d.z);
+            const float t0 = from_lower(sr.tmin), t1 = from_lower(sr.tmax);
+            const float vf = from_lower(sr.valid ? 1.f : 0.f);
+            if (helper && stepped != 0u) {
+                rstate = 0;
+                if (vf != 0.f) { ps.o = mk3(ox, oy, oz); ps.d = mk3(dx, dy, dz); ps.tmin = t0; ps.tmax = t1; rstate = 1; }
+            }
         }
         const unsigned long long s3 = STAMP();
         t_mh += s1 - s0; t_trace += s2 - s1; t_step += s3 - s2; n_iter++;
@@ -1104,7 +1160,7 @@ __global__ void __launch_bounds__(CHAIN_BLOCK) k_mutate_v4(DParams P, uint32_t n
 #undef STAMP
 #undef SECTION_PARAMS
     // "Perform the last splat": the current states with what they have accumulated since they were adopted
-    const V4Layout Y = v4_layout(P);
+    const V4Layout Y = v4_layout(P, QCAP);
     v4_enqueue(Y.L, qn, live && cum > 0.f, cs.cur.px, cs.cur.py, cs.cur.r * cum, cs.cur.g * cum, cs.cur.b * cum);
     v4_flush(P, Y.L, qn, lane);
     if (stamps && lane == 0) {
@@ -1127,6 +1183,10 @@ __global__ void __launch_bounds__(CHAIN_BLOCK) k_mutate_v4(DParams P, uint32_t n
     v[8] = wave_sum(ct.rays);
     if (lane == 0)
         for (int i = 0; i < 9; ++i) atomicAdd(P.stats + i, v[i]);
+    if (RESUMABLE) {
+        const unsigned long long nn = wave_sum(T.n_nodes), np = wave_sum(T.n_prims);
+        if (lane == 0) { atomicAdd(P.stats + 10, nn); atomicAdd(P.stats + 11, np); }
+    }
 }
 
 __global__ void __launch_bounds__(64) k_eval_paths(DParams P, const float *u, uint32_t n, uint32_t dim, float *out8) {
@@ -1203,7 +1263,8 @@ void launch_mutate(const DParams &P, uint32_t n_mut, uint32_t mut_base, hipStrea
     if (P.kernel_variant == 1) {
         hipLaunchKernelGGL(k_mutate, grid, block, D * 64 * sizeof(float), st, P, n_mut, mut_base);
     } else if (P.kernel_variant == 4) { // free-running chains, flattened bookkeeping, queued splats (rows of 33 floats)
-        size_t lds = ((D + 2 * D4 + 4) * V4_STRIDE + 32 + 5 * V4_QCAP + 3) / 4 * 4 * sizeof(float);
+        const size_t qcap = (P.features & 8) || !P.tables_in_lds ? V4_QCAP_BVH : V4_QCAP; // as the kernel variants below
+        size_t lds = ((D + 2 * D4 + 4) * V4_STRIDE + 32 + 5 * qcap + 3) / 4 * 4 * sizeof(float);
         if (P.tables_in_lds) lds += (size_t) P.n_shade * 64 + (size_t) P.n_bsdfs * 48 + (size_t) P.n_emitters * 32;
         if (getenv("DRMLT_VERBOSE")) fprintf(stderr, "[drmlt] k_mutate_v4: %zu B of LDS per wave\n", lds);
         const dim3 g4((P.n_chains + 31) / 32);
@@ -1212,9 +1273,11 @@ void launch_mutate(const DParams &P, uint32_t n_mut, uint32_t mut_base, hipStrea
             else if (P.features == 0) hipLaunchKernelGGL((k_mutate_v4<0, true, false>), g4, block, lds, st, P, n_mut, mut_base);
             else if ((P.features & ~3) == 0) hipLaunchKernelGGL((k_mutate_v4<3, true, false>), g4, block, lds, st, P, n_mut, mut_base);
             else if ((P.features & 8) == 0) hipLaunchKernelGGL((k_mutate_v4<7, true, false>), g4, block, lds, st, P, n_mut, mut_base);
+            else if (P.bvh_stack16) hipLaunchKernelGGL((k_mutate_v4<15, true, false, true>), g4, block, lds, st, P, n_mut, mut_base);
             else hipLaunchKernelGGL((k_mutate_v4<15, true, false>), g4, block, lds, st, P, n_mut, mut_base);
         } else {
-            hipLaunchKernelGGL((k_mutate_v4<15, false, false>), g4, block, lds, st, P, n_mut, mut_base);
+            if (P.bvh_stack16) hipLaunchKernelGGL((k_mutate_v4<15, false, false, true>), g4, block, lds, st, P, n_mut, mut_base);
+            else hipLaunchKernelGGL((k_mutate_v4<15, false, false>), g4, block, lds, st, P, n_mut, mut_base);
         }
     } else if (P.kernel_variant == 3) { // 32 chains per wave, rows of 32 floats
         size_t lds = (D + 2 * D4) * 32 * sizeof(float);

@@ -148,7 +148,7 @@ class SceneData:
         """Flat binary scene file read by the C++ host (host/drmlt_integrator.hpp: SceneFile::load)."""
         import struct as _st
         with open(path, "wb") as f:
-            f.write(_st.pack("<8I", 0x4C4D5244, 1, len(self.shapes), len(self.bsdfs), len(self.emitters),
+            f.write(_st.pack("<8I", 0x4C4D5244, abi.ABI_VERSION, len(self.shapes), len(self.bsdfs), len(self.emitters),
                              C.sizeof(abi.Shape), C.sizeof(abi.Bsdf), C.sizeof(abi.Emitter)))
             for group in (self.shapes, self.bsdfs, self.emitters):
                 for item in group:

@@ -186,6 +186,8 @@ typedef struct drmlt_stats {
     uint32_t n_chains;
     uint32_t max_dim;            /* findMaxDimensions(...).sensor                        */
     uint64_t launches;           /* chain-kernel launches so far                         */
+    uint64_t bvh_node_visits;    /* 4-wide BVH nodes fetched (128 B each); 0 for brute-force scenes */
+    uint64_t bvh_prim_tests;     /* primitive records fetched in BVH leaves (64 B each)           */
 } drmlt_stats;
 
 /* one evaluated PSS point: SplatList of pathsampler.cpp:529-567 (one splat) */

@@ -74,8 +74,49 @@ int main(int argc, char **argv) {
             }
         }
 
-    // ---- queries: the set of primitive boxes a ray can hit, through the tree and by brute force
-    int mismatches = 0, max_stack = 0;
+    // ---- the 4-wide tree the kernels traverse: same checks (every primitive in exactly one leaf, boxes bound subtrees),
+    // the stack bound 3 * depth4 <= BVH_STACK, and the same queries
+    std::vector<DBvh4Node> n4;
+    int shift = 0;
+    const int depth4 = build_bvh4(nodes, n4, &shift);
+    std::vector<int> seen4(n, 0);
+    int leaves4 = 0, measured_depth4 = 0;
+    {
+        struct It4 { int node, d; };
+        std::vector<It4> todo4{{0, 1}};
+        while (!todo4.empty()) {
+            const It4 it = todo4.back();
+            todo4.pop_back();
+            measured_depth4 = std::max(measured_depth4, it.d);
+            const DBvh4Node &N = n4[it.node];
+            for (int c = 0; c < 4; ++c) {
+                const float lo[3] = {N.lox[c], N.loy[c], N.loz[c]}, hi[3] = {N.hix[c], N.hiy[c], N.hiz[c]};
+                if (N.child[c] >= 0) {
+                    todo4.push_back({N.child[c], it.d + 1});
+                    const DBvh4Node &C = n4[N.child[c]];
+                    for (int q = 0; q < 4; ++q) {
+                        if (C.lox[q] == FLT_MAX) continue; // empty slot
+                        ok = ok && C.lox[q] >= lo[0] && C.loy[q] >= lo[1] && C.loz[q] >= lo[2] && C.hix[q] <= hi[0] && C.hiy[q] <= hi[1] && C.hiz[q] <= hi[2];
+                    }
+                } else {
+                    if (lo[0] == FLT_MAX) continue; // empty slot: point box at +FLT_MAX
+                    const int first = ~N.child[c] >> shift, cnt = shift ? (~N.child[c] & 7) : 1;
+                    leaves4++;
+                    ok = ok && cnt <= 4;
+                    for (int i = 0; i < cnt; ++i) {
+                        const int p = order[first + i];
+                        seen4[p]++;
+                        for (int k = 0; k < 3; ++k) ok = ok && pb[p].lo[k] >= lo[k] && pb[p].hi[k] <= hi[k];
+                    }
+                }
+            }
+        }
+    }
+    for (int i = 0; i < n; ++i) ok = ok && seen4[i] == 1;
+    ok = ok && measured_depth4 == depth4 && 3 * depth4 <= BVH_STACK;
+
+    // ---- queries: the set of primitive boxes a ray can hit, through both trees and by brute force
+    int mismatches = 0, max_stack = 0, max_stack4 = 0;
     for (int q = 0; q < 2000; ++q) {
         float o[3] = {U(rng) * 2.f, U(rng) * 2.f, U(rng) * 2.f}, d[3] = {U(rng), U(rng), U(rng)}, inv[3];
         for (int k = 0; k < 3; ++k) inv[k] = 1.f / d[k];
@@ -93,9 +134,27 @@ int main(int argc, char **argv) {
                 for (int i = 0; i < cnt; ++i) { const int p = order[~c + i]; if (box_hit(pb[p].lo, pb[p].hi, o, inv, 1e30f)) tree += p + 1; }
             }
         }
+        long tree4 = 0;
+        std::vector<int> st4{0};
+        size_t max4 = 0;
+        while (!st4.empty()) {
+            max4 = std::max(max4, st4.size());
+            const DBvh4Node &N = n4[st4.back()];
+            st4.pop_back();
+            for (int c = 0; c < 4; ++c) {
+                const float lo[3] = {N.lox[c], N.loy[c], N.loz[c]}, hi[3] = {N.hix[c], N.hiy[c], N.hiz[c]};
+                if (!box_hit(lo, hi, o, inv, 1e30f)) continue; // empty slots must fail this test by themselves
+                if (N.child[c] >= 0) { st4.push_back(N.child[c]); continue; }
+                const int first = ~N.child[c] >> shift, cnt = shift ? (~N.child[c] & 7) : 1;
+                for (int i = 0; i < cnt; ++i) { const int p = order[first + i]; if (box_hit(pb[p].lo, pb[p].hi, o, inv, 1e30f)) tree4 += p + 1; }
+            }
+        }
+        max_stack4 = std::max(max_stack4, (int) max4);
         mismatches += brute != tree;
+        mismatches += brute != tree4;
     }
-    printf("{\"ok\": %s, \"n\": %d, \"nodes\": %zu, \"leaves\": %d, \"depth\": %d, \"median_splits\": %d, \"mismatches\": %d, \"stack\": %d}\n",
-           ok ? "true" : "false", n, nodes.size(), leaves, depth, medians, mismatches, BVH_STACK);
+    printf("{\"ok\": %s, \"n\": %d, \"nodes\": %zu, \"leaves\": %d, \"depth\": %d, \"median_splits\": %d, \"mismatches\": %d, \"stack\": %d, "
+           "\"nodes4\": %zu, \"leaves4\": %d, \"depth4\": %d}\n",
+           ok ? "true" : "false", n, nodes.size(), leaves, depth, medians, mismatches, BVH_STACK, n4.size(), leaves4, depth4);
     return 0;
 }

@@ -17,18 +17,21 @@ def harness(tmp_path_factory):
     return lambda *a: json.loads(subprocess.run([exe, *map(str, a)], check=True, capture_output=True, text=True).stdout)
 
 
-@pytest.mark.parametrize("kind,n", [("soup", 3000), ("chain", 160), ("coincident", 500), ("soup", 49)])
+@pytest.mark.parametrize("kind,n", [("soup", 3000), ("chain", 160), ("coincident", 500), ("soup", 49), ("soup", 20000)])
 def test_tree_is_complete_and_answers_like_brute_force(harness, kind, n):
-    r = harness(kind, n, 24)
+    """Binary SAH tree (depth <= 16) and the 4-wide tree collapsed from it (3 * depth4 <= the 24-entry stack)."""
+    r = harness(kind, n, 16)
     assert r["ok"] and r["mismatches"] == 0, r
-    assert r["leaves"] == n and r["nodes"] == n - 1        # one primitive per leaf, binary tree
-    assert r["depth"] <= r["stack"] == 24, r
+    assert r["nodes"] == r["leaves"] - 1                     # binary tree
+    assert r["leaves"] == n                                  # one primitive per leaf
+    assert r["leaves4"] == r["leaves"] and r["nodes4"] < r["nodes"]
+    assert r["depth"] <= 16 and 3 * r["depth4"] <= r["stack"] == 24, r
 
 
 def test_depth_bound_forces_median_splits(harness):
     free = harness("chain", 160, 24)
     tight = harness("chain", 160, 9)                         # ceil(log2(160)) = 8 is the least a binary tree needs
     assert free["depth"] > 9 and tight["depth"] <= 9 and tight["median_splits"] > 0, (free, tight)
-    assert tight["ok"] and tight["mismatches"] == 0
+    assert tight["ok"] and tight["mismatches"] == 0 and 3 * tight["depth4"] <= 24
     # a bound below what a balanced tree needs is raised to that, never violated silently
     assert harness("soup", 3000, 4)["depth"] <= 12

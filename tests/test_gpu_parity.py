@@ -74,10 +74,10 @@ def test_bvh_and_brute_force_agree_on_device(pkg, ob, native_lib):
 
 
 def test_deep_bvh_stays_within_the_traversal_stack(pkg, ob, native_lib, capfd):
-    """Geometrically shrinking triangles make SAH peel a few primitives per level (a chain 24 levels deep for this
-    scene). The kernels' stack holds 24 entries, so the builder bounds the depth by falling back to median splits;
-    DRMLT_BVH_MAX_DEPTH lowers the bound so that the fallback is exercised, and traversal must still agree with the
-    brute-force loop."""
+    """Geometrically shrinking triangles make SAH peel a few primitives per level (a chain > 20 levels deep for this
+    scene). The kernels' stack holds 24 entries and a 4-wide node pushes up to 3, so the builder bounds the binary depth
+    (16, median-split fallback) and collapses to a 4-wide depth <= 8; DRMLT_BVH_MAX_DEPTH lowers the binary bound so that
+    the fallback is certainly exercised, and traversal must still agree with the brute-force loop."""
     import re
     sd = pkg.scenes.cornell_c2(64)
     white = 0
@@ -92,12 +92,12 @@ def test_deep_bvh_stays_within_the_traversal_stack(pkg, ob, native_lib, capfd):
     os.environ["DRMLT_BVH_THRESHOLD"] = "0"
     os.environ["DRMLT_VERBOSE"] = "1"
     try:
-        for bound, want_median in (("24", None), ("10", True)):
+        for bound, want_median in (("16", None), ("9", True)):
             os.environ["DRMLT_BVH_MAX_DEPTH"] = bound
             b = pkg.Context(cfg, sd).eval_paths(u)
             log = capfd.readouterr().err
-            m = re.search(r"BVH: (\d+) primitives, (\d+) nodes, depth (\d+) \(stack 24\), (\d+) median splits", log)
-            assert m and int(m.group(3)) <= int(bound) and (want_median is None or int(m.group(4)) > 0), log
+            m = re.search(r"BVH: (\d+) primitives, (\d+) binary / (\d+) 4-wide nodes, 4-wide depth (\d+) \(stack 24\), (\d+) median splits", log)
+            assert m and 3 * int(m.group(4)) <= 24 and int(m.group(3)) < int(m.group(2)) and (want_median is None or int(m.group(5)) > 0), log
             same = a["n_dims"] == b["n_dims"]
             assert same.mean() > 0.999
             assert np.allclose(a["luminance"][same], b["luminance"][same], rtol=1e-4, atol=1e-6)

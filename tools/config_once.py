@@ -6,7 +6,7 @@ pkg = g.load_package()
 scene, typ = sys.argv[1], sys.argv[2]
 res = int(sys.argv[3]) if len(sys.argv) > 3 else 256
 spp = int(sys.argv[4]) if len(sys.argv) > 4 else 256
-sd = pkg.scenes.SCENES[scene](res)
+sd = pkg.scenes.triangle_soup(int(os.environ.get('N_TRIS', 2000)), res) if scene == 'triangle_soup' else pkg.scenes.SCENES[scene](res=res)
 cfg = pkg.abi.make_config(type=typ, max_depth=8, direct_samples=-1, work_units=65536, luminance_samples=655360, sample_count=spp)
 c = pkg.Context(cfg, sd)
 c.seed(0x5EED)

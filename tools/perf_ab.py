@@ -11,7 +11,7 @@ chains = int(os.environ.get("CHAINS", 65536))
 spp = int(os.environ.get("SPP", 64))
 res = int(os.environ.get("RES", 512))
 typ = os.environ.get("TYPE", "orbital")
-sd = scenes.SCENES[os.environ.get("SCENE", "cornell_c2")](res)
+sd = scenes.triangle_soup(int(os.environ.get("N_TRIS", 2000)), res) if os.environ.get("SCENE") == "triangle_soup" else scenes.SCENES[os.environ.get("SCENE", "cornell_c2")](res=res)
 ctxs = {}
 for v in variants:
     env = dict(kv.split("=") for kv in v.split("+") if "=" in kv)
@@ -38,4 +38,4 @@ for v in variants:
     r = np.array(rates[v])
     st = ctxs[v].stats()
     if os.environ.get("ALL"): print("   rates:", " ".join("%.3e" % x for x in r))
-    print("variant %-24s median %.4e  min %.4e  max %.4e mut/s   rays/mut %.2f  acc %.3f" % (v, np.median(r), r.min(), r.max(), st.rays / st.mutations, st.accepted / st.mutations))
+    print("variant %-24s median %.4e  min %.4e  max %.4e mut/s   rays/mut %.2f  acc %.3f  bvh nodes/ray %.1f prims/ray %.1f" % (v, np.median(r), r.min(), r.max(), st.rays / st.mutations, st.accepted / st.mutations, st.bvh_node_visits / max(st.rays, 1), st.bvh_prim_tests / max(st.rays, 1)))
