@@ -1,0 +1,1 @@
+#include <mitsuba/fake_mitsuba.h>
