@@ -28,7 +28,7 @@ ABI_SYMBOLS = (
     "drmlt_seed_pool", "drmlt_comm_unique_id", "drmlt_comm_init", "drmlt_exchange_tiled",
     "drmlt_node_create", "drmlt_node_seed", "drmlt_node_run", "drmlt_node_develop", "drmlt_node_stats_get",
     "drmlt_node_set_importance_map", "drmlt_node_device_count", "drmlt_node_context", "drmlt_node_last_error",
-    "drmlt_node_destroy",
+    "drmlt_node_destroy", "drmlt_bootstrap_luminances", "drmlt_seed_indices",
 )
 
 
@@ -100,6 +100,8 @@ def load_library():
     L.drmlt_node_last_error.restype = C.c_char_p
     L.drmlt_node_last_error.argtypes = [C.c_void_p]
     L.drmlt_node_destroy.argtypes = [C.c_void_p]
+    L.drmlt_bootstrap_luminances.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_void_p]
+    L.drmlt_seed_indices.argtypes = [C.c_void_p, C.c_void_p]
     _lib = L
     return L
 
@@ -140,6 +142,16 @@ class Context:
         b = C.c_double()
         self._chk(self.L.drmlt_seed(self.h, seed, chain_offset, C.byref(b)))
         return b.value
+
+    def bootstrap_luminances(self, seed, stream, n):
+        out = np.empty(n, dtype=np.float32)
+        self._chk(self.L.drmlt_bootstrap_luminances(self.h, seed, stream, n, out.ctypes.data))
+        return out
+
+    def seed_indices(self):
+        out = np.empty(self.cfg.work_units if self.cfg.work_units > 0 else self.stats().n_chains, dtype=np.uint32)
+        self._chk(self.L.drmlt_seed_indices(self.h, out.ctypes.data))
+        return out
 
     def seed_pool(self, seed, first_chain, pool_chains):
         """Seeds [first_chain, first_chain + work_units) of ONE pool drawn for `pool_chains` chains."""

@@ -582,6 +582,7 @@ static int seed_impl(drmlt_ctx *ctx, uint64_t seed, uint32_t chain_offset, uint3
         std::vector<uint32_t> mine(seed_index.begin() + chain_offset, seed_index.begin() + chain_offset + ctx->n_chains);
         seed_index.swap(mine);
     }
+    ctx->seed_indices = seed_index;
     std::vector<float> seed_lum(ctx->n_chains);
     for (uint32_t j = 0; j < ctx->n_chains; ++j) seed_lum[j] = lum[seed_index[j]];
 
@@ -612,6 +613,30 @@ static int seed_impl(drmlt_ctx *ctx, uint64_t seed, uint32_t chain_offset, uint3
 }
 
 int drmlt_seed(drmlt_ctx *ctx, uint64_t seed, uint32_t chain_offset, double *b_out) { return seed_impl(ctx, seed, chain_offset, 0u, b_out); }
+
+int drmlt_bootstrap_luminances(drmlt_ctx *ctx, uint64_t seed, uint32_t stream, uint32_t n, float *out) {
+    if (!ctx || !out) return DRMLT_E_INVALID;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    DParams P = ctx->P;
+    P.key0 = (uint32_t) seed; P.key1 = (uint32_t) (seed >> 32);
+    P.boot_stream = stream;
+    DevBuf d_lum;
+    HIP_TRY(ctx, d_lum.alloc((size_t) n * sizeof(float)));
+    if (ctx->cfg.technique == DRMLT_TECH_MMLT) launch_bootstrap_mmlt(P, n, d_lum.as<float>(), ctx->stream);
+    else if (ctx->cfg.technique == DRMLT_TECH_BDPT) launch_bootstrap_bdpt(P, n, d_lum.as<float>(), ctx->stream);
+    else launch_bootstrap(P, n, d_lum.as<float>(), ctx->stream);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipMemcpyAsync(out, d_lum.p, (size_t) n * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return DRMLT_OK;
+}
+
+int drmlt_seed_indices(drmlt_ctx *ctx, uint32_t *out) {
+    if (!ctx || !out) return DRMLT_E_INVALID;
+    if (!ctx->seeded) return ctx->fail(DRMLT_E_STATE, "drmlt_seed_indices before drmlt_seed");
+    memcpy(out, ctx->seed_indices.data(), ctx->seed_indices.size() * sizeof(uint32_t));
+    return DRMLT_OK;
+}
 
 int drmlt_seed_pool(drmlt_ctx *ctx, uint64_t seed, uint32_t first_chain, uint32_t pool_chains, double *b_out) {
     if (!ctx) return DRMLT_E_INVALID;

@@ -62,6 +62,7 @@ struct drmlt_ctx {
     DevBuf d_prims, d_shade, d_bsdfs, d_emitters, d_bvh, d_lut, d_film, d_x, d_cur, d_stats, d_err, d_scratch, d_chain_i, d_importance, d_bd_verts, d_bd_lists, d_prims_flat;
     std::vector<DPrim> prims;
     std::vector<DShade> shade;
+    std::vector<uint32_t> seed_indices; // bootstrap sample index of every chain's seed (last drmlt_seed)
     size_t film_floats = 0; // W * H * 3 (the allocation carries FILM_PAD_ROWS more rows of zeros for the tiled reduce)
 
     uint32_t n_chains = 0, mutation_base = 0, chain_offset = 0;

@@ -265,6 +265,12 @@ int drmlt_kernel_time(drmlt_ctx *ctx, double *avg_ms, uint64_t *launches, int re
  * (test utility: equal-expectation reference for the MLT image). */
 int drmlt_render_pt(drmlt_ctx *ctx, uint32_t spp, uint64_t seed, float *out_rgb);
 
+/* Bootstrap inspection (test utilities for the seed-selection parity test): the luminance samples of
+ * generateSeeds' first loop (pathsampler.cpp:879-920) for bootstrap stream `stream`, and the sample indices the last
+ * drmlt_seed / drmlt_seed_pool picked for this context's chains (sorted, n_chains values). */
+int drmlt_bootstrap_luminances(drmlt_ctx *ctx, uint64_t seed, uint32_t stream, uint32_t n, float *out);
+int drmlt_seed_indices(drmlt_ctx *ctx, uint32_t *out);
+
 /* technique=bdpt: f(u) is a splat LIST (one sensor-side splat accumulating all
  * t >= 2 strategies + one light-image splat per t = 1 strategy,
  * pathsampler.cpp:357-361,514-519). A point is [sensor S | emitter E]

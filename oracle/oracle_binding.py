@@ -267,6 +267,17 @@ def toy_target(x, y):
     return lib().oracle_toy_target(x, y)
 
 
+def select_seeds(lum, seed, stream, n_seeds):
+    """generateSeeds' luminance-proportional picks (pathsampler.cpp:936-957) on the given luminance samples; sorted indices."""
+    lum = np.ascontiguousarray(lum, dtype=np.float32)
+    out = np.empty(n_seeds, dtype=np.uint32)
+    L = lib()
+    L.oracle_select_seeds.argtypes = [C.c_void_p, C.c_uint32, C.c_uint64, C.c_uint32, C.c_uint32, C.c_void_p]
+    L.oracle_select_seeds.restype = None
+    L.oracle_select_seeds(lum.ctypes.data, lum.size, seed, stream, n_seeds, out.ctypes.data)
+    return out
+
+
 def film_put(w, h, filt, param, xy, rgb):
     xy = np.ascontiguousarray(xy, dtype=np.float32)
     rgb = np.ascontiguousarray(rgb, dtype=np.float32)

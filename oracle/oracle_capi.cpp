@@ -460,6 +460,19 @@ int oracle_mmlt_eval(void *p, int depth, int lightImage, const float *uSensor, c
 
 // ---- unit-level entry points ------------------------------------------------
 
+// The selection half of PathSampler::generateSeeds (pathsampler.cpp:936-957) on caller-supplied luminance samples: the
+// bootstrap test hands in the DEVICE's luminances, so that the picks themselves (CDF, lower_bound, zero-mass skipping,
+// the TAG_SEEDSEL stream) are compared deterministically. out: nSeeds sample indices, sorted.
+void oracle_select_seeds(const float *lum, uint32_t n, uint64_t seed, uint32_t stream, uint32_t nSeeds, uint32_t *out) {
+    std::vector<PathSeed> temp, seeds;
+    for (uint32_t i = 0; i < n; ++i)
+        if (!std::isnan(lum[i]) && lum[i] != 0) temp.push_back(PathSeed{i, (double) lum[i], -1});
+    Random boot(seed, stream);
+    selectSeeds<double>(temp, boot, nSeeds, seeds);
+    std::sort(seeds.begin(), seeds.end(), [](const PathSeed &a, const PathSeed &b) { return a.sampleIndex < b.sampleIndex; });
+    for (uint32_t j = 0; j < nSeeds; ++j) out[j] = seeds[j].sampleIndex;
+}
+
 void oracle_philox(uint32_t k0, uint32_t k1, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t *out) {
     auto r = Philox::block(k0, k1, c0, c1, c2, c3);
     for (int i = 0; i < 4; ++i) out[i] = r[i];

@@ -154,6 +154,29 @@ template <typename F> struct ToyEvaluator {
     int height() const { return h; }
 };
 
+// Second half of generateSeeds (pathsampler.cpp:936-954): DiscreteDistribution over the non-zero luminance samples
+// (pmf.h:109-121,164-188) and `seedCount` luminance-proportional picks with replacement. Unsorted.
+template <typename F>
+inline void selectSeeds(const std::vector<PathSeed> &tempSeeds, Random &bootRandom, size_t seedCount, std::vector<PathSeed> &seeds) {
+    std::vector<F> cdf(tempSeeds.size() + 1);
+    cdf[0] = 0;
+    for (size_t i = 0; i < tempSeeds.size(); ++i) cdf[i + 1] = cdf[i] + (F) tempSeeds[i].luminance;
+    F norm = F(1) / cdf.back();
+    for (size_t i = 1; i < cdf.size(); ++i) cdf[i] *= norm;
+    cdf.back() = 1;
+    seeds.clear();
+    seeds.reserve(seedCount);
+    for (size_t j = 0; j < seedCount; ++j) {
+        bootRandom.seek(TAG_SEEDSEL, (uint32_t) j, 0);
+        F xi = (F) bootRandom.nextFloat();
+        auto entry = std::lower_bound(cdf.begin(), cdf.end(), xi);
+        size_t index = (size_t) std::max((ptrdiff_t) 0, (ptrdiff_t) (entry - cdf.begin()) - 1);
+        index = std::min(cdf.size() - 2, index);
+        while (cdf[index + 1] - cdf[index] == 0 && index < cdf.size() - 1) ++index;
+        seeds.push_back(tempSeeds.at(index));
+    }
+}
+
 // pathsampler.cpp:859-960. Returns b; seeds sorted by sample index.
 template <typename F, typename Eval>
 inline double generateSeeds(const Eval &eval, Random &bootRandom, size_t sampleCount, size_t seedCount,
@@ -180,24 +203,7 @@ inline double generateSeeds(const Eval &eval, Random &bootRandom, size_t sampleC
     }
     if (mmltMaxDepth > 0) mean *= (F) mmltMaxDepth; // "As we split the path by corresponding depth", :932-934
     if (mean == 0) return 0;
-    // DiscreteDistribution over the non-zero samples (pmf.h)
-    std::vector<F> cdf(tempSeeds.size() + 1);
-    cdf[0] = 0;
-    for (size_t i = 0; i < tempSeeds.size(); ++i) cdf[i + 1] = cdf[i] + (F) tempSeeds[i].luminance;
-    F norm = F(1) / cdf.back();
-    for (size_t i = 1; i < cdf.size(); ++i) cdf[i] *= norm;
-    cdf.back() = 1;
-    seeds.clear();
-    seeds.reserve(seedCount);
-    for (size_t j = 0; j < seedCount; ++j) {
-        bootRandom.seek(TAG_SEEDSEL, (uint32_t) j, 0);
-        F xi = (F) bootRandom.nextFloat();
-        auto entry = std::lower_bound(cdf.begin(), cdf.end(), xi);
-        size_t index = (size_t) std::max((ptrdiff_t) 0, (ptrdiff_t) (entry - cdf.begin()) - 1);
-        index = std::min(cdf.size() - 2, index);
-        while (cdf[index + 1] - cdf[index] == 0 && index < cdf.size() - 1) ++index;
-        seeds.push_back(tempSeeds.at(index));
-    }
+    selectSeeds<F>(tempSeeds, bootRandom, seedCount, seeds);
     std::sort(seeds.begin(), seeds.end(), [](const PathSeed &a, const PathSeed &b) { return a.sampleIndex < b.sampleIndex; });
     return (double) mean;
 }

@@ -111,19 +111,39 @@ def test_bootstrap_and_seed_replay(pkg, ob, native_lib):
     bg, bo = ctx.seed(0x5EED), orc.seed(0x5EED)       # seed() raises DRMLT_E_REPLAY on a luminance mismatch
     assert bg == pytest.approx(bo, rel=2e-4)
     (cg, ug), (co, uo) = ctx.chain_state(34), orc.chain_state(34)
-    # chain state = the raw uniforms of its bootstrap sample. fp32-vs-fp64 differences in ~0.1 % of the
-    # bootstrap luminances shift the resampling CDF, so compare the two seed SETS, not positions
+    # (1) the picks, deterministically: the oracle's resampler (the second half of generateSeeds, pathsampler.cpp:936-957)
+    # run on the DEVICE's own bootstrap luminances must pick exactly the device's seeds -- same CDF arithmetic, same
+    # lower_bound / zero-mass handling, same TAG_SEEDSEL stream. An off-by-one or a wrong stream cannot pass this.
+    n_boot = 10 * 4096                                 # max(luminanceSamples = 20000, 10 x workUnits), drmlt.cpp:454-466
+    lum_dev = ctx.bootstrap_luminances(0x5EED, 0, n_boot)
+    picks = ob.select_seeds(lum_dev, 0x5EED, 0, 4096)
+    assert np.array_equal(picks, ctx.seed_indices())
+    assert np.array_equal(cg["luminance"] > 0, np.ones(4096, bool)) and np.all(lum_dev[picks] > 0)
+    # (2) device (fp32) and oracle (fp64) luminances agree to ~1e-6, except for a few samples per thousand that sit on a
+    # discontinuity of f (another surface hit, another roulette outcome) and differ by O(their own size). Each of those
+    # moves the CDF under every later pick by a sizeable part of one sample's mass -- about one CDF slot -- so the two seed
+    # SETS differ widely (measured 0.67 overlap) although nothing is wrong. Shown, not assumed: give the oracle's luminance
+    # array the device's values for just those samples and the picks coincide again.
+    lum_orc = orc.bootstrap_lum(0x5EED, 0, n_boot)
+    rel = np.abs(lum_dev - lum_orc) / np.maximum(np.maximum(lum_orc, lum_dev), 1e-6)
+    jumps = rel > 1e-3
+    assert np.quantile(rel, 0.99) < 1e-4 and 0 < jumps.sum() < 3e-3 * n_boot, (np.quantile(rel, 0.99), jumps.sum())
+    picks_orc = ob.select_seeds(lum_orc, 0x5EED, 0, 4096)
+    overlap = np.intersect1d(picks, picks_orc).size / np.unique(picks_orc).size
+    assert overlap > 0.5, overlap
+    picks_fixed = ob.select_seeds(np.where(jumps, lum_dev, lum_orc), 0x5EED, 0, 4096)
+    overlap_fixed = np.intersect1d(picks, picks_fixed).size / np.unique(picks_fixed).size
+    assert overlap_fixed >= 0.95, (overlap, overlap_fixed, int(jumps.sum()))
     keys_g = {r.tobytes() for r in ug}
     keys_o = {r.tobytes() for r in uo}
-    assert len(keys_g & keys_o) / len(keys_o) > 0.5   # most picks coincide even though the CDF is perturbed
+    assert len(keys_g & keys_o) / len(keys_o) > 0.5    # the oracle's own seeding (its own luminances): same effect
     # replay: the stored current state is f(u) of the stored vector (drmlt_proc.cpp:481,509-512)
     chk = orc.eval_paths(np.pad(ug, ((0, 0), (0, 16))))
     ok = np.abs(chk["luminance"] - cg["luminance"]) <= 1e-3 * cg["luminance"]
     assert ok.mean() > 0.995
     assert np.allclose(chk["x"][ok], cg["x"][ok], atol=1e-3)
     # luminance-proportional resampling (pathsampler.cpp:946-954): E[lum of a seed] = sum(l^2) / sum(l)
-    lum_all = orc.bootstrap_lum(0x5EED, 0, 40960)
-    assert cg["luminance"].mean() == pytest.approx((lum_all ** 2).sum() / lum_all.sum(), rel=0.06)
+    assert cg["luminance"].mean() == pytest.approx((lum_orc ** 2).sum() / lum_orc.sum(), rel=0.06)
     st = ctx.stats()
     assert st.n_chains == 4096 and st.max_dim == 50
 
@@ -231,7 +251,7 @@ def test_mlt_image_is_unbiased_against_device_path_tracing(pkg, ob, native_lib):
     orc.seed(9)
     orc.run(32 * 32 * spp, 16)
     e_gpu, e_cpu = rel_mse(img, ref), rel_mse(orc.develop(), ref)
-    assert e_gpu < 1.25 * e_cpu + 2e-4, (e_gpu, e_cpu)
+    assert abs(e_gpu - e_cpu) < 0.10 * e_cpu, (e_gpu, e_cpu)   # within 10 % at equal budget
     assert e_gpu < 1e-2
 
 
