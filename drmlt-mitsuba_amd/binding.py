@@ -198,21 +198,26 @@ class Context:
         self._chk(self.L.drmlt_eval_paths(self.h, u.ctypes.data, n, dim, out))
         return np.frombuffer(out, dtype=SPLAT_DTYPE).copy()
 
-    def eval_lists_bdpt(self, u_sensor, u_emitter):
-        """technique=bdpt: rows [lum, hasMain, px, py, r, g, b, nMore, nDims, nRays, nMore x (px, py, r, g, b)]."""
-        st = self.stats()
-        S = E = None
+    def eval_lists_bdpt(self, u_sensor, u_emitter, u_direct=None):
+        """technique=bdpt: rows [lum, hasMain, px, py, r, g, b, nMore, nDims, nRays, nMore x (px, py, r, g, b)].
+        Points are [sensor S | emitter E | direct Dd]; u_direct is needed with directSampling=true (the default)."""
         rr = self.cfg.max_depth + 1 - max(self.cfg.rr_depth, 0)
         S = 2 * (self.cfg.max_depth + 1) + max(rr, 0); S += S & 1
         E = 2 * self.cfg.max_depth + max(rr - 1, 0); E += E & 1
+        Dd = 0 if self.cfg.no_direct_sampling else 2 * (2 * self.cfg.max_depth - 1)
         us, ue = np.asarray(u_sensor, dtype=np.float32), np.asarray(u_emitter, dtype=np.float32)
         n = us.shape[0]
-        u = np.zeros((n, S + E), dtype=np.float32)
+        u = np.zeros((n, S + E + Dd), dtype=np.float32)
         u[:, :min(S, us.shape[1])] = us[:, :S]
         u[:, S:S + min(E, ue.shape[1])] = ue[:, :E]
+        if Dd:
+            if u_direct is None:
+                raise ValueError("directSampling=true: the direct sampler's components are part of the point")
+            ud = np.asarray(u_direct, dtype=np.float32)
+            u[:, S + E:S + E + min(Dd, ud.shape[1])] = ud[:, :Dd]
         stride = 10 + 5 * (self.cfg.max_depth + 1)
         out = np.zeros((n, stride), dtype=np.float32)
-        self._chk(self.L.drmlt_eval_lists(self.h, u.ctypes.data, n, S + E, out.ctypes.data, stride))
+        self._chk(self.L.drmlt_eval_lists(self.h, u.ctypes.data, n, S + E + Dd, out.ctypes.data, stride))
         return out
 
     def eval_paths_mmlt(self, depth, u_sensor, u_emitter, u_direct):

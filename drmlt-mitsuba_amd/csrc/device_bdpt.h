@@ -1,5 +1,6 @@
-// technique=bdpt on the device: PathSampler::sampleSplats, EBidirectional branch, with directSampling = false
-// (src/libbidir/pathsampler.cpp:321-527). Both random walks (with russian roulette from rrDepth) are stored, then
+// technique=bdpt on the device: PathSampler::sampleSplats, EBidirectional branch (src/libbidir/pathsampler.cpp:321-527),
+// with directSampling = true (P.bd_Dd != 0: the s = 1 / t = 1 strategies of :424-452 and the sampleDirect terms of
+// Path::miWeight, path.cpp:799-824,936-1012) or false. Both random walks (with russian roulette from rrDepth) are stored, then
 // every (s, t) pair is connected and weighted with Path::miWeight; the result is a splat LIST: the sensor-side pixel
 // accumulates all t >= 2 strategies, every t = 1 strategy adds a light-image splat.
 //
@@ -30,6 +31,9 @@ __host__ __device__ inline int bdpt_dims_emitter(int max_depth, int rr_depth) {
     int d = 2 * max_depth + (rr > 1 ? rr - 1 : 0);
     return d + (d & 1);
 }
+// components of the direct sampler with directSampling = true: two per s = 1 (t = 2 .. maxDepth) and t = 1 (s = 2 .. maxDepth)
+// connection -- the size at which no chain can overrun it (the reference's maxDepth, pssmlt_utils.h:75, is too small)
+__host__ __device__ inline int bdpt_dims_direct(int max_depth) { return 2 * (2 * max_depth - 1); }
 __host__ __device__ inline int bdpt_max_dim(int max_depth, int rr_depth) { // pssmlt_utils.h:69-75
     int d = (max_depth + 2) * (2 + (rr_depth < max_depth ? 1 : 0));
     return d + (d & 1);
@@ -37,7 +41,7 @@ __host__ __device__ inline int bdpt_max_dim(int max_depth, int rr_depth) { // ps
 
 struct BdptResult {
     float lum;
-    uint32_t nrays, n_sensor, n_emitter;
+    uint32_t nrays, n_sensor, n_emitter, n_direct;
     int n_more;
     bool has_main;
 };
@@ -71,6 +75,29 @@ struct BdptStore {
     }
 };
 
+// Scene::pdfEmitterDirect under the AREA measure -- what PathVertex::evalPdfDirect(sample, EImportance, EArea) asks for
+// in Path::miWeight (vertex.cpp:1355-1382, scene.cpp:1057-1060, area.cpp:180-189, shape.cpp:118-127, sphere.cpp:356-385):
+// the density with which direct sampling from `ref` produces the emitter point (sp, sn)
+template <class TablesT>
+DEV float emitter_direct_pdf_area(const TablesT &T, f3 ref_p, f3 ref_n, bool refn_zero, f3 sp, f3 sn, int emitter) {
+    const DEmitter E = T.emitter(emitter);
+    const DShade L = T.shade(E.prim);
+    f3 d = sp - ref_p;
+    const float dist2 = dot3(d, d);
+    d = d * rsqrtf(dist2);
+    float pdf = 0.f;
+    const float dr = refn_zero ? 0.f : dot3(d, ref_n), dl = dot3(d, sn);
+    if (dr >= 0.f && dl < 0.f) {
+        pdf = L.inv_area;
+        if ((L.bsdf >> 24) == PRIM_SPHERE) {
+            const f3 rc = ld3(L.origin) - ref_p;
+            const float sinAlpha = L.eu[0] * rsqrtf(dot3(rc, rc));
+            if (sinAlpha < 1.f - EPSILON_F) pdf = 0.15915494309189535f / (1.f - sqrtf(fmaxf(0.f, 1.f - sinAlpha * sinAlpha))) * fabsf(dl) / dist2;
+        }
+    }
+    return pdf * (E.cdf_hi - E.cdf_lo);
+}
+
 // `list`: this lane's column of the target splat list (row r at list[r * n])
 template <class TablesT>
 DEV void eval_bdpt(const DParams &P, const TablesT &T, MSampler &smp, uint32_t chain, uint32_t mis_row, float *list, BdptResult &R) {
@@ -81,7 +108,7 @@ DEV void eval_bdpt(const DParams &P, const TablesT &T, MSampler &smp, uint32_t c
     auto mis = [&](int group, int slot) -> float & { return lds_x[(mis_row + (uint32_t) group * NVS + (uint32_t) slot) * 64u + lane]; };
     auto lrow = [&](int r) -> float & { return list[(size_t) r * n]; };
 
-    R.lum = 0.f; R.nrays = 0u; R.n_sensor = R.n_emitter = 0u; R.n_more = 0; R.has_main = false;
+    R.lum = 0.f; R.nrays = 0u; R.n_sensor = R.n_emitter = R.n_direct = 0u; R.n_more = 0; R.has_main = false;
     smp.reset_caches();
     const bool stamps = (P.debug & 128) != 0; // diagnostic: per-wave cycles of the walks / the pair loop -> stats[16], [17]
     const unsigned long long st0 = stamps ? __builtin_amdgcn_s_memtime() : 0ull;
@@ -275,6 +302,15 @@ DEV void eval_bdpt(const DParams &P, const TablesT &T, MSampler &smp, uint32_t c
     int n_more = 0;
 
     auto flags = [&](int slot) { return __float_as_uint(mis(MF_FLAGS, slot)); };
+    auto vpos = [&](int slot) { return mk3(W.f(BV_P, slot), W.f(BV_P + 1, slot), W.f(BV_P + 2, slot)); };
+    auto vnrm = [&](int slot) { return mk3(W.f(BV_N, slot), W.f(BV_N + 1, slot), W.f(BV_N + 2, slot)); };
+    auto vrefn_zero = [&](int slot) { return T.bsdf(__float_as_int(W.f(BV_IDS, slot)) >> 4).type == 1; }; // records.inl:160-164
+    const bool direct = P.bd_Dd != 0;
+    uint32_t kd = 0u;        // components of the direct sampler consumed so far
+    float re_walk = 0.f;     // ratioEmitterDirect of the emitter walk's own vertices 1 and 2 (every s >= 2 strategy)
+    if (direct && nE >= 3)
+        re_walk = emitter_direct_pdf_area(T, vpos(1), vnrm(1), vrefn_zero(1), vpos(0), vnrm(0), __float_as_int(W.f(BV_EMIT, 0))) / em0_fwd;
+    float em0 = em0_fwd;     // pImp[1]; the s = 1 direct strategy swaps in its own emitter sample
 #pragma nounroll
     for (int s = nE - 1; s >= 0; --s) {
         BVert vs;
@@ -293,6 +329,8 @@ DEV void eval_bdpt(const DParams &P, const TablesT &T, MSampler &smp, uint32_t c
             f3 value;
             float geo = 1.f;
             float pc_i1, pc_i2, pc_r0 = 0.f, pc_r1 = 0.f;
+            float re_s1 = 0.f;
+            em0 = em0_fwd;
             if (s == 0) {
                 if (vt.kind != BK_SURF || vt.emitter < 0) continue;
                 const DEmitter E = T.emitter(vt.emitter);
@@ -304,7 +342,65 @@ DEV void eval_bdpt(const DParams &P, const TablesT &T, MSampler &smp, uint32_t c
                 if (is_zero3(value)) continue;
                 pc_i1 = T.shade(vt.shade).inv_area * (E.cdf_hi - E.cdf_lo);
                 pc_i2 = (dp < 0.f ? 0.f : INV_PI_F * dp) * vt.e_cos / vt.e_len2;
+            } else if (direct && s == 1 && t > 1) {
+                // s = 1: the emitter vertex is drawn by direct sampling from vt (:424-437, vertex.cpp:1285-1346,
+                // scene.cpp:879-904 without the visibility test) and replaces the walk's vertex 1 in miWeight (:486-503)
+                if (vt.degenerate) continue;
+                smp.select(SEG_DIRECT);
+                float sx = smp.next(kd);
+                const float sy = smp.next(kd + 1u);
+                kd += 2u;
+                const DBsdf Bt = T.bsdf(vt.bsdf);
+                int ei = 0;
+                for (int q = 1; q < P.n_emitters; ++q)
+                    if (T.emitter_cdf_lo(q) < sx) ei = q;
+                const DEmitter E = T.emitter(ei);
+                const float emPdf = E.cdf_hi - E.cdf_lo;
+                sx = (sx - E.cdf_lo) / emPdf;
+                const DShade L = T.shade(E.prim);
+                f3 ln = ld3(L.n), dd;
+                float dist, pdf;
+                if ((L.bsdf >> 24) == PRIM_SPHERE) {
+                    sphere_sample_direct(ld3(L.origin), L.eu[0], L.inv_area, vt.p, sx, sy, dd, dist, ln, pdf);
+                } else {
+                    f3 lp;
+                    if ((L.bsdf >> 24) == PRIM_RECTANGLE) lp = fma3(ld3(L.eu), sx, fma3(ld3(L.ev), sy, ld3(L.origin)));
+                    else { const float a = sqrtf(fmaxf(0.f, 1.f - sx)); lp = fma3(ld3(L.eu), 1.f - a, fma3(ld3(L.ev), a * sy, ld3(L.origin))); }
+                    const f3 dv = lp - vt.p;
+                    const float dist2 = dot3(dv, dv);
+                    dist = sqrtf(dist2);
+                    dd = dv * (1.f / dist);
+                    const float c = dot3(dd, ln);
+                    pdf = c != 0.f ? L.inv_area * dist2 / fabsf(c) : 0.f;
+                }
+                const float dln = dot3(dd, ln);
+                const float dr = Bt.type == 1 ? 0.f : dot3(dd, vt.n);
+                if (!(dr >= 0.f && dln < 0.f && pdf != 0.f)) continue; // AreaLight::sampleDirect, area.cpp:164-178
+                if (!(dist > 0.f)) continue;
+                value = thr_t * (ld3(E.radiance) * (1.f / (pdf * emPdf))) * vert_eval(P, Bt, vt, dd, false);
+                if (is_zero3(value)) continue;
+                const Hit h = trace(P, vt.p, dd, ray_eps_closest(vt.p), dist * (1.f - SHADOW_EPSILON_F), true);
+                R.nrays++;
+                if (h.prim >= 0) continue;
+                const float len2 = dist * dist;
+                const float cs = fabsf(dln), ct = fabsf(dot3(vt.n, dd));
+                geo = ct; // ETransmittance | ECosineRad of the direct connection: the cosine at vt (:441-446)
+                const f3 wot = to_local(vt, dd);
+                em0 = L.inv_area * emPdf;
+                pc_i1 = INV_PI_F * cs * ct / len2;
+                pc_r0 = vert_pdf_sa(P, Bt, vt, vt.wi, wot, dd) * cs / len2;
+                pc_i2 = bsdf_pdf_sa(Bt, wot, vt.wi) * ((wot.z == 0.f || vt.wi.z == 0.f) ? 0.f : 1.f) * vt.e_cos / vt.e_len2;
+                pc_r1 = 1.f;
+                re_s1 = emitter_direct_pdf_area(T, vt.p, vt.n, Bt.type == 1, fma3(dd, dist, vt.p), ln, ei) / em0;
             } else {
+                // t = 1 with direct sampling: a pinhole's sampleDirect returns the point the sensor subpath's vertex 1 already is
+                // (perspective.cpp:386-420) and the same value term by term; what remains is that it consumes two components
+                if (direct && t == 1 && s > 1) {
+                    if (vs.degenerate) continue;
+                    smp.select(SEG_DIRECT);
+                    (void) smp.next(kd); (void) smp.next(kd + 1u);
+                    kd += 2u;
+                }
                 if (vs.degenerate || vt.degenerate) continue;
                 f3 dc = vt.p - vs.p;
                 const float len2 = dot3(dc, dc);
@@ -339,7 +435,7 @@ DEV void eval_bdpt(const DParams &P, const TablesT &T, MSampler &smp, uint32_t c
             auto pImp = [&](int j) -> float {
                 float v;
                 if (j == 0) v = 1.f;
-                else if (j <= s) v = j == 1 ? em0_fwd : mis(MF_FWD, j - 2);
+                else if (j <= s) v = j == 1 ? em0 : mis(MF_FWD, j - 2);
                 else if (j == s + 1) v = pc_i1;
                 else if (j == s + 2) v = pc_i2;
                 else v = mis(MF_REV, ME + (k - j + 1) - 1);
@@ -358,16 +454,28 @@ DEV void eval_bdpt(const DParams &P, const TablesT &T, MSampler &smp, uint32_t c
                 if (i <= k - 1 && i >= 3 && j != s && conn(i) && !conn(j)) v *= ginv(j);
                 return v;
             };
-            double weight = 1.0, pdf = 1.0;
+            // sampleDirect terms (path.cpp:799-824,936-965): the emitter's direct-sampling density relative to its area density
+            // at position 1. The sensor's ratio is 1: a pinhole's direct density is discrete, its position density 1.
+            const bool sd = direct && k > 3;
+            float re = 0.f;
+            double initial = 1.0;
+            if (sd) {
+                if (s == 1) { re = re_s1; initial = 1.0 / (double) re; }
+                else if (s == 0) { if (conn(2)) re = emitter_direct_pdf_area(T, vpos(ME + t - 2), vnrm(ME + t - 2), vrefn_zero(ME + t - 2), vt.p, vt.n, vt.emitter) / pc_i1; }
+                else if (conn(2)) re = re_walk;
+            }
+            double weight = 1.0, pdf = initial;
             for (int i = s + 1; i < k; ++i) {
                 double next = pdf * (double) (pImp(i) / pRad(i)); // ratio in fp32, product in fp64 (see device_bidir.h)
-                if (conn(i) && conn(i + 1) && (P.light_image || k - i - 1 > 1)) weight += next * next;
+                const double v = (sd && i == 1) ? next * (double) re : next;
+                if (conn(i) && conn(i + 1) && (P.light_image || k - i - 1 > 1)) weight += v * v;
                 pdf = next;
             }
-            pdf = 1.0;
+            pdf = initial;
             for (int i = s - 1; i >= 0; --i) {
                 double next = pdf * (double) (pRad(i + 1) / pImp(i + 1));
-                if (conn(i) && conn(i + 1) && (P.light_image || k - i - 1 > 1)) weight += next * next;
+                const double v = (sd && i == 1) ? next * (double) re : next;
+                if (conn(i) && conn(i + 1) && (P.light_image || k - i - 1 > 1)) weight += v * v;
                 pdf = next;
             }
             value = value * (geo / (float) weight);
@@ -398,4 +506,5 @@ DEV void eval_bdpt(const DParams &P, const TablesT &T, MSampler &smp, uint32_t c
     lrow(BL_MAIN + 2) = main_v.x; lrow(BL_MAIN + 3) = main_v.y; lrow(BL_MAIN + 4) = main_v.z;
     R.lum = total_lum;
     R.n_more = n_more;
+    R.n_direct = kd;
 }

@@ -41,6 +41,7 @@ struct MSampler {
     uint32_t S, E;
     uint32_t base_e, base_d; // draw bases of the emitter / direct segments
     bool emitter_ident2;     // fixEmitterPath and the current path is not pure light tracing (drmlt_proc.cpp:566-573)
+    bool direct_ident;       // mmlt: the direct sampler's stages are identities (drmlt_proc.cpp:133-135); bdpt: an ordinary third sampler
     // active segment
     int seg;
     uint32_t x_off, draw_base;
@@ -75,11 +76,11 @@ struct MSampler {
         return pick4(b2, idx & 3u);
     }
     DEV float x(uint32_t k) const { return lds_x[(x_off + k) * 64u + lane]; }
-    DEV bool ident2() const { return seg == SEG_DIRECT || (seg == SEG_EMITTER && emitter_ident2); }
+    DEV bool ident2() const { return (seg == SEG_DIRECT && direct_ident) || (seg == SEG_EMITTER && emitter_ident2); }
 
     DEV float y_raw(uint32_t k) {
         if (large) return u_s1(draw_base + k);             // the uniform branch comes first (drmlt_sampler.cpp:319-321)
-        if (seg == SEG_DIRECT) return x(k);                // identity stages (setStagesToIdentity)
+        if (seg == SEG_DIRECT && direct_ident) return x(k); // identity stages (setStagesToIdentity)
         if (type != 2) return x(k) + kelemen_sample(u_s1(draw_base + k), KELEMEN_S2);
         ensure_pair(k & ~1u, false);
         return (k & 1u) ? pair_y1 : pair_y0;

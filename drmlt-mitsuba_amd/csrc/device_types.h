@@ -118,6 +118,7 @@ struct DParams {
     int32_t fix_emitter_path; // "fixEmitterPath"
     int32_t mmlt_S, mmlt_E;   // state rows of the sensor / emitter segments: 2 (maxDepth + 1), 2 maxDepth
     int32_t mmlt_dmax;        // findMaxDimensions of the deepest chain: draw bases 2 dmax (emitter), 4 dmax (direct)
+    int32_t bd_Dd;            // technique=bdpt, directSampling=true: state rows of the direct sampler, 2 (2 maxDepth - 1); else 0
     int32_t *chain_depth;     // [n] path depth of each chain (fixed by its seed)
     int32_t *cur_t;           // [n] sensor-subpath length t of the current state (light tracing: t == 1)
     const float *importance;  // [H][W] two-stage MLT luminance image, or NULL (pathsampler.cpp:1001-1020)

@@ -301,10 +301,6 @@ drmlt_ctx *drmlt_create(const drmlt_config *cfg, const drmlt_scene *scene, int d
     if (cfg->fix_emitter_path && cfg->technique != DRMLT_TECH_MMLT) return bail(nullptr, "Impossible to use fixEmitterPath without MMLT");
     if (cfg->scale_second > 1.0f) return bail(nullptr, "scaleSecond is bigger than the first stage");
     const bool mmlt = cfg->technique == DRMLT_TECH_MMLT, bdpt = cfg->technique == DRMLT_TECH_BDPT;
-    // With directSampling=true (the reference's default) its bdpt chains overrun the direct sampler: it is given maxDepth
-    // components (pssmlt_utils.h:75) while every s = 1 / t = 1 connection draws two (pathsampler.cpp:424-452), and
-    // primarySample raises "Exceeded maximum dimension" (drmlt_sampler.cpp:256-258). Only the variant that runs is built.
-    if (bdpt && !cfg->no_direct_sampling) return bail(nullptr, "technique=bdpt needs directSampling=false (no_direct_sampling=1)");
     if (bdpt && cfg->timid_after_large) return bail(nullptr, "timidAfterLarge is not supported for technique=bdpt");
     if (bdpt && cfg->max_depth > 16) return bail(nullptr, "technique=bdpt: maxDepth above 16 is not supported on the device");
     if (cfg->max_depth <= 0) return bail(nullptr, "technique=path needs a finite maxDepth (pssmlt_utils.h:63)");
@@ -432,20 +428,24 @@ drmlt_ctx *drmlt_create(const drmlt_config *cfg, const drmlt_scene *scene, int d
     P.kelemen_weights = cfg->kelemen_style_weights; P.kelemen_mutation = cfg->kelemen_style_mutation;
     P.pss_sigma = cfg->sigma; P.luminance_b = 1.f;
     P.technique = cfg->technique; P.light_image = cfg->no_light_image ? 0 : 1; P.fix_emitter_path = cfg->fix_emitter_path;
-    P.mmlt_S = P.mmlt_E = P.mmlt_dmax = 0;
+    P.mmlt_S = P.mmlt_E = P.mmlt_dmax = P.bd_Dd = 0;
     if (mmlt) { // PSS layout of a chain: [sensor S | emitter E | direct] (device_bidir.h)
         P.mmlt_S = 2 * (cfg->max_depth + 1); P.mmlt_E = 2 * cfg->max_depth;
         P.mmlt_dmax = (cfg->max_depth + 2) * 3; P.mmlt_dmax += P.mmlt_dmax & 1; // pssmlt_utils.h:58-63
         P.max_dim = 2 * P.mmlt_dmax + 1;
         P.eff_dim = P.mmlt_S + P.mmlt_E + 1;
     }
-    if (bdpt) { // [sensor S | emitter E]: what the two walks can consume (device_bdpt.h); draw bases as for mmlt
+    if (bdpt) { // [sensor S | emitter E | direct Dd]: what the two walks and the direct strategies can consume (device_bdpt.h)
         const int rr = cfg->max_depth + 1 - (cfg->rr_depth > 0 ? cfg->rr_depth : 0);
         P.mmlt_S = 2 * (cfg->max_depth + 1) + (rr > 0 ? rr : 0); P.mmlt_S += P.mmlt_S & 1;
         P.mmlt_E = 2 * cfg->max_depth + (rr > 1 ? rr - 1 : 0); P.mmlt_E += P.mmlt_E & 1;
         P.mmlt_dmax = (cfg->max_depth + 2) * (2 + (cfg->rr_depth < cfg->max_depth ? 1 : 0)); P.mmlt_dmax += P.mmlt_dmax & 1; // pssmlt_utils.h:69-75
-        P.max_dim = 2 * P.mmlt_dmax;
-        P.eff_dim = P.mmlt_S + P.mmlt_E;
+        // directSampling=true (the reference's default): every s = 1 / t = 1 connection draws two components of the direct
+        // sampler (pathsampler.cpp:424-452, vertex.cpp:1304-1305), a sample makes up to maxDepth + (maxDepth - 1) of them. The
+        // reference sizes that sampler maxDepth (pssmlt_utils.h:75) and reads past it; here it holds what can be consumed.
+        P.bd_Dd = cfg->no_direct_sampling ? 0 : 2 * (2 * cfg->max_depth - 1); // bdpt_dims_direct, device_bdpt.h
+        P.max_dim = 2 * P.mmlt_dmax + P.bd_Dd;
+        P.eff_dim = P.mmlt_S + P.mmlt_E + P.bd_Dd;
     }
 
     ctx->film_floats = (size_t) cam.width * cam.height * 3;

@@ -5,12 +5,12 @@
 //   k_mutate_bdpt       DRMLTRenderer::process / processMixture over sampleSplats(EBidirectional) (drmlt_proc.cpp:161-380,518-770)
 //   k_eval_lists_bdpt   sampleSplats(EBidirectional) on caller-supplied PSS points, full splat lists
 //
-// LDS rows ([row][lane]): chain state [0, NX), NX = S + E (bdpt_dims_sensor / bdpt_dims_emitter), then the four row
-// groups of eval_bdpt. Splat lists live in HBM (`bd_lists`, slot 0 = current state), unnormalised next to their luminance.
+// LDS rows ([row][lane]): chain state [0, NX), NX = S + E + Dd (bdpt_dims_sensor / _emitter / _direct; Dd = 0 with
+// directSampling = false), then the four row groups of eval_bdpt. Splat lists live in HBM (`bd_lists`, slot 0 = current state), unnormalised next to their luminance.
 #include "device_bdpt.h"
 #include "kernel_common.h"
 
-DEV uint32_t bdpt_nx(const DParams &P) { return (uint32_t) (P.mmlt_S + P.mmlt_E); }
+DEV uint32_t bdpt_nx(const DParams &P) { return (uint32_t) (P.mmlt_S + P.mmlt_E + P.bd_Dd); }
 
 DEV void bsampler_setup(MSampler &smp, const DParams &P, uint32_t lane) {
     smp.key0 = P.key0; smp.key1 = P.key1;
@@ -18,7 +18,7 @@ DEV void bsampler_setup(MSampler &smp, const DParams &P, uint32_t lane) {
     smp.lane = lane; smp.arr = nullptr;
     smp.S = (uint32_t) P.mmlt_S; smp.E = (uint32_t) P.mmlt_E;
     smp.base_e = 2u * (uint32_t) P.mmlt_dmax; smp.base_d = 4u * (uint32_t) P.mmlt_dmax;
-    smp.emitter_ident2 = false;
+    smp.emitter_ident2 = false; smp.direct_ident = false;
     smp.reset_caches();
     smp.select(SEG_SENSOR);
 }
@@ -108,12 +108,14 @@ __global__ void __launch_bounds__(CHAIN_BLOCK) k_init_chains_bdpt(DParams P, con
     if (!(fabsf((R.lum - seed_lum[c]) / seed_lum[c]) <= EPSILON_F)) atomicExch(P.error_flag, 1); // drmlt_proc.cpp:509-512
     const float lum = list_finalize(P, cur, R.lum);
     P.cur_lum[c] = lum;
-    // replayed stream, in call order: emitter (n_e), sensor (n_s); fillReplay tops up sensor then emitter to D
-    const uint32_t D = (uint32_t) P.mmlt_dmax, ne = R.n_emitter;
-    const uint32_t S = (uint32_t) P.mmlt_S, E = (uint32_t) P.mmlt_E;
+    // replayed stream, in call order: emitter (n_e), sensor (n_s), direct (n_d); fillReplay then tops up the sensor and
+    // the emitter sampler to D and the direct sampler to Dd, in that order (drmlt_proc.cpp:506-509)
+    const uint32_t D = (uint32_t) P.mmlt_dmax, ne = R.n_emitter, ns = R.n_sensor, nd = R.n_direct;
+    const uint32_t S = (uint32_t) P.mmlt_S, E = (uint32_t) P.mmlt_E, Dd = (uint32_t) P.bd_Dd;
     smp.b1_idx = 0xffffffffu;
-    for (uint32_t k = 0; k < S; ++k) P.x[(size_t) k * P.n_chains + c] = smp.u_boot(ne + k); // k < ns: replayed; else top-up
-    for (uint32_t k = 0; k < E; ++k) P.x[(size_t) (S + k) * P.n_chains + c] = smp.u_boot(k < ne ? k : D + k);
+    for (uint32_t k = 0; k < S; ++k) P.x[(size_t) k * P.n_chains + c] = smp.u_boot(k < ns ? ne + k : ne + nd + k);
+    for (uint32_t k = 0; k < E; ++k) P.x[(size_t) (S + k) * P.n_chains + c] = smp.u_boot(k < ne ? k : nd + D + k);
+    for (uint32_t k = 0; k < Dd; ++k) P.x[(size_t) (S + E + k) * P.n_chains + c] = smp.u_boot(k < nd ? ne + ns + k : 2u * D + k);
 }
 
 __global__ void __launch_bounds__(CHAIN_BLOCK) k_mutate_bdpt(DParams P, uint32_t n_mut, uint32_t mut_base) {
@@ -142,7 +144,7 @@ __global__ void __launch_bounds__(CHAIN_BLOCK) k_mutate_bdpt(DParams P, uint32_t
         smp.major = m;
         smp.large = large;
         float y_lum = 0.f, z_lum = 0.f;
-        uint32_t ns1 = 0, ne1 = 0, ns2 = 0, ne2 = 0;
+        uint32_t ns1 = 0, ne1 = 0, nd1 = 0, ns2 = 0, ne2 = 0, nd2 = 0;
         float a1 = 0.f, a2 = 0.f;
         bool acc1 = false, acc2 = false, doSecond = false;
 
@@ -157,7 +159,7 @@ __global__ void __launch_bounds__(CHAIN_BLOCK) k_mutate_bdpt(DParams P, uint32_t
             ct.rays += R.nrays;
             const float lum = list_finalize(P, target, R.lum);
             if (stage == 0) {
-                y_lum = lum; ns1 = R.n_sensor; ne1 = R.n_emitter;
+                y_lum = lum; ns1 = R.n_sensor; ne1 = R.n_emitter; nd1 = R.n_direct;
                 if (!(mix ? lum_invalid_mix(y_lum) : lum_invalid(y_lum))) {
                     a1 = fminf(1.f, y_lum / cur_lum);
                     acc1 = a1 >= 1.f || u32_to_unit(coins.y) < a1;
@@ -166,7 +168,7 @@ __global__ void __launch_bounds__(CHAIN_BLOCK) k_mutate_bdpt(DParams P, uint32_t
                 else doSecond = !large && u32_to_unit(coins.w) < 0.5f;
                 if (!doSecond) break;
             } else if (stage == 1) {
-                z_lum = lum; ns2 = R.n_sensor; ne2 = R.n_emitter;
+                z_lum = lum; ns2 = R.n_sensor; ne2 = R.n_emitter; nd2 = R.n_direct;
                 if (mix) {
                     acc1 = false;
                     a1 = 0.f;
@@ -186,8 +188,8 @@ __global__ void __launch_bounds__(CHAIN_BLOCK) k_mutate_bdpt(DParams P, uint32_t
                     float aRev = fminf(1.f, y_lum / z_lum);
                     if (!(aRev >= 1.f)) {
                         float num = 0.f, den = 0.f;
-                        for (int sg = 0; sg < 2; ++sg) {
-                            const uint32_t nmax = sg == 0 ? max(ns1, ns2) : max(ne1, ne2);
+                        for (int sg = 0; sg < 3; ++sg) {
+                            const uint32_t nmax = sg == 0 ? max(ns1, ns2) : (sg == 1 ? max(ne1, ne2) : max(nd1, nd2));
                             const uint32_t dimStage = nmax > 0u ? nmax - 1u : 0u;
                             smp.select(sg);
                             for (uint32_t i = 0; i < dimStage; ++i) {
@@ -246,9 +248,9 @@ __global__ void __launch_bounds__(CHAIN_BLOCK) k_mutate_bdpt(DParams P, uint32_t
         }
 
         if (acc1 || acc2) {
-            for (int sg = 0; sg < 2; ++sg) {
+            for (int sg = 0; sg < 3; ++sg) { // every component of the three samplers (DRMLTSampler::accept, drmlt_sampler.cpp:189-199)
                 smp.select(sg);
-                const uint32_t nk = sg == 0 ? smp.S : smp.E;
+                const uint32_t nk = sg == 0 ? smp.S : (sg == 1 ? smp.E : (uint32_t) P.bd_Dd);
                 for (uint32_t k = 0; k < nk; ++k) {
                     const float v = wrap01(acc1 ? smp.y_raw(k) : smp.z_raw(k));
                     lds_x[(smp.x_off + k) * 64u + lane] = v;
@@ -279,7 +281,7 @@ __global__ void __launch_bounds__(CHAIN_BLOCK) k_mutate_bdpt(DParams P, uint32_t
     if ((P.debug & 128) && lane == 0) atomicAdd(P.stats + 18, __builtin_amdgcn_s_memtime() - k0); // whole chain loop, per wave
 }
 
-// u: [sensor S | emitter E] per point (dim >= S + E); out: rows of `stride` floats:
+// u: [sensor S | emitter E | direct Dd] per point (dim >= S + E + Dd); out: rows of `stride` floats:
 // [lum, hasMain, px, py, r, g, b, nMore, nDims, nRays, nMore x (px, py, r, g, b)]
 __global__ void __launch_bounds__(CHAIN_BLOCK) k_eval_lists_bdpt(DParams P, const float *u, uint32_t n, uint32_t dim, float *out, uint32_t stride) {
     const uint32_t lane = threadIdx.x;
@@ -299,14 +301,14 @@ __global__ void __launch_bounds__(CHAIN_BLOCK) k_eval_lists_bdpt(DParams P, cons
         for (uint32_t k = 0; k < stride; ++k) o[k] = 0.f;
         o[0] = R.lum; o[1] = R.has_main ? 1.f : 0.f;
         for (int k = 0; k < 5; ++k) o[2 + k] = L[(size_t) (BL_MAIN + k) * na];
-        o[7] = (float) R.n_more; o[8] = (float) (R.n_sensor + R.n_emitter); o[9] = (float) R.nrays;
+        o[7] = (float) R.n_more; o[8] = (float) (R.n_sensor + R.n_emitter + R.n_direct); o[9] = (float) R.nrays;
         for (int k = 0; k < R.n_more && 10 + 5 * (k + 1) <= (int) stride; ++k)
             for (int q = 0; q < 5; ++q) o[10 + 5 * k + q] = L[(size_t) (BL_MORE + 5 * k + q) * na];
     }
 }
 
 static size_t bdpt_lds_bytes(const DParams &P) {
-    return ((size_t) P.mmlt_S + P.mmlt_E + 4 * ((size_t) 2 * P.max_depth + 1)) * 64 * sizeof(float);
+    return ((size_t) P.mmlt_S + P.mmlt_E + P.bd_Dd + 4 * ((size_t) 2 * P.max_depth + 1)) * 64 * sizeof(float);
 }
 void launch_bootstrap_bdpt(const DParams &P, uint32_t n, float *lum_out, hipStream_t st) {
     hipLaunchKernelGGL(k_bootstrap_bdpt, dim3((P.n_chains_alloc + CHAIN_BLOCK - 1) / CHAIN_BLOCK), dim3(CHAIN_BLOCK), bdpt_lds_bytes(P), st, P, n, lum_out);

@@ -328,9 +328,24 @@ public:
         return result;
     }
 
-    // ---- Path::miWeight (sampleDirect = false, no null interactions) ------------------------------
-    F miWeight(const SubPath<F> &em, const SubPath<F> &se, int s, int t, bool lightImage) const {
+    // PathVertex::evalPdfDirect(sample, EImportance, EArea), vertex.cpp:1355-1382: density with which direct (emitter)
+    // sampling from `ref` produces the emitter sample, in area measure
+    F evalPdfDirectEmitter(const PVertex<F> &ref, const PVertex<F> &sample) const {
+        typename Scene<F>::DirectSample dRec;
+        dRec.ref = ref.p;
+        dRec.refN = V3<F>(0);
+        if (ref.type == VSurface && !scene.bsdfs[ref.bsdf].transmissiveOrBackside()) dRec.refN = ref.shFrame.n; // records.inl:160-164
+        dRec.p = sample.p; dRec.n = sample.n; dRec.emitter = sample.emitter;
+        dRec.d = sample.p - ref.p;
+        dRec.dist = dRec.d.length();
+        dRec.d /= dRec.dist;
+        return scene.pdfEmitterDirectArea(dRec);
+    }
+
+    // ---- Path::miWeight (no null interactions; sampleDirect: the s = 1 / t = 1 strategies use direct sampling) ----------
+    F miWeight(const SubPath<F> &em, const SubPath<F> &se, int s, int t, bool lightImage, bool sampleDirect = false) const {
         const int k = s + t + 1, n = k + 1;
+        if (k <= 3) sampleDirect = false; // path.cpp:799-800
         const PVertex<F> *vsPred = s >= 1 ? &em.v[s - 1] : nullptr, *vtPred = t >= 1 ? &se.v[t - 1] : nullptr;
         const PVertex<F> &vs = em.v[s], &vt = se.v[t];
         std::vector<F> pdfImp(n), pdfRad(n);
@@ -370,18 +385,41 @@ public:
             pdfRad[i - 1] *= edge.length * edge.length /
                              std::abs((succ.isOnSurface() ? dot(edge.d, succ.n) : F(1)) * (cur.isOnSurface() ? dot(edge.d, cur.n) : F(1)));
         }
-        double weight = 1, pdf = 1;
+        // Direct sampling strategies (path.cpp:803-824,936-965). Area emitters (direct measure: solid angle) and a pinhole
+        // (direct measure: discrete) leave `connectable` as it is: [0] and [1] stay true, [k - 1] stays true, [k] stays false.
+        // No null interactions: the reference vertices are 2 and k - 2. The sensor's ratio is pdfSensorDirect (1 under the
+        // discrete measure, perspective.cpp:386-390) / pdfRad[k - 1] (the pinhole's position density, 1).
+        F ratioEmitterDirect = 0, ratioSensorDirect = 0;
+        double initial = 1;
+        const int sensorRef = k - 2;
+        if (sampleDirect) {
+            const PVertex<F> &sample = s > 0 ? em.v[1] : vt;
+            const PVertex<F> &ref = 2 <= s ? em.v[2] : se.v[k - 2];
+            if (connectable[1] && connectable[2]) ratioEmitterDirect = evalPdfDirectEmitter(ref, sample) / pdfImp[1];
+            if (connectable[k - 1] && connectable[sensorRef]) ratioSensorDirect = F(1) / pdfRad[k - 1];
+            if (s == 1) initial /= ratioEmitterDirect;
+            else if (t == 1) initial /= ratioSensorDirect;
+        }
+        double weight = 1, pdf = initial;
         for (int i = s + 1; i < k; ++i) {
-            double next = pdf * (double) pdfImp[i] / (double) pdfRad[i];
+            double next = pdf * (double) pdfImp[i] / (double) pdfRad[i], value = next;
+            if (sampleDirect) {
+                if (i == 1) value *= ratioEmitterDirect;
+                else if (i == sensorRef) value *= ratioSensorDirect;
+            }
             int tPrime = k - i - 1;
-            if (connectable[i] && connectable[i + 1] && (lightImage || tPrime > 1)) weight += next * next;
+            if (connectable[i] && connectable[i + 1] && (lightImage || tPrime > 1)) weight += value * value;
             pdf = next;
         }
-        pdf = 1;
+        pdf = initial;
         for (int i = s - 1; i >= 0; --i) {
-            double next = pdf * (double) pdfRad[i + 1] / (double) pdfImp[i + 1];
+            double next = pdf * (double) pdfRad[i + 1] / (double) pdfImp[i + 1], value = next;
+            if (sampleDirect) {
+                if (i == 1) value *= ratioEmitterDirect;
+                else if (i == sensorRef) value *= ratioSensorDirect;
+            }
             int tPrime = k - i - 1;
-            if (connectable[i] && connectable[i + 1] && (lightImage || tPrime > 1)) weight += next * next;
+            if (connectable[i] && connectable[i + 1] && (lightImage || tPrime > 1)) weight += value * value;
             pdf = next;
         }
         return (F) (1.0 / weight);
@@ -460,9 +498,11 @@ public:
         list.luminance = oracle::luminance(value);
     }
 
-    // ---- PathSampler::sampleSplats, EBidirectional branch (pathsampler.cpp:321-527), directSampling = false ----------
+    // ---- PathSampler::sampleSplats, EBidirectional branch (pathsampler.cpp:321-527). directSampler != nullptr:
+    // directSampling = true, the s = 1 / t = 1 strategies of :424-452 (two components of the direct sampler each).
     void sampleSplatsBDPT(Sampler<F> &emitterSampler, Sampler<F> &sensorSampler, int maxDepth, int rrDepth, bool excludeDirect,
-                          bool lightImage, SplatList<F> &list) const {
+                          bool lightImage, SplatList<F> &list, Sampler<F> *directSampler = nullptr) const {
+        const bool sampleDirect = directSampler != nullptr;
         list.px = list.py = 0; list.value = V3<F>(0); list.luminance = 0; list.nDims = 0; list.nRays = 0;
         list.more.clear(); list.hasMain = false; list.s = list.t = 0;
         uint64_t rays = 0;
@@ -500,7 +540,53 @@ public:
                     if (value.isZero()) continue;
                 } else if (vt.type == VSensorSupernode) {
                     continue; // cast(ESensorSample) needs a sensor shape: a pinhole has none
+                } else if (sampleDirect && s == 1 && t > 1) {
+                    // s = 1: a position on an emitter by direct sampling from vt (vertex.cpp:1285-1346, scene.cpp:879-904
+                    // without the visibility test), which replaces the emitter subpath's own first vertex for this strategy
+                    if (vt.degenerate) continue;
+                    F sx, sy;
+                    directSampler->next2D(sx, sy);
+                    typename Scene<F>::DirectSample dRec;
+                    dRec.ref = vt.p;
+                    dRec.refN = (vt.type == VSurface && !scene.bsdfs[vt.bsdf].transmissiveOrBackside()) ? vt.shFrame.n : V3<F>(0);
+                    V3<F> direct = scene.sampleEmitterDirect(dRec, sx, sy, nullptr, false);
+                    if (direct.isZero()) continue;
+                    if ((dRec.ref - dRec.p).lengthSquared() <= 0) continue;
+                    const Emitter<F> &emr = scene.emitters[dRec.emitter];
+                    SubPath<F> em1; // tempEndpoint, tempEdge, tempSample swapped in for miWeight (pathsampler.cpp:486-503)
+                    em1.v.resize(2); em1.e.resize(1);
+                    PVertex<F> &tempEndpoint = em1.v[0], &tempSample = em1.v[1];
+                    tempEndpoint.type = VEmitterSupernode; tempEndpoint.measure = MArea; tempEndpoint.degenerate = false;
+                    tempEndpoint.pdf[EImportance] = scene.shapes[emr.shape].invArea * (scene.emitterCdf[dRec.emitter + 1] - scene.emitterCdf[dRec.emitter]);
+                    tempEndpoint.weight[EImportance] = emr.radiance * F(kPi) / tempEndpoint.pdf[EImportance];
+                    tempSample.type = VEmitterSample; tempSample.measure = MArea; tempSample.degenerate = false;
+                    tempSample.p = dRec.p; tempSample.n = dRec.n; tempSample.emitter = dRec.emitter; tempSample.shape = emr.shape;
+                    value = radW[t] * direct * eval(vt, vtPred, &tempSample, ERadiance);
+                    vt.measure = MArea;
+                    if (value.isZero()) continue;
+                    V3<F> d = tempSample.p - vt.p;
+                    F length = d.length();
+                    if (length == 0) continue;
+                    d /= length;
+                    Ray<F> ray{vt.p, d, vt.isOnSurface() ? Consts<F>::Epsilon : F(0), length * (1 - Consts<F>::ShadowEpsilon)};
+                    Intersection<F> its;
+                    ++rays;
+                    if (scene.rayIntersect(ray, its)) continue;
+                    if (excludeDirect && depth <= 2) continue;
+                    if (vt.isOnSurface() && vt.isConnectable()) value *= absDot(vsShadingNormal(vt), d); // ETransmittance | ECosineRad
+                    value *= miWeight(em1, se, s, t, lightImage, true);
+                    list.value += value; // t >= 2: the sensor-side pixel
+                    list.luminance += oracle::luminance(value);
+                    continue;
                 } else {
+                    // t = 1 with direct sampling (s > 1): a pinhole's sampleDirect returns the one point the sensor subpath's
+                    // own vertex 1 already is (perspective.cpp:386-420): importance / dist^2 times the cosine at vs equals the
+                    // generic connection below term by term -- what remains is that the strategy consumes two components
+                    if (sampleDirect && t == 1 && s > 1) {
+                        if (vs.degenerate) continue;
+                        F sx, sy;
+                        directSampler->next2D(sx, sy);
+                    }
                     if (vs.degenerate || vt.degenerate) continue;
                     value = impW[s] * radW[t] * eval(vs, vsPred, &vt, EImportance) * eval(vt, vtPred, &vs, ERadiance);
                     vs.measure = vt.measure = MArea;
@@ -519,7 +605,7 @@ public:
                 }
                 if (excludeDirect && depth <= 2) continue;
                 value *= geo;
-                value *= miWeight(em, se, s, t, lightImage);
+                value *= miWeight(em, se, s, t, lightImage, sampleDirect);
                 if (vt.type == VSensorSample && !samplePositionOf(vs.p - vt.p, sx, sy)) continue;
                 if (t < 2) { list.more.push_back({sx, sy, value}); }
                 else { list.value += value; }
@@ -540,6 +626,12 @@ inline int findMaxDimensionsMMLT(int depth) {
     return maxDim;
 }
 
+// Components of the direct sampler under technique=bdpt with directSampling=true. The reference gives it maxDepth
+// (pssmlt_utils.h:75) although every s = 1 / t = 1 connection draws two (pathsampler.cpp:424-452, vertex.cpp:1304-1305) and a
+// sample makes up to (maxDepth - 1) t = 1 and maxDepth s = 1 connections: its primarySample then reads past the vector
+// ("Exceeded maximum dimension", drmlt_sampler.cpp:256-258). Sized here to what the strategies can consume.
+inline int findDirectDimensionsBDPT(int maxDepth) { return 2 * (2 * maxDepth - 1); }
+
 // pssmlt_utils.h:69-75: sensor = emitter = (maxDepth + 2) * (2 + RR) rounded up to even; direct = 0 without direct sampling
 inline int findMaxDimensionsBDPT(int maxDepth, int rrDepth) {
     int maxDim = (maxDepth + 2) * (2 + (rrDepth < maxDepth ? 1 : 0));
@@ -554,11 +646,14 @@ template <typename F> struct MMLTSamplers {
     DRMLTSampler<F> sensor, emitter, direct;
     int depth = -1;
     uint32_t dmax;
-    bool bdpt; // technique=bdpt: same triple, dimensions independent of the seed, direct sampler unused (directSampling=false)
+    bool bdpt; // technique=bdpt: same triple, dimensions independent of the seed; the direct sampler is an ordinary third
+               // sampler when directSampling is on (no identity stages: those are mmlt's, drmlt_proc.cpp:133-141) and unused otherwise
+    uint32_t ddirect = 0;
     template <typename Cfg>
     MMLTSamplers(const Cfg &cfg, Random *r)
         : sensor(cfg, r), emitter(cfg, r), direct(cfg, r), bdpt(cfg.technique == DRMLT_TECH_BDPT) {
         dmax = (uint32_t) (bdpt ? findMaxDimensionsBDPT(cfg.maxDepth, cfg.rrDepth) : findMaxDimensionsMMLT(cfg.maxDepth));
+        if (bdpt && cfg.directSampling) ddirect = (uint32_t) findDirectDimensionsBDPT(cfg.maxDepth);
         if (!bdpt) {
             direct.setStagesToIdentity();                      // the strategy stays fixed in small steps (:133-135)
             if (cfg.fixEmitterPath) emitter.handleLightTracing(); // :136-140
@@ -568,16 +663,16 @@ template <typename F> struct MMLTSamplers {
     void configureForSeed(int d) { // :452-464
         depth = d;
         size_t D = bdpt ? (size_t) dmax : (size_t) findMaxDimensionsMMLT(d);
-        sensor.setMaxDim(D); emitter.setMaxDim(D); direct.setMaxDim(bdpt ? 0 : 1);
+        sensor.setMaxDim(D); emitter.setMaxDim(D); direct.setMaxDim(bdpt ? ddirect : 1);
         sensor.setDrawBase(0); emitter.setDrawBase(2 * dmax); direct.setDrawBase(4 * dmax);
     }
     void reset() { emitter.reset(); sensor.reset(); direct.reset(); }
     void setRandom(Random *r) { sensor.setRandom(r); emitter.setRandom(r); direct.setRandom(r); }
     void setReplay(bool v) { sensor.setReplay(v); emitter.setReplay(v); direct.setReplay(v); }
     void setMutation(uint32_t m) { sensor.setMutation(m); emitter.setMutation(m); direct.setMutation(m); }
-    void setLargeStep(bool v) { sensor.setLargeStep(v); emitter.setLargeStep(v); direct.setLargeStep(v); }
+    void setLargeStep(bool v) { sensor.setLargeStep(v); emitter.setLargeStep(v); direct.setLargeStep(v); if (bdpt && ddirect) direct.prime(); } // called after setMutation: the first-stage proposal is defined
     void setReverse(bool v) { sensor.setReverse(v); emitter.setReverse(v); direct.setReverse(v); }
-    void nextStage(bool lightTracing) { sensor.nextStage(); direct.nextStage(); emitter.nextStage(lightTracing); }
+    void nextStage(bool lightTracing) { sensor.nextStage(); direct.nextStage(); emitter.nextStage(lightTracing); if (bdpt && ddirect) direct.prime(); }
     void accept(bool first) { sensor.accept(first); emitter.accept(first); direct.accept(first); }
     void reject() { sensor.reject(); emitter.reject(); direct.reject(); }
     void fillReplay() { sensor.fillReplay(); emitter.fillReplay(); direct.fillReplay(); } // :506-509
@@ -614,19 +709,21 @@ template <typename F> struct MMLTEvaluator {
     int height() const { return scene->height; }
 };
 
-// Evaluator over a scene: PathSampler::sampleSplats(EBidirectional), directSampling = false
+// Evaluator over a scene: PathSampler::sampleSplats(EBidirectional)
 template <typename F> struct BDPTEvaluator {
     const Scene<F> *scene;
     int maxDepth, rrDepth;
     bool excludeDirect, lightImage;
-    void operator()(MMLTSamplers<F> &set, SplatList<F> &list, Stats *st) const { run(set.emitter, set.sensor, list, st); }
-    void operator()(ReplayableSampler<F> &s, SplatList<F> &list, Stats *st) const { run(s, s, list, st); }
-    void run(Sampler<F> &emitter, Sampler<F> &sensor, SplatList<F> &list, Stats *st) const {
+    bool directSampling = false;
+    void operator()(MMLTSamplers<F> &set, SplatList<F> &list, Stats *st) const { run(set.emitter, set.sensor, set.direct, list, st); }
+    // bootstrap: one replayable stream plays all three roles, in call order (emitter walk, sensor walk, direct draws)
+    void operator()(ReplayableSampler<F> &s, SplatList<F> &list, Stats *st) const { run(s, s, s, list, st); }
+    void run(Sampler<F> &emitter, Sampler<F> &sensor, Sampler<F> &direct, SplatList<F> &list, Stats *st) const {
         Bidir<F> bd(*scene);
         const bool shared = &emitter == &sensor;
-        auto consumed = [&]() { return shared ? sensor.sampleIndex : emitter.sampleIndex + sensor.sampleIndex; };
+        auto consumed = [&]() { return shared ? sensor.sampleIndex : emitter.sampleIndex + sensor.sampleIndex + (directSampling ? direct.sampleIndex : 0); };
         size_t before = consumed();
-        bd.sampleSplatsBDPT(emitter, sensor, maxDepth, rrDepth, excludeDirect, lightImage, list);
+        bd.sampleSplatsBDPT(emitter, sensor, maxDepth, rrDepth, excludeDirect, lightImage, list, directSampling ? &direct : nullptr);
         list.nDims = (int) (consumed() - before);
         if (st) { st->path_evals++; st->rays += (uint64_t) list.nRays; }
     }

@@ -77,7 +77,7 @@ def lib(native=False):
         L.oracle_find_max_dim.argtypes = [C.c_int, C.c_int]
         L.oracle_set_importance_map.argtypes = [C.c_void_p, C.c_void_p]
         L.oracle_bdpt_render.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_int, C.c_void_p]
-        L.oracle_bdpt_eval.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32]
+        L.oracle_bdpt_eval.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32]
         L.oracle_luminance_map.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
         L.oracle_find_max_dim_mmlt.argtypes = [C.c_int]
         L.oracle_roughconductor.argtypes = [C.c_int, C.c_double] + [C.c_void_p] * 3 + [C.c_uint32] + [C.c_void_p] * 7
@@ -184,15 +184,19 @@ class Oracle:
         self._chk(self.L.oracle_bdpt_render(self.h, n, seed, nthreads, out.ctypes.data))
         return out
 
-    def bdpt_eval(self, u_sensor, u_emitter):
-        """Rows: [lum, hasMain, px, py, r, g, b, nMore, nDims, nRays, nMore x (px, py, r, g, b)]."""
+    def bdpt_eval(self, u_sensor, u_emitter, u_direct=None):
+        """Rows: [lum, hasMain, px, py, r, g, b, nMore, nDims, nRays, nMore x (px, py, r, g, b)].
+        u_direct: the direct sampler's components (directSampling = true), same shape."""
         us = np.ascontiguousarray(u_sensor, dtype=np.float32)
         ue = np.ascontiguousarray(u_emitter, dtype=np.float32)
         assert us.shape == ue.shape
+        ud = np.ascontiguousarray(u_direct, dtype=np.float32) if u_direct is not None else None
+        assert ud is None or ud.shape == us.shape
         n, dim = us.shape
         stride = 10 + 5 * (self.cfg.max_depth + 1)
         out = np.zeros((n, stride), dtype=np.float32)
-        self._chk(self.L.oracle_bdpt_eval(self.h, us.ctypes.data, ue.ctypes.data, n, dim, out.ctypes.data, stride))
+        self._chk(self.L.oracle_bdpt_eval(self.h, us.ctypes.data, ue.ctypes.data, ud.ctypes.data if ud is not None else None, n, dim,
+                                          out.ctypes.data, stride))
         return out
 
     def set_importance_map(self, lum_map):

@@ -37,7 +37,7 @@ struct CtxBase {
     virtual int bootstrapLum(uint64_t seed, uint32_t stream, uint32_t n, float *out) = 0;
     virtual int setImportance(const float *map) = 0;
     virtual int bdptRender(uint64_t n, uint64_t seed, int nthreads, float *out) = 0;
-    virtual int bdptEval(const float *uSensor, const float *uEmitter, uint32_t n, uint32_t dim, float *out, uint32_t stride) = 0;
+    virtual int bdptEval(const float *uSensor, const float *uEmitter, const float *uDirect, uint32_t n, uint32_t dim, float *out, uint32_t stride) = 0;
     virtual int mmltRender(int depth, uint64_t n, uint64_t seed, int lightImage, int nthreads, float *out, double *strat) = 0;
     virtual int mmltEval(int depth, int lightImage, const float *uSensor, const float *uEmitter, const float *uDirect,
                          uint32_t n, uint32_t dim, drmlt_splat *out, int *st) = 0;
@@ -67,10 +67,6 @@ template <typename F> struct Ctx : CtxBase {
         cfg = in;
         mmlt = in.technique == DRMLT_TECH_MMLT;
         bdpt = in.technique == DRMLT_TECH_BDPT;
-        // With directSampling=true (the reference's default) its bdpt chains overrun the direct sampler: it gets
-        // maxDepth components (pssmlt_utils.h:75) but every s = 1 / t = 1 connection draws two (pathsampler.cpp:424-452),
-        // and primarySample raises "Exceeded maximum dimension" (drmlt_sampler.cpp:256-258). Only the variant that runs is restated.
-        if (bdpt && !in.no_direct_sampling) return "technique=bdpt needs directSampling=false (no_direct_sampling=1)";
         if (bdpt && in.algo == DRMLT_ALGO_PSSMLT) return "oracle: pssmlt over technique=bdpt is not restated";
         if (bdpt && in.timid_after_large) return "timidAfterLarge is not restated for technique=bdpt";
         if (mmlt && in.max_depth <= 0) return "Impossible to use MMLT with no max depth"; // drmlt.cpp:213-215
@@ -93,7 +89,8 @@ template <typename F> struct Ctx : CtxBase {
         c.pLarge = in.p_large; c.sigma = in.sigma; c.scaleSecond = in.scale_second;
         c.maxDim = findMaxDimensionsPath(in.max_depth, in.rr_depth);
         c.fixEmitterPath = in.fix_emitter_path != 0; c.lightImage = in.no_light_image == 0; c.technique = in.technique;
-        beval = BDPTEvaluator<F>{&scene, c.maxDepth, c.rrDepth, c.separateDirect, c.lightImage};
+        c.directSampling = bdpt && !in.no_direct_sampling; // drmlt.cpp:228-231 (forced off for mmlt)
+        beval = BDPTEvaluator<F>{&scene, c.maxDepth, c.rrDepth, c.separateDirect, c.lightImage, c.directSampling};
         meval = MMLTEvaluator<F>{&scene, c.maxDepth, c.separateDirect, c.lightImage};
         if (c.acceptanceMap && scene.filterType != DRMLT_FILTER_BOX) return "Box filter required for acceptance map!";
         eval = SceneEvaluator<F>{&scene, c.maxDepth, c.rrDepth, c.separateDirect};
@@ -236,11 +233,12 @@ template <typename F> struct Ctx : CtxBase {
             }
             return 0;
         }
-        if (bdpt) { // [sensor S | emitter E]: the components the walks can consume (see drmlt_abi.h)
+        if (bdpt) { // [sensor S | emitter E | direct Dd]: the components the walks / direct strategies can consume (see drmlt_abi.h)
             const uint32_t rr = (uint32_t) std::max(0, cfg.max_depth + 1 - std::max(cfg.rr_depth, 0));
             uint32_t S = 2u * (uint32_t) (cfg.max_depth + 1) + rr, E = 2u * (uint32_t) cfg.max_depth + (rr > 0 ? rr - 1 : 0);
             S += S & 1u; E += E & 1u;
-            if (u && dim < S + E) throw std::runtime_error("chain_state: need S + E dims for technique=bdpt");
+            const uint32_t Dd = c.directSampling ? (uint32_t) findDirectDimensionsBDPT(cfg.max_depth) : 0u;
+            if (u && dim < S + E + Dd) throw std::runtime_error("chain_state: need S + E + Dd dims for technique=bdpt");
             for (int i = 0; i < cfg.work_units; ++i) {
                 const SplatList<F> &l = bchains[i]->current();
                 const MMLTSamplers<F> &ms = bchains[i]->sampler();
@@ -254,6 +252,7 @@ template <typename F> struct Ctx : CtxBase {
                     for (uint32_t k = 0; k < dim; ++k) row[k] = 0.f;
                     for (uint32_t k = 0; k < S && k < ms.sensor.uCurrent.size(); ++k) row[k] = (float) ms.sensor.uCurrent[k];
                     for (uint32_t k = 0; k < E && k < ms.emitter.uCurrent.size(); ++k) row[S + k] = (float) ms.emitter.uCurrent[k];
+                    for (uint32_t k = 0; k < Dd && k < ms.direct.uCurrent.size(); ++k) row[S + E + k] = (float) ms.direct.uCurrent[k];
                 }
             }
             return 0;
@@ -351,14 +350,14 @@ template <typename F> struct Ctx : CtxBase {
         std::vector<std::unique_ptr<Film<F>>> films;
         for (int t = 0; t < nthreads; ++t) films.emplace_back(new Film<F>(scene.width, scene.height, scene.filterType, scene.filterParam));
         auto work = [&](int t) {
-            Random rs(seedv, (uint32_t) (2 * t)), re(seedv, (uint32_t) (2 * t + 1));
-            ReplayableSampler<F> sensor(&rs), emitter(&re);
+            Random rs(seedv, (uint32_t) (2 * t)), re(seedv, (uint32_t) (2 * t + 1)), rd(seedv, 0x40000000u + (uint32_t) t);
+            ReplayableSampler<F> sensor(&rs), emitter(&re), direct(&rd);
             SplatList<F> l;
             Bidir<F> bd(scene);
             for (uint64_t i = (uint64_t) t; i < n; i += (uint64_t) nthreads) {
                 uint32_t major = (uint32_t) (i / (uint64_t) nthreads);
-                rs.seek(TAG_PT, major, 0); re.seek(TAG_PT, major, 0);
-                bd.sampleSplatsBDPT(emitter, sensor, cfg.max_depth, cfg.rr_depth, cfg.direct_samples >= 0, cfg.no_light_image == 0, l);
+                rs.seek(TAG_PT, major, 0); re.seek(TAG_PT, major, 0); rd.seek(TAG_PT, major, 0);
+                bd.sampleSplatsBDPT(emitter, sensor, cfg.max_depth, cfg.rr_depth, cfg.direct_samples >= 0, cfg.no_light_image == 0, l, c.directSampling ? &direct : nullptr);
                 if (l.hasMain && spectrumValid(l.value)) films[t]->put(l.px, l.py, l.value);
                 for (const auto &sp : l.more) if (spectrumValid(sp.value)) films[t]->put(sp.px, sp.py, sp.value);
             }
@@ -374,17 +373,20 @@ template <typename F> struct Ctx : CtxBase {
         return 0;
     }
     // out row: [lum, hasMain, px, py, r, g, b, nMore, nDims, nRays, then nMore x (px, py, r, g, b)] (stride floats)
-    int bdptEval(const float *uSensor, const float *uEmitter, uint32_t n, uint32_t dim, float *out, uint32_t stride) override {
+    // uDirect: n x dim components of the direct sampler (directSampling = true), or NULL
+    int bdptEval(const float *uSensor, const float *uEmitter, const float *uDirect, uint32_t n, uint32_t dim, float *out, uint32_t stride) override {
         Bidir<F> bd(scene);
+        if (c.directSampling && !uDirect) throw std::runtime_error("bdpt_eval: directSampling=true needs the direct sampler's components");
         for (uint32_t i = 0; i < n; ++i) {
             ArraySampler<F> sensor(uSensor + (size_t) i * dim, dim), emitter(uEmitter + (size_t) i * dim, dim);
+            ArraySampler<F> direct(uDirect ? uDirect + (size_t) i * dim : uSensor, dim);
             SplatList<F> l;
-            bd.sampleSplatsBDPT(emitter, sensor, cfg.max_depth, cfg.rr_depth, cfg.direct_samples >= 0, cfg.no_light_image == 0, l);
+            bd.sampleSplatsBDPT(emitter, sensor, cfg.max_depth, cfg.rr_depth, cfg.direct_samples >= 0, cfg.no_light_image == 0, l, c.directSampling ? &direct : nullptr);
             float *o = out + (size_t) i * stride;
             for (uint32_t k = 0; k < stride; ++k) o[k] = 0.f;
             o[0] = (float) l.luminance; o[1] = l.hasMain ? 1.f : 0.f; o[2] = (float) l.px; o[3] = (float) l.py;
             o[4] = (float) l.value.x; o[5] = (float) l.value.y; o[6] = (float) l.value.z;
-            o[7] = (float) l.more.size(); o[8] = (float) (sensor.sampleIndex + emitter.sampleIndex); o[9] = (float) l.nRays;
+            o[7] = (float) l.more.size(); o[8] = (float) (sensor.sampleIndex + emitter.sampleIndex + (c.directSampling ? direct.sampleIndex : 0)); o[9] = (float) l.nRays;
             for (size_t k = 0; k < l.more.size() && 10 + 5 * (k + 1) <= stride; ++k) {
                 float *q = o + 10 + 5 * k;
                 q[0] = (float) l.more[k].px; q[1] = (float) l.more[k].py;
@@ -599,7 +601,7 @@ void oracle_roughconductor(int ggx, double alpha, const double *eta, const doubl
 }
 
 int oracle_bdpt_render(void *p, uint64_t n, uint64_t seed, int nthreads, float *out) { GUARD(static_cast<CtxBase *>(p)->bdptRender(n, seed, nthreads, out)) }
-int oracle_bdpt_eval(void *p, const float *uSensor, const float *uEmitter, uint32_t n, uint32_t dim, float *out, uint32_t stride) { GUARD(static_cast<CtxBase *>(p)->bdptEval(uSensor, uEmitter, n, dim, out, stride)) }
+int oracle_bdpt_eval(void *p, const float *uSensor, const float *uEmitter, const float *uDirect, uint32_t n, uint32_t dim, float *out, uint32_t stride) { GUARD(static_cast<CtxBase *>(p)->bdptEval(uSensor, uEmitter, uDirect, n, dim, out, stride)) }
 int oracle_set_importance_map(void *p, const float *map) { GUARD(static_cast<CtxBase *>(p)->setImportance(map)) }
 void oracle_luminance_map(const float *rgb, int w, int h, int W, int H, float *out) { luminanceMap(rgb, w, h, W, H, out); }
 int oracle_find_max_dim(int maxDepth, int rrDepth) { return findMaxDimensionsPath(maxDepth, rrDepth); }

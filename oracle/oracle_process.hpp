@@ -112,6 +112,7 @@ template <typename F> struct Config {
     int maxDim;
     int technique = 0;                              // DRMLT_TECH_*
     bool fixEmitterPath = false, lightImage = true; // technique=mmlt
+    bool directSampling = false;                    // technique=bdpt: the s = 1 / t = 1 strategies of pathsampler.cpp:424-452
     const float *importance = nullptr;              // two-stage MLT luminance image (W x H), drmlt.cpp:406-418
     int impW = 0, impH = 0;
 };

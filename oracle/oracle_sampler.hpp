@@ -248,6 +248,19 @@ public:
     }
     void reset() { uCurrent.clear(); clearProposals(); }
     void reject() { clearProposals(); }
+    // Generate this stage's proposal NOW -- the eager form of primarySample's k == 0 branch. The reference fills a sampler's
+    // proposal when its first component is requested; a sampler no component of which is requested during an evaluation
+    // keeps an EMPTY proposal, accept() then empties its current state (drmlt_sampler.cpp:189-191) and the next fillSpace reads
+    // out of bounds. Harmless where usage is fixed along a chain (mmlt: strategy kept), fatal for bdpt's direct sampler, whose
+    // use depends on the proposed path. Priming makes the proposal what a request for component 0 would have made it (the
+    // draws are addressed, so a later request regenerates the same values); the device evaluates proposals as pure functions
+    // and commits every dimension on acceptance, which is the same thing.
+    void prime() {
+        if (m_replay || m_maxDim == 0) return;
+        std::vector<F> &uProposed = isFirst ? uFirst : uSecond;
+        uProposed.clear();
+        fillSpace(isFirst);
+    }
     void fillReplay() { // drmlt_sampler.h:127-131
         while (uCurrent.size() < m_maxDim) uCurrent.push_back((F) m_random->nextFloat());
     }

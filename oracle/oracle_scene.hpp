@@ -459,8 +459,9 @@ public:
         return sh.invArea * (dRec.dist * dRec.dist) / absDot(dRec.d, dRec.n);
     }
 
-    // scene.cpp:879-904 (testVisibility = true)
-    V3<F> sampleEmitterDirect(DirectSample &dRec, F sx, F sy, uint64_t *rayCounter) const {
+    // scene.cpp:879-904; testVisibility = false is what PathVertex::sampleDirect asks for (vertex.cpp:1307: the connection
+    // edge tests visibility itself)
+    V3<F> sampleEmitterDirect(DirectSample &dRec, F sx, F sy, uint64_t *rayCounter, bool testVisibility = true) const {
         F emPdf;
         size_t index = sampleEmitterIndex(sx, emPdf);
         const Emitter<F> &em = emitters[index];
@@ -474,8 +475,10 @@ public:
             dRec.pdf = 0;
         }
         if (dRec.pdf != 0) {
-            Ray<F> ray{dRec.ref, dRec.d, Consts<F>::Epsilon, dRec.dist * (1 - Consts<F>::ShadowEpsilon)};
-            if (rayOccluded(ray, rayCounter)) return V3<F>(0);
+            if (testVisibility) {
+                Ray<F> ray{dRec.ref, dRec.d, Consts<F>::Epsilon, dRec.dist * (1 - Consts<F>::ShadowEpsilon)};
+                if (rayOccluded(ray, rayCounter)) return V3<F>(0);
+            }
             dRec.emitter = (int) index;
             dRec.pdf *= emPdf;
             value /= emPdf;
@@ -492,6 +495,24 @@ public:
             pdf = shapePdfDirect(shapes[em.shape], dRec);
         F discrete = emitterCdf[dRec.emitter + 1] - emitterCdf[dRec.emitter];
         return pdf * discrete;
+    }
+
+    // The same density under the AREA measure (Scene::pdfEmitterDirect with dRec.measure = EArea: what
+    // PathVertex::evalPdfDirect asks for in Path::miWeight, path.cpp:944-952; shape.cpp:118-127, sphere.cpp:356-385)
+    F pdfEmitterDirectArea(const DirectSample &dRec) const {
+        const Emitter<F> &em = emitters[dRec.emitter];
+        const Shape<F> &sh = shapes[em.shape];
+        F pdf = 0;
+        if (dot(dRec.d, dRec.refN) >= 0 && dot(dRec.d, dRec.n) < 0) {
+            pdf = sh.invArea;
+            if (sh.type == DRMLT_SHAPE_SPHERE) {
+                const V3<F> refToCenter = sh.center - dRec.ref;
+                const F sinAlpha = sh.radius / refToCenter.length();
+                if (sinAlpha < 1 - Consts<F>::Epsilon)
+                    pdf = F(0.5 * kInvPi) / (1 - safe_sqrt(1 - sinAlpha * sinAlpha)) * absDot(dRec.d, dRec.n) / (dRec.dist * dRec.dist);
+            }
+        }
+        return pdf * (emitterCdf[dRec.emitter + 1] - emitterCdf[dRec.emitter]);
     }
 
     // area.cpp:111-116

@@ -78,7 +78,7 @@ def test_create_validates_like_the_reference_ctor(pkg, abi, native_lib):
         (dict(type="orbital", max_depth=-1), "maxDepth"),
         (dict(type=7, max_depth=8), "implementation type"),
         (dict(type="orbital", technique="mmlt", max_depth=8, algo=1), "pssmlt"),
-        (dict(type="orbital", technique="bdpt", max_depth=8), "directSampling=false"),
+        (dict(type="orbital", technique="bdpt", max_depth=8, timid_after_large=1), "timidAfterLarge"),
         (dict(type="orbital", technique="mmlt", max_depth=8, timid_after_large=1), "timidAfterLarge"),
     ]
     for kw, needle in bad:

@@ -1,5 +1,6 @@
-"""GPU parity for technique=bdpt, directSampling=false: through the C-ABI, against the oracle's
-restatement of PathSampler::sampleSplats(EBidirectional) and of the chain loop over multi-splat lists."""
+"""GPU parity for technique=bdpt, directSampling=false and true (the reference's default): through
+the C-ABI, against the oracle's restatement of PathSampler::sampleSplats(EBidirectional) and of the chain loop over
+multi-splat lists."""
 import numpy as np
 import pytest
 
@@ -19,15 +20,17 @@ def make(pkg, ob, sd, **kw):
     return cfg, pkg.Context(cfg, sd), ob.Oracle(abi, cfg, sd, 64)
 
 
+@pytest.mark.parametrize("direct", [0, 1], ids=["nodirect", "direct"])
 @pytest.mark.parametrize("name", ["cornell_c2", "glass_sphere", "door_c3", "caustic_c5"])
-def test_lists_match_oracle(pkg, ob, name, native_lib):
-    """f(u) = a splat list: same number of light-image splats, same dims / rays, luminance and every splat within 2e-3."""
+def test_lists_match_oracle(pkg, ob, name, direct, native_lib):
+    """f(u) = a splat list: same number of light-image splats, same dims / rays, luminance and every splat within 2e-3.
+    direct: the s = 1 / t = 1 strategies by direct sampling and the sampleDirect terms of miWeight."""
     sd = pkg.scenes.SCENES[name](res=64)
-    cfg, ctx, orc = make(pkg, ob, sd, type="orbital", work_units=1024)
+    cfg, ctx, orc = make(pkg, ob, sd, type="orbital", work_units=1024, no_direct_sampling=0 if direct else 1)
     rng = np.random.default_rng(11)
     n = 6000
-    us, ue = rng.random((n, 24), dtype=np.float32), rng.random((n, 24), dtype=np.float32)
-    g, o = ctx.eval_lists_bdpt(us, ue), orc.bdpt_eval(us, ue)
+    us, ue, ud = (rng.random((n, 24), dtype=np.float32) for _ in range(3))
+    g, o = (ctx.eval_lists_bdpt(us, ue, ud), orc.bdpt_eval(us, ue, ud)) if direct else (ctx.eval_lists_bdpt(us, ue), orc.bdpt_eval(us, ue))
     same = (g[:, 1] == o[:, 1]) & (g[:, 7] == o[:, 7]) & (g[:, 8] == o[:, 8]) & (g[:, 9] == o[:, 9])
     assert same.mean() > 0.99, same.mean()
     rel = np.abs(g[:, 0] - o[:, 0])[same] / np.maximum(o[:, 0][same], 1e-3)
@@ -47,7 +50,9 @@ def rel_full(g, o):
 
 
 VARIANTS = [dict(type="orbital"), dict(type="green"), dict(type="mira"), dict(type="orbital", use_mixture=1),
-            dict(type="orbital", no_light_image=1), dict(type="green", direct_samples=16)]
+            dict(type="orbital", no_light_image=1), dict(type="green", direct_samples=16),
+            dict(type="orbital", no_direct_sampling=0), dict(type="green", no_direct_sampling=0), dict(type="mira", no_direct_sampling=0),
+            dict(type="orbital", no_direct_sampling=0, use_mixture=1), dict(type="orbital", no_direct_sampling=0, no_light_image=1)]
 
 
 @pytest.mark.parametrize("kw", VARIANTS, ids=lambda k: "-".join("%s=%s" % i for i in k.items()))
@@ -101,10 +106,27 @@ def test_bdpt_image_and_acceptance_map(pkg, ob, native_lib):
     assert fg[..., 1].sum() == pytest.approx(fo[..., 1].sum(), rel=0.05)
 
 
+def test_direct_sampling_image_matches_the_plain_estimator(pkg, ob, native_lib):
+    """directSampling=true (the reference default) is another weighting of the same integrand: chains with it converge to the
+    image of the oracle's independent bdpt samples drawn WITHOUT it, and their b agrees."""
+    sd = pkg.scenes.cornell_c2(32)
+    cfg, ctx, orc = make(pkg, ob, sd, type="orbital", work_units=8192, sample_count=512, luminance_samples=200000, no_direct_sampling=0)
+    _, _, plain = make(pkg, ob, sd, type="orbital", work_units=4, no_direct_sampling=1)
+    ref = plain.bdpt_render(32 * 32 * 3000, seed=9, nthreads=8)
+    b = ctx.seed(0x5EED)
+    assert b == pytest.approx(lum(ref).mean(), rel=0.02)
+    ctx.run(32 * 32 * 512)
+    img = ctx.develop()
+    blk = lambda a: a.reshape(8, 4, 8, 4, 3).mean((1, 3))
+    assert np.abs(blk(img) - blk(ref)).mean() / ref.mean() < 0.04
+
+
 def test_refusals(pkg, native_lib):
     sd = pkg.scenes.cornell_c2(16)
-    with pytest.raises(pkg.DrmltError, match="directSampling=false"):
-        pkg.Context(pkg.abi.make_config(technique="bdpt", max_depth=5, work_units=64), sd)
+    ctx = pkg.Context(pkg.abi.make_config(technique="bdpt", max_depth=5, work_units=64), sd)   # directSampling=true: the default
+    assert ctx.stats().max_dim == 2 * 14 + 2 * (2 * 5 - 1)
+    with pytest.raises(ValueError, match="direct sampler"):
+        ctx.eval_lists_bdpt(np.zeros((4, 24), dtype=np.float32), np.zeros((4, 24), dtype=np.float32))
     ctx = pkg.Context(pkg.abi.make_config(technique="bdpt", max_depth=5, work_units=64, no_direct_sampling=1), sd)
     with pytest.raises(pkg.DrmltError, match="drmlt_eval_lists"):
         ctx.eval_paths(np.zeros((4, 64), dtype=np.float32))

@@ -25,8 +25,6 @@ def test_ragged_chain_counts_track_the_oracle(pkg, ob, tech, n_chains, native_li
     sd = pkg.scenes.cornell_c2(16)
     kw = dict(technique=tech, type="orbital", max_depth=5, direct_samples=-1, work_units=n_chains, sample_count=1,
               luminance_samples=3000)
-    if tech == "bdpt":
-        kw["no_direct_sampling"] = 1
     cfg = pkg.abi.make_config(**kw)
     ctx, orc = pkg.Context(cfg, sd), ob.Oracle(pkg.abi, cfg, sd, 64)
     bg, bo = ctx.seed(42), orc.seed(42)

@@ -192,10 +192,52 @@ def test_bdpt_chains_converge(pkg, abi, ob, kw):
     assert np.abs(blocks(img) - blocks(ref)).mean() / ref.mean() < 0.03
 
 
-def test_bdpt_refusals(pkg, abi, ob):
+@pytest.mark.parametrize("name,maxd,rr", [("cornell_c2", 5, 2), ("glass_sphere", 5, 100), ("caustic_c5", 5, 100), ("door_c3", 4, 100)])
+def test_bdpt_direct_sampling_is_the_same_estimator(pkg, abi, ob, name, maxd, rr):
+    """directSampling = true (the reference's default, pathsampler.cpp:424-452 with miWeight's ratioEmitterDirect,
+    path.cpp:936-965): the s = 1 strategies draw their emitter point from the connecting vertex (cone sampling on the sphere
+    light of caustic_c5, where the MIS ratio is not 0 / 1), the expectation is unchanged -- full transport, direct light included."""
+    sd = pkg.scenes.SCENES[name](16)
+    n = 16 * 16 * 8000
+    a = ob.Oracle(abi, abi.make_config(technique="bdpt", max_depth=maxd, rr_depth=rr, work_units=4, direct_samples=-1, no_direct_sampling=1), sd, 64) \
+        .bdpt_render(n, seed=3, nthreads=8)
+    b = ob.Oracle(abi, abi.make_config(technique="bdpt", max_depth=maxd, rr_depth=rr, work_units=4, direct_samples=-1), sd, 64) \
+        .bdpt_render(n, seed=5, nthreads=8)
+    assert lum(b).mean() == pytest.approx(lum(a).mean(), rel=0.02)
+    assert np.abs(blocks(a) - blocks(b)).mean() / a.mean() < 0.04
+
+
+def test_bdpt_direct_sampling_dimensions_and_chains(pkg, abi, ob):
+    """Two components of the direct sampler per s = 1 / t = 1 connection, at most 2 (2 maxDepth - 1) (the reference sizes the
+    sampler to maxDepth and overruns it, pssmlt_utils.h:75); t = 1 splats are what they are without direct sampling (a pinhole
+    has one point to sample); chains with the three samplers converge to the same image."""
     sd = pkg.scenes.cornell_c2(16)
-    with pytest.raises(ob.OracleError, match="directSampling=false"):
-        ob.Oracle(abi, abi.make_config(technique="bdpt", max_depth=5, work_units=4), sd, 64)
+    rng = np.random.default_rng(2)
+    us, ue, ud = (rng.random((2000, 30), dtype=np.float32) for _ in range(3))
+    off = ob.Oracle(abi, abi.make_config(technique="bdpt", max_depth=5, rr_depth=3, work_units=4, direct_samples=-1, no_direct_sampling=1), sd, 64)
+    on = ob.Oracle(abi, abi.make_config(technique="bdpt", max_depth=5, rr_depth=3, work_units=4, direct_samples=-1), sd, 64)
+    r0, r1 = off.bdpt_eval(us, ue), on.bdpt_eval(us, ue, ud)
+    extra = r1[:, 8] - r0[:, 8]
+    assert (extra % 2 == 0).all() and extra.min() >= 0 and 0 < extra.max() <= 2 * (2 * 5 - 1)
+    assert np.array_equal(r0[:, 7], r1[:, 7])                                # the same light-image splats ...
+    m0, m1 = r0[:, 10:].reshape(len(r0), -1, 5), r1[:, 10:].reshape(len(r1), -1, 5)
+    np.testing.assert_allclose(m1[:, :, :2], m0[:, :, :2], atol=1e-9)        # ... at the same pixels
+    # their values differ only through the MIS weights (ratioEmitterDirect is 0 where vertex 2 sees the back of the light)
+    nz = (m0[:, :, 2] > 0) & (m1[:, :, 2] > 0)
+    assert nz.mean() > 0.2 and np.median(np.abs(m1[:, :, 2][nz] / m0[:, :, 2][nz] - 1)) < 0.05
+    with pytest.raises(ob.OracleError, match="direct sampler"):
+        on.bdpt_eval(us, ue)
+    sd = pkg.scenes.glass_sphere(16)
+    cfg = abi.make_config(technique="bdpt", max_depth=6, rr_depth=5, work_units=2048, direct_samples=-1, luminance_samples=100000, type="orbital")
+    o = ob.Oracle(abi, cfg, sd, 64)
+    ref = o.bdpt_render(16 * 16 * 4000, seed=9, nthreads=8)
+    b = o.seed(1234)
+    cur, u = o.chain_state(22 + 20 + 22)
+    assert u.shape[1] == 64 and ((u >= 0) & (u <= 1)).all() and (u[:, 42:] > 0).any()   # [sensor | emitter | direct] state
+    o.run(16 * 16 * 3000, nthreads=8)
+    img = o.develop()
+    assert b == pytest.approx(lum(ref).mean(), rel=0.02)
+    assert np.abs(blocks(img) - blocks(ref)).mean() / ref.mean() < 0.03
 
 
 def test_sphere_area_light(pkg, abi, ob):
