@@ -240,6 +240,12 @@ def main():
         p_acc = accepted / muts
         n_splats = 2.0 + (st1.second_base - st0.second_base) / muts
         bytes_per_mut = (4 * D + 32) * (1.0 + p_acc) + 24.0 * n_splats
+        # BVH scenes: the scene part of the algorithmic bytes (SURVEY 8d B_scene) is what the traversals fetched, counted by the
+        # kernel itself: 128 B per 4-wide node visited, 64 B per primitive record tested
+        bvh_nodes = (st1.bvh_node_visits - st0.bvh_node_visits) / muts
+        bvh_prims = (st1.bvh_prim_tests - st0.bvh_prim_tests) / muts
+        scene_bytes = 128.0 * bvh_nodes + 64.0 * bvh_prims
+        bytes_per_mut += scene_bytes
         muts_per_launch = muts / max(launches, 1)
         achieved = bytes_per_mut * muts_per_launch / (launch_ms * 1e-3) / 1e9 if launch_ms > 0 else 0.0
         traffic = valu_frac = lane_util = None
@@ -272,6 +278,8 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                          "kernel": conf["kernel"], "avg_launch_ms": launch_ms, "launches": launches,
                          "algorithmic_bytes_per_mutation": bytes_per_mut,
+                         "scene_bytes_per_mutation": scene_bytes, "bvh_node_visits_per_mutation": bvh_nodes,
+                         "bvh_prim_tests_per_mutation": bvh_prims,
                          "mutations_per_launch": muts_per_launch,
                          "hbm_measured_gbs": (traffic / (launch_ms * 1e-3) / 1e9) if traffic and launch_ms > 0 else None,
                          "hbm_measured_frac": (traffic / (launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic and launch_ms > 0 else None,
@@ -293,7 +301,9 @@ def main():
                 pass
 
     # ---- image quality at the accumulated budget (outside the timed region)
-    if not args.no_quality and not cfg_kw.get("acceptance_map"):
+    # (technique=path only: the device path tracer used as reference shares the path integrator's treatment of maxDepth;
+    # the bidirectional techniques are held to the oracle's bdpt / mmlt renders in tests/test_gpu_bdpt.py, test_gpu_mmlt.py)
+    if not args.no_quality and not cfg_kw.get("acceptance_map") and cfg_kw.get("technique", "path") == "path":
         if use_dist:  # every rank develops its tile of the summed film; rank 0 collects them
             tile, rows, b_mean = ctx.exchange_tiled(b)
             parts = [None] * world

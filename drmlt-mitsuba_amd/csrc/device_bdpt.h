@@ -99,7 +99,8 @@ DEV float emitter_direct_pdf_area(const TablesT &T, f3 ref_p, f3 ref_n, bool ref
 }
 
 // `list`: this lane's column of the target splat list (row r at list[r * n])
-template <class TablesT>
+// FEAT: as for trace() -- 15 with BVH traversal (and its 6 KB LDS stack), 7 without
+template <int FEAT = 15, class TablesT>
 DEV void eval_bdpt(const DParams &P, const TablesT &T, MSampler &smp, uint32_t chain, uint32_t mis_row, float *list, BdptResult &R) {
     const uint32_t lane = smp.lane, n = P.n_chains_alloc;
     const int ME = P.max_depth, MS = P.max_depth + 1;
@@ -241,7 +242,7 @@ DEV void eval_bdpt(const DParams &P, const TablesT &T, MSampler &smp, uint32_t c
                 thr_rr = thr_rr * rrw;
             }
 
-            const Hit h = trace(P, cur.p, d, ray_eps_closest(cur.p), INFINITY, false);
+            const Hit h = trace<FEAT>(P, cur.p, d, ray_eps_closest(cur.p), INFINITY, false);
             R.nrays++;
             if (h.prim < 0) WALK_FAIL;
             const DShade Sh = T.shade(h.prim);
@@ -342,63 +343,58 @@ DEV void eval_bdpt(const DParams &P, const TablesT &T, MSampler &smp, uint32_t c
                 if (is_zero3(value)) continue;
                 pc_i1 = T.shade(vt.shade).inv_area * (E.cdf_hi - E.cdf_lo);
                 pc_i2 = (dp < 0.f ? 0.f : INV_PI_F * dp) * vt.e_cos / vt.e_len2;
-            } else if (direct && s == 1 && t > 1) {
-                // s = 1: the emitter vertex is drawn by direct sampling from vt (:424-437, vertex.cpp:1285-1346,
-                // scene.cpp:879-904 without the visibility test) and replaces the walk's vertex 1 in miWeight (:486-503)
-                if (vt.degenerate) continue;
-                smp.select(SEG_DIRECT);
-                float sx = smp.next(kd);
-                const float sy = smp.next(kd + 1u);
-                kd += 2u;
-                const DBsdf Bt = T.bsdf(vt.bsdf);
-                int ei = 0;
-                for (int q = 1; q < P.n_emitters; ++q)
-                    if (T.emitter_cdf_lo(q) < sx) ei = q;
-                const DEmitter E = T.emitter(ei);
-                const float emPdf = E.cdf_hi - E.cdf_lo;
-                sx = (sx - E.cdf_lo) / emPdf;
-                const DShade L = T.shade(E.prim);
-                f3 ln = ld3(L.n), dd;
-                float dist, pdf;
-                if ((L.bsdf >> 24) == PRIM_SPHERE) {
-                    sphere_sample_direct(ld3(L.origin), L.eu[0], L.inv_area, vt.p, sx, sy, dd, dist, ln, pdf);
-                } else {
-                    f3 lp;
-                    if ((L.bsdf >> 24) == PRIM_RECTANGLE) lp = fma3(ld3(L.eu), sx, fma3(ld3(L.ev), sy, ld3(L.origin)));
-                    else { const float a = sqrtf(fmaxf(0.f, 1.f - sx)); lp = fma3(ld3(L.eu), 1.f - a, fma3(ld3(L.ev), a * sy, ld3(L.origin))); }
-                    const f3 dv = lp - vt.p;
-                    const float dist2 = dot3(dv, dv);
-                    dist = sqrtf(dist2);
-                    dd = dv * (1.f / dist);
-                    const float c = dot3(dd, ln);
-                    pdf = c != 0.f ? L.inv_area * dist2 / fabsf(c) : 0.f;
-                }
-                const float dln = dot3(dd, ln);
-                const float dr = Bt.type == 1 ? 0.f : dot3(dd, vt.n);
-                if (!(dr >= 0.f && dln < 0.f && pdf != 0.f)) continue; // AreaLight::sampleDirect, area.cpp:164-178
-                if (!(dist > 0.f)) continue;
-                value = thr_t * (ld3(E.radiance) * (1.f / (pdf * emPdf))) * vert_eval(P, Bt, vt, dd, false);
-                if (is_zero3(value)) continue;
-                const Hit h = trace(P, vt.p, dd, ray_eps_closest(vt.p), dist * (1.f - SHADOW_EPSILON_F), true);
-                R.nrays++;
-                if (h.prim >= 0) continue;
-                const float len2 = dist * dist;
-                const float cs = fabsf(dln), ct = fabsf(dot3(vt.n, dd));
-                geo = ct; // ETransmittance | ECosineRad of the direct connection: the cosine at vt (:441-446)
-                const f3 wot = to_local(vt, dd);
-                em0 = L.inv_area * emPdf;
-                pc_i1 = INV_PI_F * cs * ct / len2;
-                pc_r0 = vert_pdf_sa(P, Bt, vt, vt.wi, wot, dd) * cs / len2;
-                pc_i2 = bsdf_pdf_sa(Bt, wot, vt.wi) * ((wot.z == 0.f || vt.wi.z == 0.f) ? 0.f : 1.f) * vt.e_cos / vt.e_len2;
-                pc_r1 = 1.f;
-                re_s1 = emitter_direct_pdf_area(T, vt.p, vt.n, Bt.type == 1, fma3(dd, dist, vt.p), ln, ei) / em0;
             } else {
+                if (direct && s == 1) {
+                    // s = 1, t > 1: the emitter vertex is drawn by direct sampling from vt (:424-437, vertex.cpp:1285-1346,
+                    // scene.cpp:879-904 without the visibility test) and replaces the walk's vertex 1, in miWeight too
+                    // (:486-503). It goes through the connection code below as a vertex `vs` whose weight makes that code's
+                    // value radiance / (pdf_direct) * f * cos -- lanes at s = 1 and lanes at other s share one code path.
+                    if (t == 1) { W.get(0, vs, thr_s); vs.degenerate = false; }
+                    else {
+                        if (vt.degenerate) continue;
+                        smp.select(SEG_DIRECT);
+                        float sx = smp.next(kd);
+                        const float sy = smp.next(kd + 1u);
+                        kd += 2u;
+                        int ei = 0;
+                        for (int q = 1; q < P.n_emitters; ++q)
+                            if (T.emitter_cdf_lo(q) < sx) ei = q;
+                        const DEmitter E = T.emitter(ei);
+                        const float emPdf = E.cdf_hi - E.cdf_lo;
+                        sx = (sx - E.cdf_lo) / emPdf;
+                        const DShade L = T.shade(E.prim);
+                        f3 ln = ld3(L.n), dd;
+                        float dist, pdf;
+                        if ((L.bsdf >> 24) == PRIM_SPHERE) {
+                            sphere_sample_direct(ld3(L.origin), L.eu[0], L.inv_area, vt.p, sx, sy, dd, dist, ln, pdf);
+                            vs.p = fma3(dd, dist, vt.p);
+                        } else {
+                            if ((L.bsdf >> 24) == PRIM_RECTANGLE) vs.p = fma3(ld3(L.eu), sx, fma3(ld3(L.ev), sy, ld3(L.origin)));
+                            else { const float a = sqrtf(fmaxf(0.f, 1.f - sx)); vs.p = fma3(ld3(L.eu), 1.f - a, fma3(ld3(L.ev), a * sy, ld3(L.origin))); }
+                            const f3 dv = vs.p - vt.p;
+                            const float dist2 = dot3(dv, dv);
+                            dist = sqrtf(dist2);
+                            dd = dv * (1.f / dist);
+                            const float c = dot3(dd, ln);
+                            pdf = c != 0.f ? L.inv_area * dist2 / fabsf(c) : 0.f;
+                        }
+                        const float dln = dot3(dd, ln);
+                        const float dr = T.bsdf(vt.bsdf).type == 1 ? 0.f : dot3(dd, vt.n);
+                        if (!(dr >= 0.f && dln < 0.f && pdf != 0.f)) continue; // AreaLight::sampleDirect, area.cpp:164-178
+                        if (!(dist > 0.f)) continue;
+                        vs.kind = BK_END_E; vs.n = ln; vs.s = vs.wi = mk3(0.f, 0.f, 0.f); vs.e_len2 = vs.e_cos = 0.f;
+                        vs.bsdf = 0; vs.emitter = ei; vs.shade = E.prim; vs.degenerate = false;
+                        // the connection computes thr_s * (1 / pi) * f * cos_s cos_t / len^2: make that radiance / pdf * f * cos_t
+                        thr_s = ld3(E.radiance) * (PI_F * dist * dist / (pdf * emPdf * fabsf(dln)));
+                        em0 = L.inv_area * emPdf;
+                    }
+                }
                 // t = 1 with direct sampling: a pinhole's sampleDirect returns the point the sensor subpath's vertex 1 already is
                 // (perspective.cpp:386-420) and the same value term by term; what remains is that it consumes two components
+                // (only a replayed stream has a position to advance: the chain samplers are functions of the index)
                 if (direct && t == 1 && s > 1) {
                     if (vs.degenerate) continue;
-                    smp.select(SEG_DIRECT);
-                    (void) smp.next(kd); (void) smp.next(kd + 1u);
+                    if (smp.mode == SM_BOOT) { smp.select(SEG_DIRECT); (void) smp.next(kd); (void) smp.next(kd + 1u); }
                     kd += 2u;
                 }
                 if (vs.degenerate || vt.degenerate) continue;
@@ -410,7 +406,7 @@ DEV void eval_bdpt(const DParams &P, const TablesT &T, MSampler &smp, uint32_t c
                 const DBsdf Bs = T.bsdf(vs.bsdf), Bt = T.bsdf(vt.bsdf);
                 value = thr_s * thr_t * vert_eval(P, Bs, vs, dc, true) * vert_eval(P, Bt, vt, -dc, false);
                 if (is_zero3(value)) continue;
-                const Hit h = trace(P, vt.p, -dc, ray_eps_closest(vt.p), len * (1.f - SHADOW_EPSILON_F), true);
+                const Hit h = trace<FEAT>(P, vt.p, -dc, ray_eps_closest(vt.p), len * (1.f - SHADOW_EPSILON_F), true);
                 R.nrays++;
                 if (h.prim >= 0) continue;
                 const float cs = fabsf(dot3(vs.n, dc)), ct = fabsf(dot3(vt.n, dc));
@@ -422,6 +418,7 @@ DEV void eval_bdpt(const DParams &P, const TablesT &T, MSampler &smp, uint32_t c
                 else pc_i2 = bsdf_pdf_sa(Bt, wot, vt.wi) * ((wot.z == 0.f || vt.wi.z == 0.f) ? 0.f : 1.f) * vt.e_cos / vt.e_len2;
                 if (vs.kind == BK_END_E) pc_r1 = 1.f;
                 else pc_r1 = bsdf_pdf_sa(Bs, wos, vs.wi) * ((wos.z == 0.f || vs.wi.z == 0.f) ? 0.f : 1.f) * vs.e_cos / vs.e_len2;
+                if (direct && s == 1 && t > 1) re_s1 = emitter_direct_pdf_area(T, vt.p, vt.n, Bt.type == 1, vs.p, vs.n, vs.emitter) / em0;
             }
             if (P.exclude_direct && depth <= 2) continue;
 

@@ -7,6 +7,7 @@
 //
 // LDS rows ([row][lane]): chain state [0, NX), NX = S + E + Dd (bdpt_dims_sensor / _emitter / _direct; Dd = 0 with
 // directSampling = false), then the four row groups of eval_bdpt. Splat lists live in HBM (`bd_lists`, slot 0 = current state), unnormalised next to their luminance.
+#include <cstdlib>
 #include "device_bdpt.h"
 #include "kernel_common.h"
 
@@ -118,7 +119,9 @@ __global__ void __launch_bounds__(CHAIN_BLOCK) k_init_chains_bdpt(DParams P, con
     for (uint32_t k = 0; k < Dd; ++k) P.x[(size_t) (S + E + k) * P.n_chains + c] = smp.u_boot(k < nd ? ne + ns + k : 2u * D + k);
 }
 
-__global__ void __launch_bounds__(CHAIN_BLOCK) k_mutate_bdpt(DParams P, uint32_t n_mut, uint32_t mut_base) {
+// FEAT 7: scenes without a BVH -- no traversal stack in LDS (6 KB), which is what keeps four waves on a CU with
+// directSampling = true (35 KB of rows per wave; measured 4.3e7 -> 8e7 mutations/s, all of it occupancy)
+template <int FEAT> __global__ void __launch_bounds__(CHAIN_BLOCK) k_mutate_bdpt(DParams P, uint32_t n_mut, uint32_t mut_base) {
     const uint32_t lane = threadIdx.x;
     const uint32_t c = blockIdx.x * CHAIN_BLOCK + lane;
     const bool live = c < P.n_chains;
@@ -155,7 +158,7 @@ __global__ void __launch_bounds__(CHAIN_BLOCK) k_mutate_bdpt(DParams P, uint32_t
             // Green's reverse path only needs its luminance; it is written over the first-stage list, which is rejected
             // for good by then (acc1 = false) and has already been splatted (see below)
             float *target = stage == 1 ? L2 : L1;
-            eval_bdpt(P, T, smp, cc, NX, target, R);
+            eval_bdpt<FEAT>(P, T, smp, cc, NX, target, R);
             ct.rays += R.nrays;
             const float lum = list_finalize(P, target, R.lum);
             if (stage == 0) {
@@ -308,7 +311,8 @@ __global__ void __launch_bounds__(CHAIN_BLOCK) k_eval_lists_bdpt(DParams P, cons
 }
 
 static size_t bdpt_lds_bytes(const DParams &P) {
-    return ((size_t) P.mmlt_S + P.mmlt_E + P.bd_Dd + 4 * ((size_t) 2 * P.max_depth + 1)) * 64 * sizeof(float);
+    static const size_t pad = getenv("DRMLT_BDPT_LDS_PAD") ? (size_t) atoi(getenv("DRMLT_BDPT_LDS_PAD")) : 0; // diagnostic: occupancy experiments
+    return pad + ((size_t) P.mmlt_S + P.mmlt_E + P.bd_Dd + 4 * ((size_t) 2 * P.max_depth + 1)) * 64 * sizeof(float);
 }
 void launch_bootstrap_bdpt(const DParams &P, uint32_t n, float *lum_out, hipStream_t st) {
     hipLaunchKernelGGL(k_bootstrap_bdpt, dim3((P.n_chains_alloc + CHAIN_BLOCK - 1) / CHAIN_BLOCK), dim3(CHAIN_BLOCK), bdpt_lds_bytes(P), st, P, n, lum_out);
@@ -318,7 +322,9 @@ void launch_init_chains_bdpt(const DParams &P, const uint32_t *seed_index, const
                        seed_lum);
 }
 void launch_mutate_bdpt(const DParams &P, uint32_t n_mut, uint32_t mut_base, hipStream_t st) {
-    hipLaunchKernelGGL(k_mutate_bdpt, dim3((P.n_chains + CHAIN_BLOCK - 1) / CHAIN_BLOCK), dim3(CHAIN_BLOCK), bdpt_lds_bytes(P), st, P, n_mut, mut_base);
+    const dim3 grid((P.n_chains + CHAIN_BLOCK - 1) / CHAIN_BLOCK), block(CHAIN_BLOCK);
+    if (P.use_bvh) hipLaunchKernelGGL(k_mutate_bdpt<15>, grid, block, bdpt_lds_bytes(P), st, P, n_mut, mut_base);
+    else hipLaunchKernelGGL(k_mutate_bdpt<7>, grid, block, bdpt_lds_bytes(P), st, P, n_mut, mut_base);
 }
 void launch_eval_lists_bdpt(const DParams &P, const float *u, uint32_t n, uint32_t dim, float *out, uint32_t stride, hipStream_t st) {
     hipLaunchKernelGGL(k_eval_lists_bdpt, dim3((P.n_chains_alloc + CHAIN_BLOCK - 1) / CHAIN_BLOCK), dim3(CHAIN_BLOCK), bdpt_lds_bytes(P), st, P, u, n, dim, out,
