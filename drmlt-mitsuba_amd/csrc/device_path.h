@@ -382,6 +382,24 @@ struct Hit {
     float t, u, v;
 };
 
+// Records fetched per lane from device memory, read through a GLOBAL-address-space pointer whatever the origin of `p`:
+// a pointer that passed through a copied parameter block (k_mutate_v4's per-section copies) is generic to the compiler,
+// which then emits FLAT loads -- both wait counters, the LDS aperture check. T: 16-byte multiple in a 16-byte aligned array.
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+template <class T> DEV T load_global16(const T *p) {
+    static_assert(sizeof(T) % 16 == 0, "records are read in 16-byte words");
+    typedef const u32x4_t __attribute__((address_space(1))) *GQ;
+    const GQ q = (GQ) (uintptr_t) p;
+    union { T v; u32x4_t w[sizeof(T) / 16]; } u;
+#pragma unroll
+    for (unsigned i = 0; i < sizeof(T) / 16u; ++i) u.w[i] = q[i];
+    return u.v;
+}
+DEV float load_global_f32(const float *p) { return *(const float __attribute__((address_space(1))) *) (uintptr_t) p; }
+DEV void atomic_add_global_f32(float *p, float v) { // no-return float add on device memory (global_atomic_add_f32)
+    (void) __hip_atomic_fetch_add((float __attribute__((address_space(1))) *) (uintptr_t) p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // One primitive against one ray. `P` is wave-uniform in the brute-force loop (SGPR operands).
 // Flat primitives are branch-free (selects only): no exec-mask traffic in the hot loop.
 template <int FEAT = 15> DEV void intersect_prim(const DPrim &P, int idx, f3 o, f3 d, float tmin, Hit &h) {
@@ -493,6 +511,7 @@ struct Trav {
     int cur, sp;      // cur >= 0 inner node, < 0 leaf reference
     bool active, any_hit;
     uint32_t n_nodes, n_prims; // fetched so far by this lane (k_mutate_v4 reports them: the scene part of the algorithmic bytes)
+    uint32_t it_inner, it_leaf; // wave-uniform: traversal iterations of each kind (lane occupancy = n_nodes / (64 it_inner) ...)
 };
 
 DEV void trav_begin(Trav &T, f3 o, f3 d, float tmin, float tmax, bool any_hit) {
@@ -504,7 +523,7 @@ DEV void trav_begin(Trav &T, f3 o, f3 d, float tmin, float tmax, bool any_hit) {
     T.cur = 0; T.sp = 0;
     T.active = true; T.any_hit = any_hit;
 }
-DEV void trav_reset_counters(Trav &T) { T.n_nodes = T.n_prims = 0u; }
+DEV void trav_reset_counters(Trav &T) { T.n_nodes = T.n_prims = T.it_inner = T.it_leaf = 0u; }
 
 DEV unsigned umin2(unsigned a, unsigned b) { return a < b ? a : b; }
 DEV unsigned umax2(unsigned a, unsigned b) { return a < b ? b : a; }
@@ -525,8 +544,9 @@ template <class StackT, class PT> DEV void trav_run(const PT &P, Trav &T, bool m
         if (yield_lanes > 0 && finished >= yield_lanes) break;
         bool done_now = false;
         if (__popcll(m_inner) >= __popcll(m_leaf)) {
+            T.it_inner++;
             if (run && T.cur >= 0) {
-                const DBvh4Node &N = P.bvh[T.cur];
+                const DBvh4Node N = load_global16(P.bvh + T.cur);
                 T.n_nodes++;
                 unsigned key[4];
 #pragma unroll
@@ -554,11 +574,15 @@ template <class StackT, class PT> DEV void trav_run(const PT &P, Trav &T, bool m
                 else T.cur = stk[--T.sp * 64];
             }
         } else {
+            T.it_leaf++;
             if (run && T.cur < 0) {
                 // leaf reference: ~(first << shift | count); shift = 0 when every leaf holds one primitive (the default build)
                 const int first = ~T.cur >> P.bvh_leaf_shift, n = P.bvh_leaf_shift ? (~T.cur & 7) : 1;
                 T.n_prims += (uint32_t) n;
-                for (int i = 0; i < n; ++i) intersect_prim(P.prims[first + i], P.prims[first + i].shade, T.o, T.d, T.tmin, T.h);
+                for (int i = 0; i < n; ++i) {
+                    const DPrim G = load_global16(P.prims + first + i);
+                    intersect_prim(G, G.shade, T.o, T.d, T.tmin, T.h);
+                }
                 if ((T.any_hit && T.h.prim >= 0) || T.sp == 0) { T.active = false; done_now = true; }
                 else T.cur = stk[--T.sp * 64];
             }
@@ -669,10 +693,10 @@ template <int FEAT = 15> DEV Hit trace(const DParams &P, f3 o, f3 d, float tmin,
 // at one wave per SIMD); large scenes read them from HBM/L2.
 struct GlobalTables {
     const DShade *sh; const DBsdf *bs; const DEmitter *em;
-    DEV DShade shade(int i) const { return sh[i]; }
-    DEV DBsdf bsdf(int i) const { return bs[i]; }
-    DEV DEmitter emitter(int i) const { return em[i]; }
-    DEV float emitter_cdf_lo(int i) const { return em[i].cdf_lo; }
+    DEV DShade shade(int i) const { return load_global16(sh + i); }
+    DEV DBsdf bsdf(int i) const { return load_global16(bs + i); }
+    DEV DEmitter emitter(int i) const { return load_global16(em + i); }
+    DEV float emitter_cdf_lo(int i) const { return load_global_f32(&em[i].cdf_lo); }
 };
 struct LdsTables {
     uint32_t shade_off, bsdf_off, emit_off; // float offsets into lds_x, multiples of 4

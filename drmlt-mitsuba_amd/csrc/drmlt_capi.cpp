@@ -806,6 +806,12 @@ int drmlt_stats_get(drmlt_ctx *ctx, drmlt_stats *o) {
                 v[16], v[17], v[18], v[19], v[20], v[21]),
         fprintf(stderr, "[drmlt stamps] mh sections: decide+splat %llu commit %llu start %llu fill %llu\n", v[22], v[23], v[24], v[25]),
         fprintf(stderr, "[drmlt stamps] iterations by chains tracing (of 32): 0: %llu, 1-4: %llu, 5-8: %llu, 9-16: %llu, 17-24: %llu, 25-32: %llu\n", v[26], v[27], v[28], v[29], v[30], v[31]);
+    if (getenv("DRMLT_VERBOSE") && v[12])
+        fprintf(stderr, "[drmlt bvh] wave iterations: inner %llu (%.1f lanes each), leaf %llu (%.1f lanes each)\n", v[12], (double) v[10] / (double) v[12], v[13],
+                v[13] ? (double) v[11] / (double) v[13] : 0.0);
+    if ((ctx->P.debug & 1024) && v[20])
+        fprintf(stderr, "[drmlt bvh] lanes at slice start, of 64: tracing %.1f, chain waiting for its partner %.1f, chain parked for bookkeeping %.1f, helper idle %.1f, flush %.1f (%llu slices)\n",
+                (double) v[21] / v[20], (double) v[22] / v[20], (double) v[23] / v[20], (double) v[24] / v[20], (double) v[25] / v[20], v[20]);
     memset(o, 0, sizeof *o);
     const uint64_t M = ctx->mutations;
     const uint64_t n_large = v[0], acc1_l = v[1], acc1_b = v[2], sec_l = v[3], sec_b = v[4], acc2_l = v[5], acc2_b = v[6], n_rev = v[7];

@@ -13,15 +13,23 @@
 
 #include "kernel_common.h"
 
+// Bootstrap sample `index` of the replayable stream. ONE compiled body serves k_bootstrap and k_init_chains: the replay is
+// checked for EQUALITY with the bootstrap luminance (drmlt_proc.cpp:509-512), and two inlined copies of the same source
+// may be contracted / scheduled differently by the compiler -- a rounding difference that flips one discrete decision in
+// one of 1e5 paths fails the seeding.
+__device__ __attribute__((noinline)) DSplat eval_boot_sample(const DParams &P, uint32_t index, uint32_t &nd) {
+    Sampler smp;
+    smp.key0 = P.key0; smp.key1 = P.key1; smp.chain = P.boot_stream; smp.major = index;
+    smp.mode = SM_BOOT; smp.type = P.type; smp.large = false; smp.sigma2 = P.sigma2; smp.lane = 0u; smp.arr = nullptr;
+    uint32_t nr;
+    return eval_path(P, smp, nr, nd);
+}
+
 __global__ void __launch_bounds__(64) k_bootstrap(DParams P, uint32_t n, float *lum_out) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    Sampler smp;
-    smp.key0 = P.key0; smp.key1 = P.key1; smp.chain = P.boot_stream; smp.major = i;
-    smp.mode = SM_BOOT; smp.type = P.type; smp.large = false; smp.sigma2 = P.sigma2; smp.lane = 0u; smp.arr = nullptr;
-    uint32_t nr, nd;
-    DSplat s = eval_path(P, smp, nr, nd);
-    lum_out[i] = s.lum;
+    uint32_t nd;
+    lum_out[i] = eval_boot_sample(P, i, nd).lum;
 }
 
 __global__ void __launch_bounds__(64) k_init_chains(DParams P, const uint32_t *seed_index, const float *seed_lum) {
@@ -30,8 +38,8 @@ __global__ void __launch_bounds__(64) k_init_chains(DParams P, const uint32_t *s
     Sampler smp;
     smp.key0 = P.key0; smp.key1 = P.key1; smp.chain = P.boot_stream; smp.major = seed_index[c];
     smp.mode = SM_BOOT; smp.type = P.type; smp.large = false; smp.sigma2 = P.sigma2; smp.lane = 0u; smp.arr = nullptr;
-    uint32_t nr, nd;
-    DSplat s = eval_path(P, smp, nr, nd);
+    uint32_t nd;
+    DSplat s = eval_boot_sample(P, smp.major, nd);
     // sanity check of drmlt_proc.cpp:509-512: same function, same inputs -> bit-equal on the device
     if (!(s.lum == seed_lum[c])) atomicExch(P.error_flag, 1);
     normalize_splat(s, P);
@@ -797,7 +805,7 @@ DEV void film_put_channel(const DParams &P, float px, float py, float v, int ch)
         for (int x = minx; x <= maxx; ++x) {
             const int ix = min((int) fabsf(((float) x - posx) * P.filter_scale), 31);
             float w = (box ? (ix < 31 ? P.box_weight : 0.f) : P.filter_lut[ix]) * wy;
-            atomicAdd(P.film + ((size_t) y * P.width + x) * 3 + ch, w * v);
+            atomic_add_global_f32(P.film + ((size_t) y * P.width + x) * 3 + ch, w * v);
         }
     }
 }
@@ -919,6 +927,7 @@ __global__ void __launch_bounds__(CHAIN_BLOCK) k_mutate_v4(DParams P, uint32_t n
     unsigned long long t_mh = 0, t_trace = 0, t_step = 0, n_iter = 0, n_mh = 0, n_busy = 0;
     unsigned long long t_decide = 0, t_commit = 0, t_start = 0, t_fill = 0;
     unsigned long long hist[6] = {0, 0, 0, 0, 0, 0};
+    unsigned long long dg[6] = {0, 0, 0, 0, 0, 0};
 #define STAMP() (stamps ? __builtin_amdgcn_s_memtime() : 0ull)
     for (;;) {
         const bool parked = ps.phase == PH_DONE;
@@ -1116,6 +1125,11 @@ __global__ void __launch_bounds__(CHAIN_BLOCK) k_mutate_v4(DParams P, uint32_t n
             // or `trace_yield` lanes have finished theirs. A chain lane steps when its own ray AND its partner's shadow
             // ray (of the previous vertex) are both done; everybody else just keeps traversing next time round.
             if (prio) __builtin_amdgcn_s_setprio(0);
+            if (P.debug & 1024) { // diagnostic: where the 64 lanes are when a traversal slice starts
+                dg[0]++; dg[1] += __popcll(__ballot(rstate == 1 || rstate == 2)); dg[2] += __popcll(__ballot(!helper && rstate == 3));
+                dg[3] += __popcll(__ballot(!helper && ps.phase == PH_DONE)); dg[4] += __popcll(__ballot(helper && rstate == 0));
+                dg[5] += __popcll(__ballot(!helper && ps.phase == PH_FLUSH));
+            }
             {
                 SECTION_PARAMS(Pt);
                 if (rstate == 1) { trav_begin(T, ps.o, ps.d, ps.tmin, ps.tmax, helper); rstate = 2; }
@@ -1185,7 +1199,9 @@ __global__ void __launch_bounds__(CHAIN_BLOCK) k_mutate_v4(DParams P, uint32_t n
         for (int i = 0; i < 9; ++i) atomicAdd(P.stats + i, v[i]);
     if (RESUMABLE) {
         const unsigned long long nn = wave_sum(T.n_nodes), np = wave_sum(T.n_prims);
-        if (lane == 0) { atomicAdd(P.stats + 10, nn); atomicAdd(P.stats + 11, np); }
+        if (lane == 0) { atomicAdd(P.stats + 10, nn); atomicAdd(P.stats + 11, np); atomicAdd(P.stats + 12, (unsigned long long) T.it_inner); atomicAdd(P.stats + 13, (unsigned long long) T.it_leaf); }
+        if ((P.debug & 1024) && lane == 0)
+            for (int q = 0; q < 6; ++q) atomicAdd(P.stats + 20 + q, dg[q]);
     }
 }
 
