@@ -534,7 +534,7 @@ DEV unsigned umax2(unsigned a, unsigned b) { return a < b ? b : a; }
 // the LDS, which is what lets k_mutate_v4 keep 8 waves per CU on BVH scenes (measured: 1.13e8 -> 2.0e8 mutations/s on the
 // 2000-triangle soup, all of it occupancy).
 template <class StackT, class PT> DEV void trav_run(const PT &P, Trav &T, bool mine, int yield_lanes) {
-    __shared__ StackT bvh_stack[BVH_STACK * 64];
+    __shared__ StackT bvh_stack[(BVH_STACK + 2) * 64]; // + 2: the branch-free pushes write one or two entries above the top
     StackT *const stk = bvh_stack + (threadIdx.x & 63u); // every kernel that traces runs one wave per workgroup
     int finished = 0;
     for (;;) {
@@ -543,11 +543,47 @@ template <class StackT, class PT> DEV void trav_run(const PT &P, Trav &T, bool m
         if (!m_inner && !m_leaf) break;
         if (yield_lanes > 0 && finished >= yield_lanes) break;
         bool done_now = false;
-        if (__popcll(m_inner) >= __popcll(m_leaf)) {
+        if (__popcll(m_inner) * P.trace_vote >= __popcll(m_leaf) * 16) { // a leaf test costs about 0.4 node tests: see drmlt_capi.cpp
             T.it_inner++;
             if (run && T.cur >= 0) {
                 const DBvh4Node N = load_global16(P.bvh + T.cur);
                 T.n_nodes++;
+                if constexpr (sizeof(StackT) == 2) {
+                    // 16-bit child references: the sort key carries the child itself -- entry distance in the upper half (its bit
+                    // pattern orders like an unsigned: tn >= tmin >= 0; 7 mantissa bits are plenty for an ORDER), reference in
+                    // the lower half. Everything below is selects: no exec-mask traffic, no branches but the pop.
+                    typedef float f2 __attribute__((ext_vector_type(2)));
+                    const f2 ix = {T.inv.x, T.inv.x}, iy = {T.inv.y, T.inv.y}, iz = {T.inv.z, T.inv.z};
+                    const f2 ox = {T.oi.x, T.oi.x}, oy = {T.oi.y, T.oi.y}, oz = {T.oi.z, T.oi.z};
+                    unsigned key[4];
+#pragma unroll
+                    for (int h2 = 0; h2 < 2; ++h2) { // children (0, 1), then (2, 3): v_pk_fma_f32
+                        const int c = 2 * h2;
+                        const f2 t0x = __builtin_elementwise_fma((f2){N.lox[c], N.lox[c + 1]}, ix, ox), t1x = __builtin_elementwise_fma((f2){N.hix[c], N.hix[c + 1]}, ix, ox);
+                        const f2 t0y = __builtin_elementwise_fma((f2){N.loy[c], N.loy[c + 1]}, iy, oy), t1y = __builtin_elementwise_fma((f2){N.hiy[c], N.hiy[c + 1]}, iy, oy);
+                        const f2 t0z = __builtin_elementwise_fma((f2){N.loz[c], N.loz[c + 1]}, iz, oz), t1z = __builtin_elementwise_fma((f2){N.hiz[c], N.hiz[c + 1]}, iz, oz);
+#pragma unroll
+                        for (int q = 0; q < 2; ++q) {
+                            const float tn = fmaxf(fmaxf(fmaxf(fminf(t0x[q], t1x[q]), fminf(t0y[q], t1y[q])), fminf(t0z[q], t1z[q])), T.tmin);
+                            const float tf = fminf(fminf(fminf(fmaxf(t0x[q], t1x[q]), fmaxf(t0y[q], t1y[q])), fmaxf(t0z[q], t1z[q])), T.h.t);
+                            const unsigned kk = (__float_as_uint(tn) & 0xffff0000u) | ((unsigned) N.child[c + q] & 0xffffu);
+                            key[c + q] = tn <= tf ? kk : 0xffffffffu;
+                        }
+                    }
+                    // sorting network (0,1)(2,3)(0,2)(1,3)(1,2)
+                    const unsigned a0 = umin2(key[0], key[1]), a1 = umax2(key[0], key[1]), a2 = umin2(key[2], key[3]), a3 = umax2(key[2], key[3]);
+                    const unsigned b0 = umin2(a0, a2), b2 = umax2(a0, a2), b1 = umin2(a1, a3), b3 = umax2(a1, a3);
+                    const unsigned k0 = b0, k1 = umin2(b1, b2), k2 = umax2(b1, b2), k3 = b3;
+                    // far ones first, so that the nearest pending child ends on top; a write above the top of the stack is harmless
+                    int sp = T.sp;
+                    stk[sp * 64] = (StackT) k3; sp += k3 != 0xffffffffu ? 1 : 0;
+                    stk[sp * 64] = (StackT) k2; sp += k2 != 0xffffffffu ? 1 : 0;
+                    stk[sp * 64] = (StackT) k1; sp += k1 != 0xffffffffu ? 1 : 0;
+                    T.sp = sp;
+                    if (k0 != 0xffffffffu) T.cur = (int) (short) (k0 & 0xffffu);
+                    else if (sp == 0) { T.active = false; done_now = true; }
+                    else T.cur = stk[--T.sp * 64];
+                } else {
                 unsigned key[4];
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
@@ -572,6 +608,7 @@ template <class StackT, class PT> DEV void trav_run(const PT &P, Trav &T, bool m
                 if (k0 != 0xffffffffu) T.cur = child_of(k0);
                 else if (T.sp == 0) { T.active = false; done_now = true; }
                 else T.cur = stk[--T.sp * 64];
+                }
             }
         } else {
             T.it_leaf++;

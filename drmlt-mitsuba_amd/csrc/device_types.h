@@ -136,6 +136,7 @@ struct DParams {
     int32_t bvh_leaf_shift;      // 0: one primitive per leaf, ~child = slot; 3: ~child = slot << 3 | count
     int32_t bvh_stack16;         // every stack entry fits a short: k_mutate_v4 runs its 16-bit-stack variant
     int32_t trace_yield;         // k_mutate_v4 on BVH scenes: a traversal slice ends once this many lanes have finished their ray
+    int32_t trace_vote;          // traversal: the wave tests nodes when 16 * (lanes at a leaf) <= trace_vote * (lanes at a node), leaves otherwise
 };
 
 // result of one PSS evaluation, SoA-friendly

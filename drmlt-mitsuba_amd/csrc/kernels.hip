@@ -1292,7 +1292,8 @@ void launch_mutate(const DParams &P, uint32_t n_mut, uint32_t mut_base, hipStrea
             else if (P.bvh_stack16) hipLaunchKernelGGL((k_mutate_v4<15, true, false, true>), g4, block, lds, st, P, n_mut, mut_base);
             else hipLaunchKernelGGL((k_mutate_v4<15, true, false>), g4, block, lds, st, P, n_mut, mut_base);
         } else {
-            if (P.bvh_stack16) hipLaunchKernelGGL((k_mutate_v4<15, false, false, true>), g4, block, lds, st, P, n_mut, mut_base);
+            if (P.bvh_stack16 && (P.debug & 128)) hipLaunchKernelGGL((k_mutate_v4<15, false, true, true>), g4, block, lds, st, P, n_mut, mut_base); // diagnostic stamps
+            else if (P.bvh_stack16) hipLaunchKernelGGL((k_mutate_v4<15, false, false, true>), g4, block, lds, st, P, n_mut, mut_base);
             else hipLaunchKernelGGL((k_mutate_v4<15, false, false>), g4, block, lds, st, P, n_mut, mut_base);
         }
     } else if (P.kernel_variant == 3) { // 32 chains per wave, rows of 32 floats
