@@ -584,30 +584,33 @@ template <class StackT, class PT> DEV void trav_run(const PT &P, Trav &T, bool m
                     else if (sp == 0) { T.active = false; done_now = true; }
                     else T.cur = stk[--T.sp * 64];
                 } else {
-                unsigned key[4];
+                    // 32-bit child references: the key carries the SLOT in its two low mantissa bits; selects pick the child
+                    unsigned key[4];
 #pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const float t0x = fmaf(N.lox[c], T.inv.x, T.oi.x), t1x = fmaf(N.hix[c], T.inv.x, T.oi.x);
-                    const float t0y = fmaf(N.loy[c], T.inv.y, T.oi.y), t1y = fmaf(N.hiy[c], T.inv.y, T.oi.y);
-                    const float t0z = fmaf(N.loz[c], T.inv.z, T.oi.z), t1z = fmaf(N.hiz[c], T.inv.z, T.oi.z);
-                    const float tn = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fmaxf(fminf(t0z, t1z), T.tmin));
-                    const float tf = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fminf(fmaxf(t0z, t1z), T.h.t));
-                    // entry distance >= tmin >= 0: its bit pattern orders like an unsigned; the two low mantissa bits carry the slot
-                    key[c] = tn <= tf ? ((__float_as_uint(tn) & 0x7ffffffcu) | (unsigned) c) : 0xffffffffu;
-                }
-                // sorting network (0,1)(2,3)(0,2)(1,3)(1,2)
-                unsigned a0 = umin2(key[0], key[1]), a1 = umax2(key[0], key[1]), a2 = umin2(key[2], key[3]), a3 = umax2(key[2], key[3]);
-                const unsigned b0 = umin2(a0, a2), b2 = umax2(a0, a2), b1 = umin2(a1, a3), b3 = umax2(a1, a3);
-                const unsigned k0 = b0, k1 = umin2(b1, b2), k2 = umax2(b1, b2), k3 = b3;
-                const int c0 = N.child[0], c1 = N.child[1], c2 = N.child[2], c3 = N.child[3];
-                auto child_of = [&](unsigned k) { const unsigned sl = k & 3u; return sl == 0u ? c0 : (sl == 1u ? c1 : (sl == 2u ? c2 : c3)); };
-                // far ones first, so that the nearest pending child is on top
-                if (k3 != 0xffffffffu) { stk[T.sp * 64] = (StackT) child_of(k3); T.sp++; }
-                if (k2 != 0xffffffffu) { stk[T.sp * 64] = (StackT) child_of(k2); T.sp++; }
-                if (k1 != 0xffffffffu) { stk[T.sp * 64] = (StackT) child_of(k1); T.sp++; }
-                if (k0 != 0xffffffffu) T.cur = child_of(k0);
-                else if (T.sp == 0) { T.active = false; done_now = true; }
-                else T.cur = stk[--T.sp * 64];
+                    for (int c = 0; c < 4; ++c) {
+                        const float t0x = fmaf(N.lox[c], T.inv.x, T.oi.x), t1x = fmaf(N.hix[c], T.inv.x, T.oi.x);
+                        const float t0y = fmaf(N.loy[c], T.inv.y, T.oi.y), t1y = fmaf(N.hiy[c], T.inv.y, T.oi.y);
+                        const float t0z = fmaf(N.loz[c], T.inv.z, T.oi.z), t1z = fmaf(N.hiz[c], T.inv.z, T.oi.z);
+                        const float tn = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fmaxf(fminf(t0z, t1z), T.tmin));
+                        const float tf = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fminf(fmaxf(t0z, t1z), T.h.t));
+                        key[c] = tn <= tf ? ((__float_as_uint(tn) & 0x7ffffffcu) | (unsigned) c) : 0xffffffffu;
+                    }
+                    const unsigned a0 = umin2(key[0], key[1]), a1 = umax2(key[0], key[1]), a2 = umin2(key[2], key[3]), a3 = umax2(key[2], key[3]);
+                    const unsigned b0 = umin2(a0, a2), b2 = umax2(a0, a2), b1 = umin2(a1, a3), b3 = umax2(a1, a3);
+                    const unsigned k0 = b0, k1 = umin2(b1, b2), k2 = umax2(b1, b2), k3 = b3;
+                    const int c0 = N.child[0], c1 = N.child[1], c2 = N.child[2], c3 = N.child[3];
+                    auto child_of = [&](unsigned k) {
+                        const int lo = (k & 1u) ? c1 : c0, hi = (k & 1u) ? c3 : c2;
+                        return (k & 2u) ? hi : lo;
+                    };
+                    int sp = T.sp;
+                    stk[sp * 64] = (StackT) child_of(k3); sp += k3 != 0xffffffffu ? 1 : 0;
+                    stk[sp * 64] = (StackT) child_of(k2); sp += k2 != 0xffffffffu ? 1 : 0;
+                    stk[sp * 64] = (StackT) child_of(k1); sp += k1 != 0xffffffffu ? 1 : 0;
+                    T.sp = sp;
+                    if (k0 != 0xffffffffu) T.cur = child_of(k0);
+                    else if (sp == 0) { T.active = false; done_now = true; }
+                    else T.cur = stk[--T.sp * 64];
                 }
             }
         } else {
