@@ -1287,6 +1287,7 @@ void launch_mutate(const DParams &P, uint32_t n_mut, uint32_t mut_base, hipStrea
         if (P.tables_in_lds) {
             if (P.features == 0 && (P.debug & 128)) hipLaunchKernelGGL((k_mutate_v4<0, true, true>), g4, block, lds, st, P, n_mut, mut_base);
             else if (P.features == 0) hipLaunchKernelGGL((k_mutate_v4<0, true, false>), g4, block, lds, st, P, n_mut, mut_base);
+            else if ((P.features & ~3) == 0 && (P.debug & 128)) hipLaunchKernelGGL((k_mutate_v4<3, true, true>), g4, block, lds, st, P, n_mut, mut_base); // diagnostic stamps
             else if ((P.features & ~3) == 0) hipLaunchKernelGGL((k_mutate_v4<3, true, false>), g4, block, lds, st, P, n_mut, mut_base);
             else if ((P.features & 8) == 0) hipLaunchKernelGGL((k_mutate_v4<7, true, false>), g4, block, lds, st, P, n_mut, mut_base);
             else if (P.bvh_stack16) hipLaunchKernelGGL((k_mutate_v4<15, true, false, true>), g4, block, lds, st, P, n_mut, mut_base);
