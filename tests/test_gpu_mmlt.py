@@ -174,6 +174,6 @@ def test_refused_configurations(pkg, native_lib):
     for kw, msg in ((dict(technique="mmlt", max_depth=-1), "no max depth"),
                     (dict(technique="path", max_depth=5, fix_emitter_path=1), "fixEmitterPath without MMLT"),
                     (dict(technique="mmlt", max_depth=5, timid_after_large=1), "timidAfterLarge"),
-                    (dict(technique="bdpt", max_depth=5), "bdpt")):
+                    (dict(technique="bdpt", max_depth=5, timid_after_large=1), "bdpt")):
         with pytest.raises(pkg.DrmltError, match=msg):
             pkg.Context(pkg.abi.make_config(work_units=64, **kw), sd)
