@@ -312,16 +312,26 @@ DEV void eval_bdpt(const DParams &P, const TablesT &T, MSampler &smp, uint32_t c
     if (direct && nE >= 3)
         re_walk = emitter_direct_pdf_area(T, vpos(1), vnrm(1), vrefn_zero(1), vpos(0), vnrm(0), __float_as_int(W.f(BV_EMIT, 0))) / em0_fwd;
     float em0 = em0_fwd;     // pImp[1]; the s = 1 direct strategy swaps in its own emitter sample
+    // Canonical order: the wave walks ONE (s, t) grid, every lane taking the cells its own subpaths reach. For each chain
+    // that is the reference's order (s and t descending, :373-380), so the direct sampler's components and the light-image
+    // splats come out in the same sequence -- but s, t and k are wave-uniform: one strategy branch per iteration, uniform
+    // trip counts in the two sweeps of miWeight, scalar slot arithmetic. (Per-lane loops over each chain's own range ran
+    // the same number of iterations, the longest chain's, with every branch populated in most of them.)
 #pragma nounroll
-    for (int s = nE - 1; s >= 0; --s) {
+    for (int s = ME; s >= 0; --s) {
+        const bool has_s = s <= nE - 1;
+        if (!__builtin_amdgcn_ballot_w64(has_s)) continue;
         BVert vs;
         f3 thr_s = mk3(1.f, 1.f, 1.f);
-        if (s >= 1) W.get(s - 1, vs, thr_s);
-        vs.degenerate = s >= 1 ? (flags(s - 1) & BF_DEGEN) != 0u : false;
-        int minT = max(2 - s, P.light_image ? 0 : 2), maxT = min(nS - 1, P.max_depth + 1 - s);
+        vs.p = vs.n = vs.s = vs.wi = mk3(0.f, 0.f, 0.f); vs.e_len2 = vs.e_cos = 0.f; vs.kind = BK_SURF; vs.bsdf = 0; vs.emitter = -1; vs.shade = 0;
+        if (s >= 1 && has_s) W.get(s - 1, vs, thr_s);
+        vs.degenerate = (s >= 1 && has_s) ? (flags(s - 1) & BF_DEGEN) != 0u : false;
+        int minT = max(2 - s, P.light_image ? 0 : 2);
+        const int maxT = min(MS, P.max_depth + 1 - s);
         if (minT < 1) minT = 1; // t = 0 needs a sensor that can be hit: a pinhole cannot (vertex.cpp:1405-1413)
 #pragma nounroll
         for (int t = maxT; t >= minT; --t) {
+            if (!has_s || t > nS - 1) continue;
             BVert vt;
             f3 thr_t;
             W.get(ME + t - 1, vt, thr_t);
