@@ -46,10 +46,10 @@ CONFIGS = {
               kernel="k_mutate_mmlt", pmc="r02_c5_pmc.json",
               what="glass caustic (dielectric sphere, small sphere light) %(res)dx%(res)d, drmlt technique=mmlt type=orbital "
                    "fixEmitterPath acceptanceMap, %(chains)d chains/GPU, sampleCount %(spp)d (BASELINE.json configs[4])"),
-    "bdpt": dict(scene=("cornell_c2", {}), res=256, cfg=dict(technique="bdpt", type="orbital", max_depth=8, rr_depth=5),
+    "bdpt": dict(scene=("cornell_c2", {}), res=512, cfg=dict(technique="bdpt", type="orbital", max_depth=8, rr_depth=5),
                  spp=64, kernel="k_mutate_bdpt", pmc="r02_bdpt_pmc.json",
                  what="Cornell box %(res)dx%(res)d, drmlt technique=bdpt type=orbital, %(chains)d chains/GPU, sampleCount %(spp)d"),
-    "soup": dict(scene=("triangle_soup", dict(n_tris=2000)), res=256,
+    "soup": dict(scene=("triangle_soup", dict(n_tris=2000)), res=512,
                  cfg=dict(technique="path", type="orbital", max_depth=8, rr_depth=5), spp=64, kernel="k_mutate_v4",
                  pmc="r02_soup_pmc.json",
                  what="closed room with 2000 random triangles (BVH in HBM) %(res)dx%(res)d, drmlt technique=path type=orbital, "

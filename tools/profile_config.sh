@@ -8,7 +8,7 @@ rt=$1; shift
 for cfg in "$@"; do
   case $cfg in
     2|3|5) muts=$((512*512*64)); name=c$cfg;;
-    *) muts=$((256*256*64)); name=$cfg;;
+    *) muts=$((512*512*64)); name=$cfg;;
   esac
   cmd="python3 $R/bench.py --config $cfg --steps 1 --warmup 0 --spp 64 --no-cpu-baseline --no-quality"
   echo "== $cfg: kernel trace" >> $R/gpurun_out/profile_progress.txt
