@@ -130,6 +130,7 @@ template <int FEAT> __global__ void __launch_bounds__(CHAIN_BLOCK) k_mutate_bdpt
     for (uint32_t k = 0; k < NX; ++k) lds_x[k * 64u + lane] = P.x[(size_t) k * P.n_chains + cc];
     float cur_lum = P.cur_lum[cc];
     float *L0 = list_col(P, 0, cc), *L1 = list_col(P, 1, cc), *L2 = list_col(P, 2, cc);
+    float cum = 0.f; // weight the current state has gathered since it was adopted
 
     MSampler smp;
     bsampler_setup(smp, P, lane);
@@ -227,17 +228,28 @@ template <int FEAT> __global__ void __launch_bounds__(CHAIN_BLOCK) k_mutate_bdpt
         }
         const bool y_splatted = !mix && P.type == 0 && doSecond && !lum_invalid(z_lum); // Green went on to the reverse move
 
+        // Expectation weights. The current state's share is accumulated and its list splatted once, when the state is
+        // replaced or the launch ends (the reference's pssmlt loop does the same, pssmlt_proc.cpp:205-228): the same film,
+        // one list splat per mutation instead of two or three. Acceptance-map runs keep one splat per event.
         if (!mix) {
             float w1 = a1, w2 = (1.f - a1) * a2, w0 = 1.f - w1 - w2;
             if (!amap) {
-                list_splat(P, L0, cur_lum, w0);
-                if (!y_splatted) list_splat(P, L1, y_lum, w1);
-                if (doSecond) list_splat(P, L2, z_lum, w2);
+                cum += w0;
+                if (acc1 || acc2) { list_splat(P, L0, cur_lum, cum); cum = acc1 ? w1 : w2; }
+                if (!acc1 && !y_splatted) list_splat(P, L1, y_lum, w1);
+                if (doSecond && !acc2) list_splat(P, L2, z_lum, w2);
             }
         } else {
             const float a = doSecond ? a2 : a1;
-            list_splat(P, L0, cur_lum, 1.f - a);
-            if (doSecond) list_splat(P, L2, z_lum, a); else list_splat(P, L1, y_lum, a);
+            if (amap) {
+                list_splat(P, L0, cur_lum, 1.f - a);
+                if (doSecond) list_splat(P, L2, z_lum, a); else list_splat(P, L1, y_lum, a);
+            } else {
+                cum += 1.f - a;
+                if (acc1 || acc2) { list_splat(P, L0, cur_lum, cum); cum = a; }
+                else if (doSecond) list_splat(P, L2, z_lum, a);
+                else list_splat(P, L1, y_lum, a);
+            }
         }
 
         if (large) {
@@ -260,7 +272,7 @@ template <int FEAT> __global__ void __launch_bounds__(CHAIN_BLOCK) k_mutate_bdpt
                     if (smp.type == 2 && (k & 1u)) smp.pair_base = 0xffffffffu;
                 }
             }
-            list_copy(P, L0, acc1 ? L1 : L2);
+            { float *t = L0; if (acc1) { L0 = L1; L1 = t; } else { L0 = L2; L2 = t; } } // the accepted list becomes the current one: swap, do not copy
             cur_lum = acc1 ? y_lum : z_lum;
             if (amap) {
                 if (acc1) { if (!large && !mix) list_splat_const(P, L0, mk3(1.f, 0.f, 0.f)); }
@@ -270,6 +282,8 @@ template <int FEAT> __global__ void __launch_bounds__(CHAIN_BLOCK) k_mutate_bdpt
     }
 
     if (live) {
+        if (!amap) list_splat(P, L0, cur_lum, cum); // "perform the last splat"
+        if (L0 != list_col(P, 0, cc)) list_copy(P, list_col(P, 0, cc), L0); // slot 0 is where the next launch (and drmlt_chain_state) look
         for (uint32_t k = 0; k < NX; ++k) P.x[(size_t) k * P.n_chains + c] = lds_x[k * 64u + lane];
         P.cur_lum[c] = cur_lum;
     }
