@@ -41,7 +41,9 @@ CONFIGS = {
               spp=64, kernel="k_mutate_v4", pmc="r02_c3_pmc.json",
               what="door scene (occluded area light, rough-conductor floor) %(res)dx%(res)d, drmlt technique=path type=green, "
                    "%(chains)d chains/GPU, sampleCount %(spp)d (BASELINE.json configs[2])"),
-    "5": dict(scene=("caustic_c5", {}), res=512,
+    # 131 072 chains: k_mutate_mmlt runs one chain per lane at 256 VGPRs, so 65 536 chains are 1024 waves = one per SIMD;
+    # twice as many put two on a SIMD (7.3e8 -> 1.31e9 mutations/s). BASELINE's config 5 does not fix the chain count.
+    "5": dict(scene=("caustic_c5", {}), res=512, chains=131072,
               cfg=dict(technique="mmlt", type="orbital", max_depth=6, fix_emitter_path=1, acceptance_map=1), spp=64,
               kernel="k_mutate_mmlt", pmc="r02_c5_pmc.json",
               what="glass caustic (dielectric sphere, small sphere light) %(res)dx%(res)d, drmlt technique=mmlt type=orbital "
@@ -142,7 +144,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--config", default="2", choices=sorted(CONFIGS))
     ap.add_argument("--res", type=int, default=0, help="film size (default: the configuration's)")
-    ap.add_argument("--chains", type=int, default=65536)
+    ap.add_argument("--chains", type=int, default=None, help="chains per GPU (default: the configuration's own, 65536 unless noted)")
     ap.add_argument("--spp", type=int, default=0, help="mutations per pixel per step (sampleCount)")
     ap.add_argument("--type", default="")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -152,6 +154,8 @@ def main():
     conf = CONFIGS[args.config]
     res = args.res or conf["res"]
     spp = args.spp or conf["spp"]
+    if args.chains is None:
+        args.chains = conf.get("chains", 65536)
 
     # Libraries loaded below write to the process's stdout on their own (RCCL prints a version banner when its first
     # communicator comes up): keep file descriptor 1 pointed at stderr until the one JSON line is ready.
