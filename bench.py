@@ -48,7 +48,8 @@ CONFIGS = {
               kernel="k_mutate_mmlt", pmc="r02_c5_pmc.json",
               what="glass caustic (dielectric sphere, small sphere light) %(res)dx%(res)d, drmlt technique=mmlt type=orbital "
                    "fixEmitterPath acceptanceMap, %(chains)d chains/GPU, sampleCount %(spp)d (BASELINE.json configs[4])"),
-    "bdpt": dict(scene=("cornell_c2", {}), res=512, cfg=dict(technique="bdpt", type="orbital", max_depth=8, rr_depth=5),
+    # 131 072 chains, as config 5: above 65 536 the launcher picks the two-waves-per-SIMD build of k_mutate_bdpt
+    "bdpt": dict(scene=("cornell_c2", {}), res=512, chains=131072, cfg=dict(technique="bdpt", type="orbital", max_depth=8, rr_depth=5),
                  spp=64, kernel="k_mutate_bdpt", pmc="r02_bdpt_pmc.json",
                  what="Cornell box %(res)dx%(res)d, drmlt technique=bdpt type=orbital, %(chains)d chains/GPU, sampleCount %(spp)d"),
     "soup": dict(scene=("triangle_soup", dict(n_tris=2000)), res=512,

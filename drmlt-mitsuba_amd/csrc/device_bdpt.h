@@ -6,17 +6,17 @@
 //
 // Storage per chain:
 //   global workspace `bd_verts`  [BV_FIELDS][NVS][n]   geometry of every stored vertex (SoA, coalesced per field)
-//   LDS rows from `mis_row`      4 x NVS rows           fwd / rev densities (area measure), edge factor len^2/|cos cos|,
-//                                                       flags -- what the MIS sweep reads for every pair
+//   LDS rows from `mis_row`      2 x NVS rows           fwd / rev densities (area measure) -- what the MIS sweep reads for every pair
 //   global lists `bd_lists`      [slot][BL_ROWS][n]     splat lists of the current state and the two proposals
 // NVS = ME + MS vertex slots: emitter vertices 1..ME (ME = maxDepth), sensor vertices 1..MS (MS = maxDepth + 1);
 // the supernodes are implicit.
 #pragma once
 #include "device_bidir.h"
 
-enum { BV_P = 0, BV_N = 3, BV_S = 6, BV_WI = 9, BV_LEN2 = 12, BV_COS = 13, BV_THR = 14, BV_IDS = 17, BV_EMIT = 18, BV_SHADE = 19, BV_FIELDS = 20 };
+enum { BV_P = 0, BV_N = 3, BV_S = 6, BV_WI = 9, BV_LEN2 = 12, BV_COS = 13, BV_THR = 14, BV_IDS = 17, BV_EMIT = 18, BV_SHADE = 19, BV_GINV = 20, BV_FIELDS = 21 };
 enum { BL_LUM = 0, BL_META = 1, BL_MAIN = 2, BL_MORE = 7 }; // rows of a splat list; 5 rows (px, py, r, g, b) per splat
-enum { MF_FWD = 0, MF_REV = 1, MF_GINV = 2, MF_FLAGS = 3 }; // LDS row groups
+enum { MF_FWD = 0, MF_REV = 1, MF_GROUPS = 2 }; // LDS row groups. The edge factor len^2 / |cos cos| (read by the rare specular-chain correction only) sits in
+// the vertex workspace, the two flag bits per vertex in a 64-bit register.
 #define BF_CONN 1u
 #define BF_DEGEN 2u
 
@@ -108,6 +108,9 @@ DEV void eval_bdpt(const DParams &P, const TablesT &T, MSampler &smp, uint32_t c
     const BdptStore W{P.bd_verts, n, chain, NVS};
     auto mis = [&](int group, int slot) -> float & { return lds_x[(mis_row + (uint32_t) group * NVS + (uint32_t) slot) * 64u + lane]; };
     auto lrow = [&](int r) -> float & { return list[(size_t) r * n]; };
+    unsigned long long flagbits = 0ull; // two bits per vertex slot: BF_CONN, BF_DEGEN
+    auto set_flags = [&](int slot, unsigned v) { flagbits = (flagbits & ~(3ull << (2 * slot))) | ((unsigned long long) v << (2 * slot)); };
+    auto flags = [&](int slot) -> unsigned { return (unsigned) (flagbits >> (2 * slot)) & 3u; };
 
     R.lum = 0.f; R.nrays = 0u; R.n_sensor = R.n_emitter = R.n_direct = 0u; R.n_more = 0; R.has_main = false;
     smp.reset_caches();
@@ -146,7 +149,7 @@ DEV void eval_bdpt(const DParams &P, const TablesT &T, MSampler &smp, uint32_t c
                 cur.kind = BK_END_S; cur.p = cam_pos(P); cur.n = cam_dir(P); cur.degenerate = false; cur.e_len2 = 0.f; cur.e_cos = 0.f;
                 cur.s = cur.wi = mk3(0.f, 0.f, 0.f);
                 W.put(base, cur, thr);
-                mis(MF_GINV, base) = 0.f; mis(MF_FLAGS, base) = 0.f;
+                W.f(BV_GINV, base) = 0.f; set_flags(base, 0u);
                 nS = 2;
                 continue;
             }
@@ -172,7 +175,7 @@ DEV void eval_bdpt(const DParams &P, const TablesT &T, MSampler &smp, uint32_t c
                 cur.kind = BK_END_E; cur.n = sph ? lp : ld3(L.n); cur.p = sph ? fma3(lp, L.eu[0], ld3(L.origin)) : lp; cur.emitter = ei; cur.shade = E.prim; cur.degenerate = false;
                 cur.e_len2 = 0.f; cur.e_cos = 0.f; cur.s = cur.wi = mk3(0.f, 0.f, 0.f);
                 W.put(base, cur, thr);
-                mis(MF_GINV, base) = 0.f; mis(MF_FLAGS, base) = 0.f;
+                W.f(BV_GINV, base) = 0.f; set_flags(base, 0u);
                 nE = 2;
                 continue;
             }
@@ -272,7 +275,7 @@ DEV void eval_bdpt(const DParams &P, const TablesT &T, MSampler &smp, uint32_t c
             const int cslot = base + i - 1;
             mis(MF_FWD, cslot) = fwd;
             mis(MF_REV, cslot) = rev;
-            mis(MF_FLAGS, cslot) = __uint_as_float(((!cur.degenerate && !delta) ? BF_CONN : 0u) | (cur.degenerate ? BF_DEGEN : 0u));
+            set_flags(cslot, ((!cur.degenerate && !delta) ? BF_CONN : 0u) | (cur.degenerate ? BF_DEGEN : 0u));
             thr = thr * (w * rrw);
 
             nv.kind = BK_SURF;
@@ -287,8 +290,8 @@ DEV void eval_bdpt(const DParams &P, const TablesT &T, MSampler &smp, uint32_t c
             nv.e_len2 = len2;
             nv.e_cos = cosCur;
             W.put(base + i, nv, thr);                            // vertex i + 1
-            mis(MF_GINV, base + i) = len2 / (cosNew * cosCur);   // edge (i, i + 1), kept with vertex i + 1
-            mis(MF_FLAGS, base + i) = __uint_as_float(nv.degenerate ? BF_DEGEN : 0u);
+            W.f(BV_GINV, base + i) = len2 / (cosNew * cosCur);   // edge (i, i + 1), kept with vertex i + 1
+            set_flags(base + i, nv.degenerate ? BF_DEGEN : 0u);
             if (emitter) nE = i + 2; else nS = i + 2;
             cur = nv;
         }
@@ -302,7 +305,6 @@ DEV void eval_bdpt(const DParams &P, const TablesT &T, MSampler &smp, uint32_t c
     R.has_main = nS > 2; // "if (m_sensorSubpath.vertexCount() > 2)", :357-361
     int n_more = 0;
 
-    auto flags = [&](int slot) { return __float_as_uint(mis(MF_FLAGS, slot)); };
     auto vpos = [&](int slot) { return mk3(W.f(BV_P, slot), W.f(BV_P + 1, slot), W.f(BV_P + 2, slot)); };
     auto vnrm = [&](int slot) { return mk3(W.f(BV_N, slot), W.f(BV_N + 1, slot), W.f(BV_N + 2, slot)); };
     auto vrefn_zero = [&](int slot) { return T.bsdf(__float_as_int(W.f(BV_IDS, slot)) >> 4).type == 1; }; // records.inl:160-164
@@ -438,7 +440,7 @@ DEV void eval_bdpt(const DParams &P, const TablesT &T, MSampler &smp, uint32_t c
                 if (j >= k) return false;
                 return (flags(j < s ? j - 1 : ME + (k - j) - 1) & BF_CONN) != 0u;
             };
-            auto ginv = [&](int e) -> float { return e < s ? mis(MF_GINV, e) : mis(MF_GINV, ME + (k - e) - 1); }; // edge (e, e + 1)
+            auto ginv = [&](int e) -> float { return e < s ? W.f(BV_GINV, e) : W.f(BV_GINV, ME + (k - e) - 1); }; // edge (e, e + 1)
             auto pImp = [&](int j) -> float {
                 float v;
                 if (j == 0) v = 1.f;

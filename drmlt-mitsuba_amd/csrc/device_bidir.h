@@ -37,6 +37,8 @@ struct MSampler {
     bool large;
     float sigma2;
     uint32_t lane;
+    const float *x_dir;      // bdpt chains: the direct sampler's state stays in memory (column of this chain, row stride x_dir_n); else NULL
+    uint32_t x_dir_n;
     const float *arr;        // SM_ARRAY: [sensor S | emitter E | direct]
     uint32_t S, E;
     uint32_t base_e, base_d; // draw bases of the emitter / direct segments
@@ -75,7 +77,10 @@ struct MSampler {
         if (blk != b2_idx) { b2 = philox4x32_10(key0, key1, blk, major, chain, TAG_S2); b2_idx = blk; }
         return pick4(b2, idx & 3u);
     }
-    DEV float x(uint32_t k) const { return lds_x[(x_off + k) * 64u + lane]; }
+    DEV float x(uint32_t k) const {
+        if (x_dir && seg == SEG_DIRECT) return x_dir[(size_t) k * x_dir_n];
+        return lds_x[(x_off + k) * 64u + lane];
+    }
     DEV bool ident2() const { return (seg == SEG_DIRECT && direct_ident) || (seg == SEG_EMITTER && emitter_ident2); }
 
     DEV float y_raw(uint32_t k) {

@@ -5,13 +5,15 @@
 //   k_mutate_bdpt       DRMLTRenderer::process / processMixture over sampleSplats(EBidirectional) (drmlt_proc.cpp:161-380,518-770)
 //   k_eval_lists_bdpt   sampleSplats(EBidirectional) on caller-supplied PSS points, full splat lists
 //
-// LDS rows ([row][lane]): chain state [0, NX), NX = S + E + Dd (bdpt_dims_sensor / _emitter / _direct; Dd = 0 with
-// directSampling = false), then the four row groups of eval_bdpt. Splat lists live in HBM (`bd_lists`, slot 0 = current state), unnormalised next to their luminance.
+// LDS rows ([row][lane]): the walks' part of the chain state [0, S + E) (bdpt_dims_sensor / _emitter), then the two row
+// groups of eval_bdpt: 76 rows = 19 KB for maxDepth 8 -- under the 20 KB that put eight waves on a CU. The direct
+// sampler's Dd components (directSampling = true) stay in memory: a sample reads at most a few of them. Splat lists live in HBM (`bd_lists`, slot 0 = current state), unnormalised next to their luminance.
 #include <cstdlib>
 #include "device_bdpt.h"
 #include "kernel_common.h"
 
-DEV uint32_t bdpt_nx(const DParams &P) { return (uint32_t) (P.mmlt_S + P.mmlt_E + P.bd_Dd); }
+DEV uint32_t bdpt_nx(const DParams &P) { return (uint32_t) (P.mmlt_S + P.mmlt_E + P.bd_Dd); } // components of a chain's state
+DEV uint32_t bdpt_nx_lds(const DParams &P) { return (uint32_t) (P.mmlt_S + P.mmlt_E); }        // ... of which LDS holds the two walks'
 
 DEV void bsampler_setup(MSampler &smp, const DParams &P, uint32_t lane) {
     smp.key0 = P.key0; smp.key1 = P.key1;
@@ -19,7 +21,7 @@ DEV void bsampler_setup(MSampler &smp, const DParams &P, uint32_t lane) {
     smp.lane = lane; smp.arr = nullptr;
     smp.S = (uint32_t) P.mmlt_S; smp.E = (uint32_t) P.mmlt_E;
     smp.base_e = 2u * (uint32_t) P.mmlt_dmax; smp.base_d = 4u * (uint32_t) P.mmlt_dmax;
-    smp.emitter_ident2 = false; smp.direct_ident = false;
+    smp.emitter_ident2 = false; smp.direct_ident = false; smp.x_dir = nullptr; smp.x_dir_n = 0u;
     smp.reset_caches();
     smp.select(SEG_SENSOR);
 }
@@ -90,7 +92,7 @@ __global__ void __launch_bounds__(CHAIN_BLOCK) k_bootstrap_bdpt(DParams P, uint3
     for (uint32_t i = c; i < n; i += P.n_chains_alloc) {
         smp.major = i;
         BdptResult R;
-        eval_bdpt(P, T, smp, c, bdpt_nx(P), list_col(P, 1, c), R);
+        eval_bdpt(P, T, smp, c, bdpt_nx_lds(P), list_col(P, 1, c), R);
         lum_out[i] = R.lum;
     }
 }
@@ -105,7 +107,7 @@ __global__ void __launch_bounds__(CHAIN_BLOCK) k_init_chains_bdpt(DParams P, con
     const GlobalTables T{P.shade, P.bsdfs, P.emitters};
     BdptResult R;
     float *cur = list_col(P, 0, c);
-    eval_bdpt(P, T, smp, c, bdpt_nx(P), cur, R);
+    eval_bdpt(P, T, smp, c, bdpt_nx_lds(P), cur, R);
     if (!(fabsf((R.lum - seed_lum[c]) / seed_lum[c]) <= EPSILON_F)) atomicExch(P.error_flag, 1); // drmlt_proc.cpp:509-512
     const float lum = list_finalize(P, cur, R.lum);
     P.cur_lum[c] = lum;
@@ -121,12 +123,15 @@ __global__ void __launch_bounds__(CHAIN_BLOCK) k_init_chains_bdpt(DParams P, con
 
 // FEAT 7: scenes without a BVH -- no traversal stack in LDS (6 KB), which is what keeps four waves on a CU with
 // directSampling = true (35 KB of rows per wave; measured 4.3e7 -> 8e7 mutations/s, all of it occupancy)
-template <int FEAT> __global__ void __launch_bounds__(CHAIN_BLOCK) k_mutate_bdpt(DParams P, uint32_t n_mut, uint32_t mut_base) {
+// OCC 2: registers capped at 256 (the rest spills to scratch) so that two waves share a SIMD -- chosen by the launcher when
+// there are waves to fill them (more than 65 536 chains): a single wave64 issues a vector instruction every 4 cycles at
+// best, the SIMD one every 2.
+template <int FEAT, int OCC> __global__ void __launch_bounds__(CHAIN_BLOCK, OCC) k_mutate_bdpt(DParams P, uint32_t n_mut, uint32_t mut_base) {
     const uint32_t lane = threadIdx.x;
     const uint32_t c = blockIdx.x * CHAIN_BLOCK + lane;
     const bool live = c < P.n_chains;
     const uint32_t cc = live ? c : P.n_chains - 1;
-    const uint32_t NX = bdpt_nx(P);
+    const uint32_t NX = bdpt_nx_lds(P);
     for (uint32_t k = 0; k < NX; ++k) lds_x[k * 64u + lane] = P.x[(size_t) k * P.n_chains + cc];
     float cur_lum = P.cur_lum[cc];
     float *L0 = list_col(P, 0, cc), *L1 = list_col(P, 1, cc), *L2 = list_col(P, 2, cc);
@@ -135,6 +140,8 @@ template <int FEAT> __global__ void __launch_bounds__(CHAIN_BLOCK) k_mutate_bdpt
     MSampler smp;
     bsampler_setup(smp, P, lane);
     smp.chain = P.chain_offset + cc;
+    float *const xdir = P.x + (size_t) NX * P.n_chains + cc; // the direct sampler's components of this chain
+    smp.x_dir = xdir; smp.x_dir_n = P.n_chains;
     const GlobalTables T{P.shade, P.bsdfs, P.emitters};
     Counters ct = {0u, 0u, 0u, 0u, 0u};
     const bool amap = P.acceptance_map != 0;
@@ -268,7 +275,8 @@ template <int FEAT> __global__ void __launch_bounds__(CHAIN_BLOCK) k_mutate_bdpt
                 const uint32_t nk = sg == 0 ? smp.S : (sg == 1 ? smp.E : (uint32_t) P.bd_Dd);
                 for (uint32_t k = 0; k < nk; ++k) {
                     const float v = wrap01(acc1 ? smp.y_raw(k) : smp.z_raw(k));
-                    lds_x[(smp.x_off + k) * 64u + lane] = v;
+                    if (sg == 2) xdir[(size_t) k * P.n_chains] = v;
+                    else lds_x[(smp.x_off + k) * 64u + lane] = v;
                     if (smp.type == 2 && (k & 1u)) smp.pair_base = 0xffffffffu;
                 }
             }
@@ -313,7 +321,7 @@ __global__ void __launch_bounds__(CHAIN_BLOCK) k_eval_lists_bdpt(DParams P, cons
         smp.arr = u + (size_t) i * dim;
         BdptResult R;
         float *L = list_col(P, 1, c);
-        eval_bdpt(P, T, smp, c, bdpt_nx(P), L, R);
+        eval_bdpt(P, T, smp, c, bdpt_nx_lds(P), L, R);
         float *o = out + (size_t) i * stride;
         for (uint32_t k = 0; k < stride; ++k) o[k] = 0.f;
         o[0] = R.lum; o[1] = R.has_main ? 1.f : 0.f;
@@ -326,7 +334,7 @@ __global__ void __launch_bounds__(CHAIN_BLOCK) k_eval_lists_bdpt(DParams P, cons
 
 static size_t bdpt_lds_bytes(const DParams &P) {
     static const size_t pad = getenv("DRMLT_BDPT_LDS_PAD") ? (size_t) atoi(getenv("DRMLT_BDPT_LDS_PAD")) : 0; // diagnostic: occupancy experiments
-    return pad + ((size_t) P.mmlt_S + P.mmlt_E + P.bd_Dd + 4 * ((size_t) 2 * P.max_depth + 1)) * 64 * sizeof(float);
+    return pad + ((size_t) P.mmlt_S + P.mmlt_E + 2 * ((size_t) 2 * P.max_depth + 1)) * 64 * sizeof(float);
 }
 void launch_bootstrap_bdpt(const DParams &P, uint32_t n, float *lum_out, hipStream_t st) {
     hipLaunchKernelGGL(k_bootstrap_bdpt, dim3((P.n_chains_alloc + CHAIN_BLOCK - 1) / CHAIN_BLOCK), dim3(CHAIN_BLOCK), bdpt_lds_bytes(P), st, P, n, lum_out);
@@ -337,8 +345,11 @@ void launch_init_chains_bdpt(const DParams &P, const uint32_t *seed_index, const
 }
 void launch_mutate_bdpt(const DParams &P, uint32_t n_mut, uint32_t mut_base, hipStream_t st) {
     const dim3 grid((P.n_chains + CHAIN_BLOCK - 1) / CHAIN_BLOCK), block(CHAIN_BLOCK);
-    if (P.use_bvh) hipLaunchKernelGGL(k_mutate_bdpt<15>, grid, block, bdpt_lds_bytes(P), st, P, n_mut, mut_base);
-    else hipLaunchKernelGGL(k_mutate_bdpt<7>, grid, block, bdpt_lds_bytes(P), st, P, n_mut, mut_base);
+    static const int force_occ = getenv("DRMLT_BDPT_OCC") ? atoi(getenv("DRMLT_BDPT_OCC")) : 0; // diagnostic
+    const bool two = force_occ ? force_occ == 2 : (!P.use_bvh && grid.x > 1024u + 256u && bdpt_lds_bytes(P) <= 20480);
+    if (P.use_bvh) hipLaunchKernelGGL((k_mutate_bdpt<15, 1>), grid, block, bdpt_lds_bytes(P), st, P, n_mut, mut_base);
+    else if (two) hipLaunchKernelGGL((k_mutate_bdpt<7, 2>), grid, block, bdpt_lds_bytes(P), st, P, n_mut, mut_base);
+    else hipLaunchKernelGGL((k_mutate_bdpt<7, 1>), grid, block, bdpt_lds_bytes(P), st, P, n_mut, mut_base);
 }
 void launch_eval_lists_bdpt(const DParams &P, const float *u, uint32_t n, uint32_t dim, float *out, uint32_t stride, hipStream_t st) {
     hipLaunchKernelGGL(k_eval_lists_bdpt, dim3((P.n_chains_alloc + CHAIN_BLOCK - 1) / CHAIN_BLOCK), dim3(CHAIN_BLOCK), bdpt_lds_bytes(P), st, P, u, n, dim, out,

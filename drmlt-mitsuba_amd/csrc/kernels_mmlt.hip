@@ -17,7 +17,7 @@ DEV void msampler_setup(MSampler &smp, const DParams &P, uint32_t lane) {
     smp.lane = lane; smp.arr = nullptr;
     smp.S = (uint32_t) P.mmlt_S; smp.E = (uint32_t) P.mmlt_E;
     smp.base_e = 2u * (uint32_t) P.mmlt_dmax; smp.base_d = 4u * (uint32_t) P.mmlt_dmax;
-    smp.emitter_ident2 = false; smp.direct_ident = true;
+    smp.emitter_ident2 = false; smp.direct_ident = true; smp.x_dir = nullptr; smp.x_dir_n = 0u;
     smp.reset_caches();
     smp.select(SEG_SENSOR);
 }
