@@ -399,8 +399,21 @@ drmlt_ctx *drmlt_create(const drmlt_config *cfg, const drmlt_scene *scene, int d
     // ---- derived quantities of DRMLT::render (drmlt.cpp:434-476)
     const uint64_t budget = (uint64_t) cam.width * cam.height * (uint64_t) cfg->sample_count;
     int work_units = cfg->work_units;
-    const uint64_t per_unit = (mmlt || bdpt) ? 100000 : 200000; // desiredMutationsPerWorkUnit, drmlt.cpp:434-444
-    if (work_units <= 0) work_units = (int) std::max<uint64_t>(1, (budget + per_unit - 1) / per_unit);
+    if (work_units <= 0) {
+        // "derived" (workUnits = -1, the default). The reference sizes work units for its CPU scheduler -- 200 000 (path) or
+        // 100 000 (mmlt, bdpt) mutations each, drmlt.cpp:434-444: a few hundred chains for a whole image. A device wants the
+        // count that fills it: 65 536 chains for the path kernels (32 per wave, two waves per SIMD), 131 072 for the
+        // one-chain-per-lane bidirectional kernels, but never chains shorter than 64 mutations. An explicit workUnits is
+        // taken as given; DRMLT_AUTO_WORK_UNITS=reference restores the reference's formula.
+        const char *mode = getenv("DRMLT_AUTO_WORK_UNITS");
+        if (mode && !strcmp(mode, "reference")) {
+            const uint64_t per_unit = (mmlt || bdpt) ? 100000 : 200000;
+            work_units = (int) std::max<uint64_t>(1, (budget + per_unit - 1) / per_unit);
+        } else {
+            const uint64_t fill = (mmlt || bdpt) ? 131072 : 65536;
+            work_units = (int) std::min<uint64_t>(fill, std::max<uint64_t>(64, budget / 64 / 64 * 64));
+        }
+    }
     ctx->cfg.work_units = work_units;
     ctx->n_chains = (uint32_t) work_units;
 
