@@ -42,6 +42,8 @@ inline int median_depth(int n, int leaf_max) {
     return d;
 }
 
+constexpr int kMaxBinaryDepth = 64; // recursion bound of the builder; the traversal stack spills to memory beyond BVH_STACK / 3 four-wide levels
+
 struct Builder {
     const std::vector<PrimBounds> &pb;
     std::vector<int> &order; // primitive indices, leaf ranges are contiguous
@@ -149,7 +151,7 @@ inline int build_bvh(const std::vector<PrimBounds> &pb, std::vector<DBvhNode> &n
     nodes.clear();
     Builder b{pb, order, nodes};
     if (const char *t = getenv("DRMLT_BVH_LEAF")) b.leaf_max = std::max(1, std::min(kLeafCap, atoi(t)));
-    b.max_depth = std::max(std::min(max_depth, BVH_STACK), median_depth(n, b.leaf_max)); // never below what a balanced tree needs
+    b.max_depth = std::max(std::min(max_depth, kMaxBinaryDepth), median_depth(n, b.leaf_max)); // never below what a balanced tree needs
     if (n <= b.leaf_max) {
         // single leaf under a root whose second child is empty
         nodes.emplace_back();
@@ -232,8 +234,8 @@ inline int collapse4(const std::vector<DBvhNode> &bin, int node, std::vector<DBv
 }
 } // namespace bvh_detail
 
-// nodes4[0] is the root. The traversal pushes at most 3 entries per inner node on the current path, so the tree is usable
-// iff 3 * depth4 <= BVH_STACK; the caller checks the returned depth.
+// nodes4[0] is the root. The traversal pushes at most 3 entries per inner node on the current path: 3 * depth4 entries
+// bound its stack; what does not fit the LDS column (BVH_STACK) spills to memory (device_path.h: trav_run).
 // `leaf_shift` (out): 0 when every leaf holds one primitive, else 3 (see DBvh4Node).
 inline int build_bvh4(const std::vector<DBvhNode> &bin, std::vector<DBvh4Node> &nodes4, int *leaf_shift_out = nullptr) {
     std::vector<int> memo(bin.size(), 0);
@@ -242,10 +244,5 @@ inline int build_bvh4(const std::vector<DBvhNode> &bin, std::vector<DBvh4Node> &
     for (const DBvhNode &N : bin) single = single && (N.c0 >= 0 || N.n0 <= 1) && (N.c1 >= 0 || N.n1 <= 1);
     const int leaf_shift = single ? 0 : 3;
     if (leaf_shift_out) *leaf_shift_out = leaf_shift;
-    int depth = bvh_detail::collapse4(bin, 0, nodes4, false, memo, leaf_shift);
-    if (3 * depth > BVH_STACK) { // rare: a path the area-driven collapse left uncollapsed; collapse by subtree height instead
-        nodes4.clear();
-        depth = bvh_detail::collapse4(bin, 0, nodes4, true, memo, leaf_shift);
-    }
-    return depth;
+    return bvh_detail::collapse4(bin, 0, nodes4, false, memo, leaf_shift);
 }

@@ -509,6 +509,7 @@ struct Trav {
     float tmin;
     Hit h;
     int cur, sp;      // cur >= 0 inner node, < 0 leaf reference
+    int ovf;          // entries of this lane's stack that sit in the overflow area (multiples of BVH_SPILL; 0 for trees the LDS column holds)
     bool active, any_hit;
     uint32_t n_nodes, n_prims; // fetched so far by this lane (k_mutate_v4 reports them: the scene part of the algorithmic bytes)
     uint32_t it_inner, it_leaf; // wave-uniform: traversal iterations of each kind (lane occupancy = n_nodes / (64 it_inner) ...)
@@ -520,7 +521,7 @@ DEV void trav_begin(Trav &T, f3 o, f3 d, float tmin, float tmax, bool any_hit) {
     T.oi = mk3(-o.x * T.inv.x, -o.y * T.inv.y, -o.z * T.inv.z);
     T.tmin = tmin;
     T.h = Hit{-1, tmax, 0.f, 0.f};
-    T.cur = 0; T.sp = 0;
+    T.cur = 0; T.sp = 0; T.ovf = 0;
     T.active = true; T.any_hit = any_hit;
 }
 DEV void trav_reset_counters(Trav &T) { T.n_nodes = T.n_prims = T.it_inner = T.it_leaf = 0u; }
@@ -533,9 +534,26 @@ DEV unsigned umax2(unsigned a, unsigned b) { return a < b ? b : a; }
 // StackT: int, or short when every node index and leaf reference of the scene fits 15 bits (drmlt_create decides): half
 // the LDS, which is what lets k_mutate_v4 keep 8 waves per CU on BVH scenes (measured: 1.13e8 -> 2.0e8 mutations/s on the
 // 2000-triangle soup, all of it occupancy).
-template <class StackT, class PT> DEV void trav_run(const PT &P, Trav &T, bool mine, int yield_lanes) {
+// OVF: compile the spill / refill paths in (k_mutate_v4 has a build without them for trees that fit the column: they cost
+// 4 % there even when never taken).
+template <class StackT, class PT, bool OVF = true> DEV void trav_run(const PT &P, Trav &T, bool mine, int yield_lanes) {
     __shared__ StackT bvh_stack[(BVH_STACK + 2) * 64]; // + 2: the branch-free pushes write one or two entries above the top
     StackT *const stk = bvh_stack + (threadIdx.x & 63u); // every kernel that traces runs one wave per workgroup
+    // The LDS column holds BVH_STACK entries (+ 2 spare); a tree deeper than BVH_STACK / 3 levels can need more. Rare slow
+    // paths: before a node's pushes could run past the column its BVH_SPILL OLDEST entries move to this lane's column of an
+    // overflow area in memory and the rest slides down; a pop that finds the column empty brings the newest BVH_SPILL back.
+    const size_t ovf_col = (size_t) blockIdx.x * 64u + (threadIdx.x & 63u);
+    auto spill = [&]() {
+        for (int i = 0; i < BVH_SPILL; ++i) P.bvh_overflow[(size_t) (T.ovf + i) * P.bvh_ovf_lanes + ovf_col] = (int) stk[i * 64];
+        for (int i = BVH_SPILL; i < T.sp; ++i) stk[(i - BVH_SPILL) * 64] = stk[i * 64];
+        T.sp -= BVH_SPILL; T.ovf += BVH_SPILL;
+    };
+    auto refill = [&]() {
+        T.ovf -= BVH_SPILL;
+        for (int i = 0; i < BVH_SPILL; ++i) stk[i * 64] = (StackT) P.bvh_overflow[(size_t) (T.ovf + i) * P.bvh_ovf_lanes + ovf_col];
+        T.sp = BVH_SPILL;
+    };
+    const bool has_ovf = OVF && P.bvh_overflow != nullptr; // wave-uniform
     int finished = 0;
     for (;;) {
         const bool run = mine && T.active;
@@ -548,6 +566,7 @@ template <class StackT, class PT> DEV void trav_run(const PT &P, Trav &T, bool m
             if (run && T.cur >= 0) {
                 const DBvh4Node N = load_global16(P.bvh + T.cur);
                 T.n_nodes++;
+                if (has_ovf && T.sp > BVH_STACK - 3) spill();
                 if constexpr (sizeof(StackT) == 2) {
                     // 16-bit child references: the sort key carries the child itself -- entry distance in the upper half (its bit
                     // pattern orders like an unsigned: tn >= tmin >= 0; 7 mantissa bits are plenty for an ORDER), reference in
@@ -581,8 +600,9 @@ template <class StackT, class PT> DEV void trav_run(const PT &P, Trav &T, bool m
                     stk[sp * 64] = (StackT) k1; sp += k1 != 0xffffffffu ? 1 : 0;
                     T.sp = sp;
                     if (k0 != 0xffffffffu) T.cur = (int) (short) (k0 & 0xffffu);
-                    else if (sp == 0) { T.active = false; done_now = true; }
-                    else T.cur = stk[--T.sp * 64];
+                    else if (T.sp != 0) T.cur = stk[--T.sp * 64];
+                    else if (has_ovf && T.ovf > 0) { refill(); T.cur = stk[--T.sp * 64]; }
+                    else { T.active = false; done_now = true; }
                 } else {
                     // 32-bit child references: the key carries the SLOT in its two low mantissa bits; selects pick the child
                     unsigned key[4];
@@ -609,8 +629,9 @@ template <class StackT, class PT> DEV void trav_run(const PT &P, Trav &T, bool m
                     stk[sp * 64] = (StackT) child_of(k1); sp += k1 != 0xffffffffu ? 1 : 0;
                     T.sp = sp;
                     if (k0 != 0xffffffffu) T.cur = child_of(k0);
-                    else if (sp == 0) { T.active = false; done_now = true; }
-                    else T.cur = stk[--T.sp * 64];
+                    else if (T.sp != 0) T.cur = stk[--T.sp * 64];
+                    else if (has_ovf && T.ovf > 0) { refill(); T.cur = stk[--T.sp * 64]; }
+                    else { T.active = false; done_now = true; }
                 }
             }
         } else {
@@ -623,8 +644,10 @@ template <class StackT, class PT> DEV void trav_run(const PT &P, Trav &T, bool m
                     const DPrim G = load_global16(P.prims + first + i);
                     intersect_prim(G, G.shade, T.o, T.d, T.tmin, T.h);
                 }
-                if ((T.any_hit && T.h.prim >= 0) || T.sp == 0) { T.active = false; done_now = true; }
-                else T.cur = stk[--T.sp * 64];
+                if (T.any_hit && T.h.prim >= 0) { T.active = false; done_now = true; }
+                else if (T.sp != 0) T.cur = stk[--T.sp * 64];
+                else if (has_ovf && T.ovf > 0) { refill(); T.cur = stk[--T.sp * 64]; }
+                else { T.active = false; done_now = true; }
             }
         }
         finished += __popcll(__ballot(done_now));

@@ -62,6 +62,7 @@ struct DEmitter {
     float pad[2];
 };
 
+#define BVH_SPILL 12 // entries moved to / from the overflow area at a time (trees deeper than BVH_STACK / 3 levels)
 #define BVH_STACK 24 // per-lane traversal stack entries (LDS): a 4-wide node pushes at most 3, so the 4-wide depth is bounded by 8 (bvh_build.h)
 // 4-wide node, 128 B = one cache line: the four child boxes component by component (each row one 16 B load), then the
 // children. child >= 0: inner node index; child < 0: leaf, ~child = (first primitive slot << shift) | count, with
@@ -136,6 +137,8 @@ struct DParams {
     int32_t bvh_leaf_shift;      // 0: one primitive per leaf, ~child = slot; 3: ~child = slot << 3 | count
     int32_t bvh_stack16;         // every stack entry fits a short: k_mutate_v4 runs its 16-bit-stack variant
     int32_t trace_yield;         // k_mutate_v4 on BVH scenes: a traversal slice ends once this many lanes have finished their ray
+    int32_t *bvh_overflow;       // [entry][lane of the grid]: where a traversal stack that outgrows its LDS column puts its oldest entries, or NULL
+    uint32_t bvh_ovf_lanes;      // column count of that area (>= lanes of the launch)
     int32_t trace_vote;          // traversal: the wave tests nodes when 16 * (lanes at a leaf) <= trace_vote * (lanes at a node), leaves otherwise
 };
 

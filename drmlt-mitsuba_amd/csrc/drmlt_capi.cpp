@@ -258,6 +258,23 @@ void build_filter(int type, float param, float lut[32], float &radius, float &sc
     for (int i = 0; i < res; ++i) lut[i] *= normalization;
 }
 
+// Overflow area of the traversal stacks (deep trees only): [ovf_entries][lanes of the launch] ints. Grown on demand before a
+// launch whose grid has more lanes than any before it; `P` is the parameter block the launch will use.
+static hipError_t ensure_overflow(drmlt_ctx *ctx, DParams &P, size_t lanes) {
+    if (ctx->ovf_entries == 0) { P.bvh_overflow = nullptr; P.bvh_ovf_lanes = 0; return hipSuccess; }
+    lanes = (lanes + 63) / 64 * 64;
+    if (lanes > ctx->ovf_lanes) {
+        hipError_t e = hipStreamSynchronize(ctx->stream); // a launch in flight may still be using the old area
+        if (e != hipSuccess) return e;
+        e = ctx->d_ovf.alloc((size_t) ctx->ovf_entries * lanes * sizeof(int32_t));
+        if (e != hipSuccess) { ctx->ovf_lanes = 0; return e; }
+        ctx->ovf_lanes = lanes;
+    }
+    ctx->P.bvh_overflow = P.bvh_overflow = ctx->d_ovf.as<int32_t>();
+    ctx->P.bvh_ovf_lanes = P.bvh_ovf_lanes = (uint32_t) ctx->ovf_lanes;
+    return hipSuccess;
+}
+
 int find_max_dim_path(int maxDepth, int rrDepth) { // pssmlt_utils.h:62-68 (no media, no rough dielectric)
     int maxDim = (maxDepth + 2) * (4 + (rrDepth < maxDepth ? 1 : 0));
     if (maxDim % 2 == 1) ++maxDim;
@@ -342,9 +359,9 @@ drmlt_ctx *drmlt_create(const drmlt_config *cfg, const drmlt_scene *scene, int d
     P.use_bvh = (int) ctx->prims.size() > bvh_threshold ? 1 : 0;
     if (P.use_bvh) {
         std::vector<int> order;
-        // binary depth <= 16: collapsing by subtree height then gives a 4-wide depth <= 8 = BVH_STACK / 3 whatever the
-        // primitive distribution (bvh_build.h); the area-driven collapse is tried first
-        int max_depth = 2 * (BVH_STACK / 3);
+        // SAH splits wherever they lead (the builder's recursion bound, 64 levels, is far from what a surface-area tree
+        // needs): a traversal stack that outgrows its LDS column spills to memory (device_path.h: trav_run)
+        int max_depth = 64;
         if (const char *t = getenv("DRMLT_BVH_MAX_DEPTH")) max_depth = std::min(max_depth, atoi(t)); // tests: exercise the depth-bounded splits
         const int median_splits = build_bvh(bounds, nodes, order, max_depth);
         int leaf_shift = 0;
@@ -352,10 +369,12 @@ drmlt_ctx *drmlt_create(const drmlt_config *cfg, const drmlt_scene *scene, int d
         P.bvh_leaf_shift = leaf_shift;
         // 16-bit stack entries when every node index and leaf reference fits (k_mutate_v4: 3 KB of LDS instead of 6)
         P.bvh_stack16 = (nodes4.size() < 32768 && ((order.size() << leaf_shift) | 7u) < 32768 && !getenv("DRMLT_BVH_STACK32")) ? 1 : 0;
-        // the kernels' per-lane stack holds BVH_STACK entries and does not check for overflow: a 4-wide node pushes at most 3
-        if (3 * depth4 > BVH_STACK) return bail(ctx, "internal error: BVH deeper than the traversal stack");
+        // a 4-wide node pushes at most 3 entries, so a node at level l is entered with at most 3 (l - 1) on the stack and
+        // 3 * depth4 bound it: up to BVH_STACK that is the LDS column (the branch-free pushes use its two spare rows); deeper
+        // trees get an overflow area in memory, sized per launch (ensure_overflow)
         ctx->bvh_depth = depth4;
-        if (getenv("DRMLT_VERBOSE")) fprintf(stderr, "[drmlt] BVH: %zu primitives, %zu binary / %zu 4-wide nodes, 4-wide depth %d (stack %d), %d median splits, %d-bit stack entries\n", order.size(), nodes.size(), nodes4.size(), depth4, BVH_STACK, median_splits, P.bvh_stack16 ? 16 : 32);
+        ctx->ovf_entries = 3 * depth4 > BVH_STACK ? (3 * depth4 + 3 + BVH_SPILL - 1) / BVH_SPILL * BVH_SPILL : 0;
+        if (getenv("DRMLT_VERBOSE")) fprintf(stderr, "[drmlt] BVH: %zu primitives, %zu binary / %zu 4-wide nodes, 4-wide depth %d (stack %d in LDS + %d in memory), %d median splits, %d-bit stack entries\n", order.size(), nodes.size(), nodes4.size(), depth4, BVH_STACK, ctx->ovf_entries, median_splits, P.bvh_stack16 ? 16 : 32);
         // intersection records go into leaf order; shading records stay where the emitters expect them
         std::vector<DPrim> np(order.size());
         for (size_t i = 0; i < order.size(); ++i) np[i] = ctx->prims[order[i]];
@@ -500,6 +519,7 @@ drmlt_ctx *drmlt_create(const drmlt_config *cfg, const drmlt_scene *scene, int d
     if (getenv("DRMLT_FEAT_ALL")) P.features = 15;
     P.mh_batch = P.kernel_variant == 4 ? (P.use_bvh ? 4 : 8) : 32; // v4: chains run free, the bookkeeping branch fires as soon as a few are parked
     if (const char *k = getenv("DRMLT_MH_BATCH")) P.mh_batch = std::max(1, std::min(64, atoi(k)));
+    P.bvh_overflow = nullptr; P.bvh_ovf_lanes = 0;
     P.trace_yield = 20; // measured on the 2000-triangle soup: 12 2.69e8, 16 2.78e8, 20 2.82e8, 24 2.82e8 mutations/s
     if (const char *k = getenv("DRMLT_TRACE_YIELD")) P.trace_yield = std::max(0, std::min(64, atoi(k)));
     P.trace_vote = 10; // measured on the 2000-triangle soup: 16 (plain majority) 2.70e8, 10 2.78e8, 5 2.73e8 mutations/s
@@ -554,6 +574,7 @@ static int seed_impl(drmlt_ctx *ctx, uint64_t seed, uint32_t chain_offset, uint3
     DevBuf d_lum;
     HIP_TRY(ctx, d_lum.alloc((size_t) n * sizeof(float)));
     const bool bdpt = ctx->cfg.technique == DRMLT_TECH_BDPT;
+    HIP_TRY(ctx, ensure_overflow(ctx, P, std::max<size_t>(n, 2 * (size_t) P.n_chains_alloc)));
     if (mmlt) launch_bootstrap_mmlt(P, n, d_lum.as<float>(), ctx->stream);
     else if (bdpt) launch_bootstrap_bdpt(P, n, d_lum.as<float>(), ctx->stream);
     else launch_bootstrap(P, n, d_lum.as<float>(), ctx->stream);
@@ -607,6 +628,7 @@ static int seed_impl(drmlt_ctx *ctx, uint64_t seed, uint32_t chain_offset, uint3
     HIP_TRY(ctx, hipMemcpyAsync(d_si.p, seed_index.data(), seed_index.size() * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(d_sl.p, seed_lum.data(), seed_lum.size() * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(ctx, hipMemsetAsync(ctx->d_err.p, 0, 64, ctx->stream));
+    HIP_TRY(ctx, ensure_overflow(ctx, P, 2 * (size_t) P.n_chains_alloc));
     if (mmlt) launch_init_chains_mmlt(P, d_si.as<uint32_t>(), d_sl.as<float>(), ctx->stream);
     else if (bdpt) launch_init_chains_bdpt(P, d_si.as<uint32_t>(), d_sl.as<float>(), ctx->stream);
     else launch_init_chains(P, d_si.as<uint32_t>(), d_sl.as<float>(), ctx->stream);
@@ -637,6 +659,7 @@ int drmlt_bootstrap_luminances(drmlt_ctx *ctx, uint64_t seed, uint32_t stream, u
     P.boot_stream = stream;
     DevBuf d_lum;
     HIP_TRY(ctx, d_lum.alloc((size_t) n * sizeof(float)));
+    HIP_TRY(ctx, ensure_overflow(ctx, P, std::max<size_t>(n, 2 * (size_t) P.n_chains_alloc)));
     if (ctx->cfg.technique == DRMLT_TECH_MMLT) launch_bootstrap_mmlt(P, n, d_lum.as<float>(), ctx->stream);
     else if (ctx->cfg.technique == DRMLT_TECH_BDPT) launch_bootstrap_bdpt(P, n, d_lum.as<float>(), ctx->stream);
     else launch_bootstrap(P, n, d_lum.as<float>(), ctx->stream);
@@ -748,6 +771,7 @@ int drmlt_run(drmlt_ctx *ctx, uint64_t total_mutations, volatile int *stop, drml
         HIP_TRY(ctx, ev.create());
         HIP_TRY(ctx, hipEventRecord(ev.a, ctx->stream));
         ctx->P.luminance_b = (float) ctx->b;
+        HIP_TRY(ctx, ensure_overflow(ctx, ctx->P, 2 * (size_t) ctx->P.n_chains_alloc + 128));
         if (ctx->cfg.algo == DRMLT_ALGO_PSSMLT) launch_mutate_pssmlt(ctx->P, n, ctx->mutation_base, ctx->stream);
         else if (ctx->cfg.technique == DRMLT_TECH_MMLT) launch_mutate_mmlt(ctx->P, n, ctx->mutation_base, ctx->stream);
         else if (ctx->cfg.technique == DRMLT_TECH_BDPT) launch_mutate_bdpt(ctx->P, n, ctx->mutation_base, ctx->stream);
@@ -875,6 +899,7 @@ int drmlt_eval_paths(drmlt_ctx *ctx, const float *u, uint32_t n, uint32_t dim, d
     HIP_TRY(ctx, d_u.alloc((size_t) n * dim * sizeof(float)));
     HIP_TRY(ctx, d_o.alloc((size_t) n * 8 * sizeof(float)));
     HIP_TRY(ctx, hipMemcpyAsync(d_u.p, u, (size_t) n * dim * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, ensure_overflow(ctx, ctx->P, std::max<size_t>(n, (size_t) ctx->P.n_chains_alloc)));
     if (mmlt) launch_eval_paths_mmlt(ctx->P, d_u.as<float>(), n, dim, d_o.as<float>(), ctx->stream);
     else launch_eval_paths(ctx->P, d_u.as<float>(), n, dim, d_o.as<float>(), ctx->stream);
     HIP_TRY(ctx, hipGetLastError());
@@ -920,6 +945,7 @@ int drmlt_render_pt(drmlt_ctx *ctx, uint32_t spp, uint64_t seed, float *out_rgb)
     P.film = film.as<float>();
     P.key0 = (uint32_t) seed; P.key1 = (uint32_t) (seed >> 32);
     const uint64_t n = (uint64_t) spp * P.width * P.height;
+    HIP_TRY(ctx, ensure_overflow(ctx, P, (size_t) 16384 * 64));
     launch_render_pt(P, n, 0u, 1.0f / (float) spp, ctx->stream);
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipMemcpyAsync(out_rgb, film.p, bytes, hipMemcpyDeviceToHost, ctx->stream));
@@ -938,6 +964,7 @@ int drmlt_eval_lists(drmlt_ctx *ctx, const float *u, uint32_t n, uint32_t dim, f
     HIP_TRY(ctx, d_u.alloc((size_t) n * dim * sizeof(float)));
     HIP_TRY(ctx, d_o.alloc((size_t) n * stride * sizeof(float)));
     HIP_TRY(ctx, hipMemcpyAsync(d_u.p, u, (size_t) n * dim * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, ensure_overflow(ctx, ctx->P, (size_t) ctx->P.n_chains_alloc));
     launch_eval_lists_bdpt(ctx->P, d_u.as<float>(), n, dim, d_o.as<float>(), stride, ctx->stream);
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipMemcpyAsync(out, d_o.p, (size_t) n * stride * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));

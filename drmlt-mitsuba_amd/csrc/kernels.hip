@@ -863,7 +863,7 @@ DEV V4Layout v4_layout(const DParams &P, uint32_t qcap) {
     return Y;
 }
 
-template <int FEAT, bool LDS_TABLES, bool STAMPS, bool STACK16 = false>
+template <int FEAT, bool LDS_TABLES, bool STAMPS, bool STACK16 = false, bool OVF = false>
 __global__ void __launch_bounds__(CHAIN_BLOCK) k_mutate_v4(DParams P, uint32_t n_mut, uint32_t mut_base) {
     // The parameter block is ~80 dwords, most of it used by one loop section only. Left to itself the compiler loads every
     // field it will ever need before the loop and then spills scalar registers into vector lanes all through the loop
@@ -896,7 +896,7 @@ __global__ void __launch_bounds__(CHAIN_BLOCK) k_mutate_v4(DParams P, uint32_t n
     int batch;
     constexpr bool RESUMABLE = (FEAT & 8) != 0; // BVH scenes: traversals survive loop iterations (device_path.h: Trav)
     Trav T;
-    T.active = false; T.cur = 0; T.sp = 0; T.any_hit = false; T.h = h; T.tmin = 0.f;
+    T.active = false; T.cur = 0; T.sp = 0; T.ovf = 0; T.any_hit = false; T.h = h; T.tmin = 0.f;
     T.o = T.d = T.inv = T.oi = mk3(0.f, 0.f, 0.f);
     trav_reset_counters(T);
     int rstate = 0; // ray of this lane: 0 none, 1 issued, 2 being traversed, 3 result waiting to be consumed
@@ -1133,8 +1133,8 @@ __global__ void __launch_bounds__(CHAIN_BLOCK) k_mutate_v4(DParams P, uint32_t n
             {
                 SECTION_PARAMS(Pt);
                 if (rstate == 1) { trav_begin(T, ps.o, ps.d, ps.tmin, ps.tmax, helper); rstate = 2; }
-                if (STACK16) trav_run<short>(Pt, T, rstate == 2, Pt.trace_yield);
-                else trav_run<int>(Pt, T, rstate == 2, Pt.trace_yield);
+                if (STACK16) trav_run<short, DParams, OVF>(Pt, T, rstate == 2, Pt.trace_yield);
+                else trav_run<int, DParams, OVF>(Pt, T, rstate == 2, Pt.trace_yield);
                 if (rstate == 2 && !T.active) rstate = 3;
             }
             if (prio) __builtin_amdgcn_s_setprio(3);
@@ -1290,8 +1290,14 @@ void launch_mutate(const DParams &P, uint32_t n_mut, uint32_t mut_base, hipStrea
             else if ((P.features & ~3) == 0 && (P.debug & 128)) hipLaunchKernelGGL((k_mutate_v4<3, true, true>), g4, block, lds, st, P, n_mut, mut_base); // diagnostic stamps
             else if ((P.features & ~3) == 0) hipLaunchKernelGGL((k_mutate_v4<3, true, false>), g4, block, lds, st, P, n_mut, mut_base);
             else if ((P.features & 8) == 0) hipLaunchKernelGGL((k_mutate_v4<7, true, false>), g4, block, lds, st, P, n_mut, mut_base);
-            else if (P.bvh_stack16) hipLaunchKernelGGL((k_mutate_v4<15, true, false, true>), g4, block, lds, st, P, n_mut, mut_base);
+            else if (P.bvh_overflow) { // trees deeper than the LDS column: the build with the spill / refill paths
+                if (P.bvh_stack16) hipLaunchKernelGGL((k_mutate_v4<15, true, false, true, true>), g4, block, lds, st, P, n_mut, mut_base);
+                else hipLaunchKernelGGL((k_mutate_v4<15, true, false, false, true>), g4, block, lds, st, P, n_mut, mut_base);
+            } else if (P.bvh_stack16) hipLaunchKernelGGL((k_mutate_v4<15, true, false, true>), g4, block, lds, st, P, n_mut, mut_base);
             else hipLaunchKernelGGL((k_mutate_v4<15, true, false>), g4, block, lds, st, P, n_mut, mut_base);
+        } else if (P.bvh_overflow) {
+            if (P.bvh_stack16) hipLaunchKernelGGL((k_mutate_v4<15, false, false, true, true>), g4, block, lds, st, P, n_mut, mut_base);
+            else hipLaunchKernelGGL((k_mutate_v4<15, false, false, false, true>), g4, block, lds, st, P, n_mut, mut_base);
         } else {
             if (P.bvh_stack16 && (P.debug & 128)) hipLaunchKernelGGL((k_mutate_v4<15, false, true, true>), g4, block, lds, st, P, n_mut, mut_base); // diagnostic stamps
             else if (P.bvh_stack16) hipLaunchKernelGGL((k_mutate_v4<15, false, false, true>), g4, block, lds, st, P, n_mut, mut_base);

@@ -1,5 +1,6 @@
-"""Host-side BVH builder (csrc/bvh_build.h), checked on the CPU: the kernels' per-lane traversal stack has BVH_STACK
-entries and no overflow test, so the builder has to bound the depth whatever the primitive distribution."""
+"""Host-side BVH builder (csrc/bvh_build.h), checked on the CPU: binary SAH tree, optional depth bound (median-split
+fallback), 4-wide collapse. The kernels' traversal stack keeps BVH_STACK entries in LDS and spills to memory beyond, so
+the depth is no longer bounded by the stack (tests/test_gpu_parity.py runs a deep tree on the device)."""
 import json
 import os
 import subprocess
@@ -17,21 +18,24 @@ def harness(tmp_path_factory):
     return lambda *a: json.loads(subprocess.run([exe, *map(str, a)], check=True, capture_output=True, text=True).stdout)
 
 
+@pytest.mark.parametrize("bound", [16, 64])
 @pytest.mark.parametrize("kind,n", [("soup", 3000), ("chain", 160), ("coincident", 500), ("soup", 49), ("soup", 20000)])
-def test_tree_is_complete_and_answers_like_brute_force(harness, kind, n):
-    """Binary SAH tree (depth <= 16) and the 4-wide tree collapsed from it (3 * depth4 <= the 24-entry stack)."""
-    r = harness(kind, n, 16)
+def test_tree_is_complete_and_answers_like_brute_force(harness, kind, n, bound):
+    """Binary SAH tree (depth <= bound; 64 = the builder's own limit, i.e. free) and the 4-wide tree collapsed from it."""
+    r = harness(kind, n, bound)
     assert r["ok"] and r["mismatches"] == 0, r
     assert r["nodes"] == r["leaves"] - 1                     # binary tree
     assert r["leaves"] == n                                  # one primitive per leaf
     assert r["leaves4"] == r["leaves"] and r["nodes4"] < r["nodes"]
-    assert r["depth"] <= 16 and 3 * r["depth4"] <= r["stack"] == 24, r
+    assert r["depth"] <= bound and r["depth4"] <= r["depth"] and r["stack"] == 24, r
+    if bound == 64:
+        assert r["median_splits"] == 0, r
 
 
 def test_depth_bound_forces_median_splits(harness):
     free = harness("chain", 160, 24)
     tight = harness("chain", 160, 9)                         # ceil(log2(160)) = 8 is the least a binary tree needs
     assert free["depth"] > 9 and tight["depth"] <= 9 and tight["median_splits"] > 0, (free, tight)
-    assert tight["ok"] and tight["mismatches"] == 0 and 3 * tight["depth4"] <= 24
+    assert tight["ok"] and tight["mismatches"] == 0 and tight["depth4"] <= 9
     # a bound below what a balanced tree needs is raised to that, never violated silently
     assert harness("soup", 3000, 4)["depth"] <= 12

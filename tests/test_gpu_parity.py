@@ -73,11 +73,12 @@ def test_bvh_and_brute_force_agree_on_device(pkg, ob, native_lib):
     assert np.allclose(a["luminance"][same], b["luminance"][same], rtol=1e-4, atol=1e-6)
 
 
-def test_deep_bvh_stays_within_the_traversal_stack(pkg, ob, native_lib, capfd):
+def test_deep_bvh_spills_its_traversal_stack(pkg, ob, native_lib, capfd):
     """Geometrically shrinking triangles make SAH peel a few primitives per level (a chain > 20 levels deep for this
-    scene). The kernels' stack holds 24 entries and a 4-wide node pushes up to 3, so the builder bounds the binary depth
-    (16, median-split fallback) and collapses to a 4-wide depth <= 8; DRMLT_BVH_MAX_DEPTH lowers the binary bound so that
-    the fallback is certainly exercised, and traversal must still agree with the brute-force loop."""
+    scene). The kernels' stack keeps 24 entries in LDS and a 4-wide node pushes up to 3: with the builder left free the
+    4-wide tree is deeper than 8 levels and the stacks must spill to (and refill from) their overflow area in memory;
+    DRMLT_BVH_MAX_DEPTH bounds the binary depth instead (median-split fallback). Either way the traversal must agree
+    with the brute-force loop."""
     import re
     sd = pkg.scenes.cornell_c2(64)
     white = 0
@@ -92,12 +93,14 @@ def test_deep_bvh_stays_within_the_traversal_stack(pkg, ob, native_lib, capfd):
     os.environ["DRMLT_BVH_THRESHOLD"] = "0"
     os.environ["DRMLT_VERBOSE"] = "1"
     try:
-        for bound, want_median in (("16", None), ("9", True)):
+        for bound, want_median in (("64", False), ("9", True)):
             os.environ["DRMLT_BVH_MAX_DEPTH"] = bound
             b = pkg.Context(cfg, sd).eval_paths(u)
             log = capfd.readouterr().err
-            m = re.search(r"BVH: (\d+) primitives, (\d+) binary / (\d+) 4-wide nodes, 4-wide depth (\d+) \(stack 24\), (\d+) median splits", log)
-            assert m and 3 * int(m.group(4)) <= 24 and int(m.group(3)) < int(m.group(2)) and (want_median is None or int(m.group(5)) > 0), log
+            m = re.search(r"BVH: (\d+) primitives, (\d+) binary / (\d+) 4-wide nodes, 4-wide depth (\d+) \(stack 24 in LDS \+ (\d+) in memory\), (\d+) median splits", log)
+            assert m and int(m.group(3)) < int(m.group(2)) and (int(m.group(6)) > 0) == want_median, log
+            if not want_median:
+                assert 3 * int(m.group(4)) > 24 and int(m.group(5)) > 0, log          # deeper than the LDS column: the overflow area is in use
             same = a["n_dims"] == b["n_dims"]
             assert same.mean() > 0.999
             assert np.allclose(a["luminance"][same], b["luminance"][same], rtol=1e-4, atol=1e-6)
