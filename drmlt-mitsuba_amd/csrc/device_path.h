@@ -509,7 +509,7 @@ struct Trav {
     float tmin;
     Hit h;
     int cur, sp;      // cur >= 0 inner node, < 0 leaf reference
-    int ovf;          // entries of this lane's stack that sit in the overflow area (multiples of BVH_SPILL; 0 for trees the LDS column holds)
+    int ovf;          // entries of this lane's stack that sit in the overflow area (0 for trees the LDS column holds)
     bool active, any_hit;
     uint32_t n_nodes, n_prims; // fetched so far by this lane (k_mutate_v4 reports them: the scene part of the algorithmic bytes)
     uint32_t it_inner, it_leaf; // wave-uniform: traversal iterations of each kind (lane occupancy = n_nodes / (64 it_inner) ...)
@@ -536,22 +536,25 @@ DEV unsigned umax2(unsigned a, unsigned b) { return a < b ? b : a; }
 // 2000-triangle soup, all of it occupancy).
 // OVF: compile the spill / refill paths in (k_mutate_v4 has a build without them for trees that fit the column: they cost
 // 4 % there even when never taken).
-template <class StackT, class PT, bool OVF = true> DEV void trav_run(const PT &P, Trav &T, bool mine, int yield_lanes) {
-    __shared__ StackT bvh_stack[(BVH_STACK + 2) * 64]; // + 2: the branch-free pushes write one or two entries above the top
+// CAP: entries of the LDS column (k_mutate_v4 gives its 32-bit stacks 12 instead of 24 -- with the overflow paths the column
+// only has to hold the hot top of the stack, and 3.5 KB instead of 6.5 KB keep eight waves on a CU).
+template <class StackT, class PT, bool OVF = true, int CAP = BVH_STACK> DEV void trav_run(const PT &P, Trav &T, bool mine, int yield_lanes) {
+    constexpr int SPILL = CAP / 2; // entries moved at a time
+    __shared__ StackT bvh_stack[(CAP + 2) * 64]; // + 2: the branch-free pushes write one or two entries above the top
     StackT *const stk = bvh_stack + (threadIdx.x & 63u); // every kernel that traces runs one wave per workgroup
-    // The LDS column holds BVH_STACK entries (+ 2 spare); a tree deeper than BVH_STACK / 3 levels can need more. Rare slow
-    // paths: before a node's pushes could run past the column its BVH_SPILL OLDEST entries move to this lane's column of an
-    // overflow area in memory and the rest slides down; a pop that finds the column empty brings the newest BVH_SPILL back.
+    // The LDS column holds CAP entries (+ 2 spare); a tree deeper than CAP / 3 levels can need more. Slow paths: before a
+    // node's pushes could run past the column its SPILL OLDEST entries move to this lane's column of an overflow area in
+    // memory and the rest slides down; a pop that finds the column empty brings the newest SPILL back.
     const size_t ovf_col = (size_t) blockIdx.x * 64u + (threadIdx.x & 63u);
     auto spill = [&]() {
-        for (int i = 0; i < BVH_SPILL; ++i) P.bvh_overflow[(size_t) (T.ovf + i) * P.bvh_ovf_lanes + ovf_col] = (int) stk[i * 64];
-        for (int i = BVH_SPILL; i < T.sp; ++i) stk[(i - BVH_SPILL) * 64] = stk[i * 64];
-        T.sp -= BVH_SPILL; T.ovf += BVH_SPILL;
+        for (int i = 0; i < SPILL; ++i) P.bvh_overflow[(size_t) (T.ovf + i) * P.bvh_ovf_lanes + ovf_col] = (int) stk[i * 64];
+        for (int i = SPILL; i < T.sp; ++i) stk[(i - SPILL) * 64] = stk[i * 64];
+        T.sp -= SPILL; T.ovf += SPILL;
     };
     auto refill = [&]() {
-        T.ovf -= BVH_SPILL;
-        for (int i = 0; i < BVH_SPILL; ++i) stk[i * 64] = (StackT) P.bvh_overflow[(size_t) (T.ovf + i) * P.bvh_ovf_lanes + ovf_col];
-        T.sp = BVH_SPILL;
+        T.ovf -= SPILL;
+        for (int i = 0; i < SPILL; ++i) stk[i * 64] = (StackT) P.bvh_overflow[(size_t) (T.ovf + i) * P.bvh_ovf_lanes + ovf_col];
+        T.sp = SPILL;
     };
     const bool has_ovf = OVF && P.bvh_overflow != nullptr; // wave-uniform
     int finished = 0;
@@ -566,7 +569,7 @@ template <class StackT, class PT, bool OVF = true> DEV void trav_run(const PT &P
             if (run && T.cur >= 0) {
                 const DBvh4Node N = load_global16(P.bvh + T.cur);
                 T.n_nodes++;
-                if (has_ovf && T.sp > BVH_STACK - 3) spill();
+                if (has_ovf && T.sp > CAP - 3) spill();
                 if constexpr (sizeof(StackT) == 2) {
                     // 16-bit child references: the sort key carries the child itself -- entry distance in the upper half (its bit
                     // pattern orders like an unsigned: tn >= tmin >= 0; 7 mantissa bits are plenty for an ORDER), reference in

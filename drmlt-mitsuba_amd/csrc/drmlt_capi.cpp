@@ -373,7 +373,8 @@ drmlt_ctx *drmlt_create(const drmlt_config *cfg, const drmlt_scene *scene, int d
         // 3 * depth4 bound it: up to BVH_STACK that is the LDS column (the branch-free pushes use its two spare rows); deeper
         // trees get an overflow area in memory, sized per launch (ensure_overflow)
         ctx->bvh_depth = depth4;
-        ctx->ovf_entries = 3 * depth4 > BVH_STACK ? (3 * depth4 + 3 + BVH_SPILL - 1) / BVH_SPILL * BVH_SPILL : 0;
+        // (k_mutate_v4 keeps only 12 entries of a 32-bit stack in LDS: those scenes always have the area)
+        ctx->ovf_entries = (3 * depth4 > BVH_STACK || !P.bvh_stack16) ? (3 * depth4 + 3 + BVH_SPILL - 1) / BVH_SPILL * BVH_SPILL : 0;
         if (getenv("DRMLT_VERBOSE")) fprintf(stderr, "[drmlt] BVH: %zu primitives, %zu binary / %zu 4-wide nodes, 4-wide depth %d (stack %d in LDS + %d in memory), %d median splits, %d-bit stack entries\n", order.size(), nodes.size(), nodes4.size(), depth4, BVH_STACK, ctx->ovf_entries, median_splits, P.bvh_stack16 ? 16 : 32);
         // intersection records go into leaf order; shading records stay where the emitters expect them
         std::vector<DPrim> np(order.size());

@@ -774,6 +774,7 @@ __global__ void __launch_bounds__(CHAIN_BLOCK) k_mutate_v3(DParams P, uint32_t n
 // Chains are the same as k_mutate_v2/v3's (same addressed draws, same arithmetic per chain).
 #define V4_STRIDE 33u // row stride of the sampler rows: (row + chain) mod 32 banks serve per-chain AND per-dimension access patterns
 #define V4_QCAP 160u  // splat queue entries: flushed when a bookkeeping branch (at most 3 x 32 new entries) might not fit
+#define V4_STACK32_CAP 12 // LDS entries of a 32-bit traversal stack (the rest spills): 14 rows of 256 B keep eight waves on a CU
 #define V4_QCAP_BVH 100u // BVH scenes: their kernel also keeps the traversal stack in LDS (6 KB); flushes are a negligible part of it
 
 // field-by-field copy of the parameter block out of the kernarg segment (constant address space: scalar loads)
@@ -1134,7 +1135,7 @@ __global__ void __launch_bounds__(CHAIN_BLOCK) k_mutate_v4(DParams P, uint32_t n
                 SECTION_PARAMS(Pt);
                 if (rstate == 1) { trav_begin(T, ps.o, ps.d, ps.tmin, ps.tmax, helper); rstate = 2; }
                 if (STACK16) trav_run<short, DParams, OVF>(Pt, T, rstate == 2, Pt.trace_yield);
-                else trav_run<int, DParams, OVF>(Pt, T, rstate == 2, Pt.trace_yield);
+                else trav_run<int, DParams, true, V4_STACK32_CAP>(Pt, T, rstate == 2, Pt.trace_yield); // always with the overflow paths
                 if (rstate == 2 && !T.active) rstate = 3;
             }
             if (prio) __builtin_amdgcn_s_setprio(3);
@@ -1290,19 +1291,15 @@ void launch_mutate(const DParams &P, uint32_t n_mut, uint32_t mut_base, hipStrea
             else if ((P.features & ~3) == 0 && (P.debug & 128)) hipLaunchKernelGGL((k_mutate_v4<3, true, true>), g4, block, lds, st, P, n_mut, mut_base); // diagnostic stamps
             else if ((P.features & ~3) == 0) hipLaunchKernelGGL((k_mutate_v4<3, true, false>), g4, block, lds, st, P, n_mut, mut_base);
             else if ((P.features & 8) == 0) hipLaunchKernelGGL((k_mutate_v4<7, true, false>), g4, block, lds, st, P, n_mut, mut_base);
-            else if (P.bvh_overflow) { // trees deeper than the LDS column: the build with the spill / refill paths
-                if (P.bvh_stack16) hipLaunchKernelGGL((k_mutate_v4<15, true, false, true, true>), g4, block, lds, st, P, n_mut, mut_base);
-                else hipLaunchKernelGGL((k_mutate_v4<15, true, false, false, true>), g4, block, lds, st, P, n_mut, mut_base);
-            } else if (P.bvh_stack16) hipLaunchKernelGGL((k_mutate_v4<15, true, false, true>), g4, block, lds, st, P, n_mut, mut_base);
-            else hipLaunchKernelGGL((k_mutate_v4<15, true, false>), g4, block, lds, st, P, n_mut, mut_base);
-        } else if (P.bvh_overflow) {
-            if (P.bvh_stack16) hipLaunchKernelGGL((k_mutate_v4<15, false, false, true, true>), g4, block, lds, st, P, n_mut, mut_base);
-            else hipLaunchKernelGGL((k_mutate_v4<15, false, false, false, true>), g4, block, lds, st, P, n_mut, mut_base);
-        } else {
-            if (P.bvh_stack16 && (P.debug & 128)) hipLaunchKernelGGL((k_mutate_v4<15, false, true, true>), g4, block, lds, st, P, n_mut, mut_base); // diagnostic stamps
-            else if (P.bvh_stack16) hipLaunchKernelGGL((k_mutate_v4<15, false, false, true>), g4, block, lds, st, P, n_mut, mut_base);
-            else hipLaunchKernelGGL((k_mutate_v4<15, false, false>), g4, block, lds, st, P, n_mut, mut_base);
-        }
+            // BVH: 32-bit stacks always run the build with the spill / refill paths (short LDS column), 16-bit stacks only for
+            // trees deeper than their column
+            else if (!P.bvh_stack16) hipLaunchKernelGGL((k_mutate_v4<15, true, false, false, true>), g4, block, lds, st, P, n_mut, mut_base);
+            else if (P.bvh_overflow) hipLaunchKernelGGL((k_mutate_v4<15, true, false, true, true>), g4, block, lds, st, P, n_mut, mut_base);
+            else hipLaunchKernelGGL((k_mutate_v4<15, true, false, true>), g4, block, lds, st, P, n_mut, mut_base);
+        } else if (!P.bvh_stack16) hipLaunchKernelGGL((k_mutate_v4<15, false, false, false, true>), g4, block, lds, st, P, n_mut, mut_base);
+        else if (P.bvh_overflow) hipLaunchKernelGGL((k_mutate_v4<15, false, false, true, true>), g4, block, lds, st, P, n_mut, mut_base);
+        else if (P.debug & 128) hipLaunchKernelGGL((k_mutate_v4<15, false, true, true>), g4, block, lds, st, P, n_mut, mut_base); // diagnostic stamps
+        else hipLaunchKernelGGL((k_mutate_v4<15, false, false, true>), g4, block, lds, st, P, n_mut, mut_base);
     } else if (P.kernel_variant == 3) { // 32 chains per wave, rows of 32 floats
         size_t lds = (D + 2 * D4) * 32 * sizeof(float);
         if (P.tables_in_lds) lds += (size_t) P.n_shade * 64 + (size_t) P.n_bsdfs * 48 + (size_t) P.n_emitters * 32;
