@@ -369,3 +369,39 @@ def test_state_machine_kernel_equals_nested_kernel(pkg, ob, kw, native_lib):
     # ... and neither does tracing the shadow rays on a partner lane (k_mutate_v3)
     (c3, u3), s3, f3 = results[3]
     assert np.array_equal(u1, u3) and s1.accepted == s3.accepted and s1.rays == s3.rays
+
+
+def test_large_scene_short_stack_column_spills_and_refills(pkg, ob, native_lib, capfd):
+    """40 000 triangles: leaf references need 32 bits, the SAH tree is 11+ four-wide levels deep. k_mutate_v4 keeps 12
+    stack entries per lane in LDS and spills the rest to memory; k_mutate_v3 traverses with the full 24-entry column (and
+    the same overflow area). Same chains, bit for bit -- and f(u) through the BVH equals f(u) through the brute-force loop."""
+    import re
+    sd = pkg.scenes.triangle_soup(40000, 32)
+    n_chains, n_mut = 2048, 12
+    cfg = pkg.abi.make_config(type="orbital", max_depth=8, direct_samples=-1, luminance_samples=20000, work_units=n_chains, sample_count=1)
+    os.environ["DRMLT_VERBOSE"] = "1"
+    try:
+        res = []
+        for env in (dict(DRMLT_KERNEL=4), dict(DRMLT_KERNEL=3)):
+            ctx = _ctx_with_env(pkg, cfg, sd, **env)
+            ctx.seed(0x99)
+            ctx.run(n_chains * n_mut)
+            res.append((ctx.chain_state(34), ctx.stats(), ctx.film()))
+        log = capfd.readouterr().err
+    finally:
+        del os.environ["DRMLT_VERBOSE"]
+    m = re.search(r"4-wide depth (\d+) \(stack 24 in LDS \+ (\d+) in memory\), (\d+) median splits, 32-bit stack entries", log)
+    assert m and int(m.group(1)) > 8 and int(m.group(2)) > 0 and int(m.group(3)) == 0, log
+    ((c4, u4), s4, f4), ((c3, u3), s3, f3) = res
+    assert np.array_equal(u4, u3) and s4.accepted == s3.accepted and s4.rays == s3.rays
+    assert lum(f4).sum() == pytest.approx(lum(f3).sum(), rel=1e-5)
+    u = np.random.default_rng(3).random((4096, 50), dtype=np.float32)
+    b = pkg.Context(cfg, sd).eval_paths(u)
+    os.environ["DRMLT_BVH_THRESHOLD"] = "1000000"
+    try:
+        a = pkg.Context(cfg, sd).eval_paths(u)
+    finally:
+        del os.environ["DRMLT_BVH_THRESHOLD"]
+    same = a["n_dims"] == b["n_dims"]
+    assert same.mean() > 0.995
+    assert np.allclose(a["luminance"][same], b["luminance"][same], rtol=1e-4, atol=1e-6)
