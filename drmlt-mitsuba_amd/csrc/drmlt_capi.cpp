@@ -839,8 +839,8 @@ int drmlt_stats_get(drmlt_ctx *ctx, drmlt_stats *o) {
     HIP_TRY(ctx, hipMemcpyAsync(v, ctx->d_stats.p, sizeof v, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     if ((ctx->P.debug & 128) && ctx->cfg.technique == DRMLT_TECH_BDPT) // diagnostic stamps of eval_bdpt / k_mutate_bdpt
-        fprintf(stderr, "[drmlt stamps] bdpt cycles per wave, summed: walks %llu pair loop %llu whole chain loop %llu | evaluations %llu\n",
-                v[16], v[17], v[18], v[19]);
+        fprintf(stderr, "[drmlt stamps] bdpt cycles per wave, summed: walks %llu pair loop %llu whole chain loop %llu | evaluations %llu | stages (all evaluations) %llu, weights + splats %llu, counters + commit %llu\n",
+                v[16], v[17], v[18], v[19], v[20], v[21], v[22]);
     else if (ctx->P.debug & 128) // diagnostic stamps of k_mutate_v2 / v3
         fprintf(stderr, "[drmlt stamps] cycles: mh %llu trace %llu step %llu | iterations %llu mh-branches %llu tracing-lanes %llu\n",
                 v[16], v[17], v[18], v[19], v[20], v[21]),

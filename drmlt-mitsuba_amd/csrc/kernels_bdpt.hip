@@ -147,13 +147,17 @@ template <int FEAT, int OCC> __global__ void __launch_bounds__(CHAIN_BLOCK, OCC)
     const bool amap = P.acceptance_map != 0;
     const bool mix = P.use_mixture != 0;
 
-    const unsigned long long k0 = (P.debug & 128) ? __builtin_amdgcn_s_memtime() : 0ull;
+    const bool dbg = (P.debug & 128) != 0;
+    unsigned long long t_stages = 0, t_splat = 0, t_commit = 0;
+#define BSTAMP() (dbg ? __builtin_amdgcn_s_memtime() : 0ull)
+    const unsigned long long k0 = BSTAMP();
     if (live) for (uint32_t it = 0; it < n_mut; ++it) {
         const uint32_t m = mut_base + it;
         const u4 coins = philox4x32_10(P.key0, P.key1, 0u, m, smp.chain, TAG_COIN);
         const bool large = u32_to_unit(coins.x) < P.p_large;
         smp.major = m;
         smp.large = large;
+        const unsigned long long b0 = BSTAMP();
         float y_lum = 0.f, z_lum = 0.f;
         uint32_t ns1 = 0, ne1 = 0, nd1 = 0, ns2 = 0, ne2 = 0, nd2 = 0;
         float a1 = 0.f, a2 = 0.f;
@@ -233,6 +237,7 @@ template <int FEAT, int OCC> __global__ void __launch_bounds__(CHAIN_BLOCK, OCC)
                 }
             }
         }
+        const unsigned long long b1 = BSTAMP();
         const bool y_splatted = !mix && P.type == 0 && doSecond && !lum_invalid(z_lum); // Green went on to the reverse move
 
         // Expectation weights. The current state's share is accumulated and its list splatted once, when the state is
@@ -259,6 +264,7 @@ template <int FEAT, int OCC> __global__ void __launch_bounds__(CHAIN_BLOCK, OCC)
             }
         }
 
+        const unsigned long long b2 = BSTAMP();
         if (large) {
             ct.large_acc1l += 1u + (acc1 ? 1u << 16 : 0u);
             if (doSecond) ct.acc1b_secl += 1u << 16;
@@ -287,6 +293,8 @@ template <int FEAT, int OCC> __global__ void __launch_bounds__(CHAIN_BLOCK, OCC)
                 else if (!mix) list_splat_const(P, L0, mk3(0.f, 1.f, 0.f));
             }
         }
+        const unsigned long long b3 = BSTAMP();
+        t_stages += b1 - b0; t_splat += b2 - b1; t_commit += b3 - b2;
     }
 
     if (live) {
@@ -303,7 +311,8 @@ template <int FEAT, int OCC> __global__ void __launch_bounds__(CHAIN_BLOCK, OCC)
     v[8] = wave_sum(ct.rays);
     if (lane == 0)
         for (int i = 0; i < 9; ++i) atomicAdd(P.stats + i, v[i]);
-    if ((P.debug & 128) && lane == 0) atomicAdd(P.stats + 18, __builtin_amdgcn_s_memtime() - k0); // whole chain loop, per wave
+    if (dbg && lane == 0) { atomicAdd(P.stats + 18, __builtin_amdgcn_s_memtime() - k0); atomicAdd(P.stats + 20, t_stages); atomicAdd(P.stats + 21, t_splat); atomicAdd(P.stats + 22, t_commit); } // per wave
+#undef BSTAMP
 }
 
 // u: [sensor S | emitter E | direct Dd] per point (dim >= S + E + Dd); out: rows of `stride` floats:
