@@ -263,7 +263,8 @@ DEV float vert_pdf_sa(const DParams &P, const DBsdf &B, const BVert &v, f3 wi, f
 
 // ------------------------------------------------------------------ the estimator
 // LDS rows used for the MIS sweep, per lane: pImp[NV], pRad[NV], gInv[NV] from row `mis_row`, NV = maxDepth + 3.
-template <class TablesT>
+// FEAT: as for trace() -- 15 with BVH traversal (its LDS stack, its registers), 7 without
+template <int FEAT = 15, class TablesT>
 DEV void eval_mmlt(const DParams &P, const TablesT &T, MSampler &smp, int depth, uint32_t mis_row, MmltResult &R) {
     const uint32_t lane = smp.lane;
     const uint32_t NV = (uint32_t) P.max_depth + 3u;
@@ -397,7 +398,7 @@ DEV void eval_mmlt(const DParams &P, const TablesT &T, MSampler &smp, int depth,
         }
 
         // ---- PathEdge::sampleNext: next surface along the ray
-        const Hit h = trace(P, cur.p, d, ray_eps_closest(cur.p), INFINITY, false);
+        const Hit h = trace<FEAT>(P, cur.p, d, ray_eps_closest(cur.p), INFINITY, false);
         R.nrays++;
         if (h.prim < 0) WALK_FAIL;
         const DShade Sh = T.shade(h.prim);
@@ -490,7 +491,7 @@ DEV void eval_mmlt(const DParams &P, const TablesT &T, MSampler &smp, int depth,
         value = thr * vert_eval(P, Bs, vs, dc, true) * vert_eval(P, Bt, vt, -dc, false);
         if (is_zero3(value)) return;
         // mutual visibility, ray from vt towards vs (edge.cpp:575-600)
-        const Hit h = trace(P, vt.p, -dc, ray_eps_closest(vt.p), len * (1.f - SHADOW_EPSILON_F), true);
+        const Hit h = trace<FEAT>(P, vt.p, -dc, ray_eps_closest(vt.p), len * (1.f - SHADOW_EPSILON_F), true);
         R.nrays++;
         if (h.prim >= 0) return;
         const float cs = fabsf(dot3(vs.n, dc)), ct = fabsf(dot3(vt.n, dc));

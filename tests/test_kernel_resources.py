@@ -1,0 +1,37 @@
+"""Occupancy of the chain kernels, read from the compiler's resource remarks of the build (libdrmlt_amd.so.resources).
+Two waves per SIMD are worth almost 2x on this hardware (a single wave64 issues a vector instruction every 4 cycles at
+best, the SIMD one every 2): a kernel that silently grows past 256 registers loses half its throughput."""
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def kernels(path):
+    out, name = {}, None
+    for line in open(path, errors="replace"):
+        m = re.search(r"remark: Function Name: (\S+)", line)
+        if m:
+            name = m.group(1)
+            out[name] = {}
+            continue
+        m = re.search(r"remark:\s+(VGPRs|AGPRs|ScratchSize \[bytes/lane\]|Occupancy \[waves/SIMD\]|LDS Size \[bytes/block\]): (\d+)", line)
+        if m and name:
+            out[name][m.group(1).split(" ")[0]] = int(m.group(2))
+    return out
+
+
+def test_chain_kernels_keep_their_occupancy(native_lib):
+    res = os.path.join(ROOT, "drmlt-mitsuba_amd", "libdrmlt_amd.so.resources")
+    assert os.path.exists(res), "the Makefile writes it next to the library"
+    k = kernels(res)
+    v4 = {n: r for n, r in k.items() if n.startswith("_Z11k_mutate_v4")}
+    assert len(v4) >= 8
+    for n, r in v4.items():
+        assert r["Occupancy"] >= 2 and r["VGPRs"] + r["AGPRs"] <= 256, (n, r)
+    headline = k["_Z11k_mutate_v4ILi0ELb1ELb0ELb0ELb0EEv7DParamsjj"]      # config 2's build
+    assert headline["VGPRs"] <= 168 and headline["ScratchSize"] <= 16, headline
+    for n in ("_Z13k_mutate_mmltILi7EEv7DParamsjj", "_Z13k_mutate_mmltILi15EEv7DParamsjj", "_Z13k_mutate_bdptILi7ELi2EEv7DParamsjj"):
+        assert k[n]["Occupancy"] >= 2 and k[n]["VGPRs"] + k[n]["AGPRs"] <= 256, (n, k[n])
+    # static LDS: only the builds that traverse a BVH carry a stack
+    assert k["_Z13k_mutate_mmltILi7EEv7DParamsjj"]["LDS"] == 0 and k["_Z13k_mutate_bdptILi7ELi2EEv7DParamsjj"]["LDS"] == 0
