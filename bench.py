@@ -38,27 +38,27 @@ CONFIGS = {
               what="Cornell box %(res)dx%(res)d, integrator=drmlt technique=path type=orbital, %(chains)d chains/GPU, "
                    "sampleCount %(spp)d (BASELINE.json configs[1])"),
     "3": dict(scene=("door_c3", {}), res=512, cfg=dict(technique="path", type="green", max_depth=8, rr_depth=5),
-              spp=64, kernel="k_mutate_v4", pmc="r02_c3_pmc.json",
+              spp=256, kernel="k_mutate_v4", pmc="r02_c3_pmc.json",
               what="door scene (occluded area light, rough-conductor floor) %(res)dx%(res)d, drmlt technique=path type=green, "
                    "%(chains)d chains/GPU, sampleCount %(spp)d (BASELINE.json configs[2])"),
     # 131 072 chains: k_mutate_mmlt runs one chain per lane at 256 VGPRs, so 65 536 chains are 1024 waves = one per SIMD;
     # twice as many put two on a SIMD (7.3e8 -> 1.31e9 mutations/s). BASELINE's config 5 does not fix the chain count.
     "5": dict(scene=("caustic_c5", {}), res=512, chains=131072,
-              cfg=dict(technique="mmlt", type="orbital", max_depth=6, fix_emitter_path=1, acceptance_map=1), spp=64,
+              cfg=dict(technique="mmlt", type="orbital", max_depth=6, fix_emitter_path=1, acceptance_map=1), spp=256,
               kernel="k_mutate_mmlt", pmc="r02_c5_pmc.json",
               what="glass caustic (dielectric sphere, small sphere light) %(res)dx%(res)d, drmlt technique=mmlt type=orbital "
                    "fixEmitterPath acceptanceMap, %(chains)d chains/GPU, sampleCount %(spp)d (BASELINE.json configs[4])"),
     # 131 072 chains, as config 5: above 65 536 the launcher picks the two-waves-per-SIMD build of k_mutate_bdpt
     "bdpt": dict(scene=("cornell_c2", {}), res=512, chains=131072, cfg=dict(technique="bdpt", type="orbital", max_depth=8, rr_depth=5),
-                 spp=64, kernel="k_mutate_bdpt", pmc="r02_bdpt_pmc.json",
+                 spp=256, kernel="k_mutate_bdpt", pmc="r02_bdpt_pmc.json",
                  what="Cornell box %(res)dx%(res)d, drmlt technique=bdpt type=orbital, %(chains)d chains/GPU, sampleCount %(spp)d"),
     "soup": dict(scene=("triangle_soup", dict(n_tris=2000)), res=512,
-                 cfg=dict(technique="path", type="orbital", max_depth=8, rr_depth=5), spp=64, kernel="k_mutate_v4",
+                 cfg=dict(technique="path", type="orbital", max_depth=8, rr_depth=5), spp=256, kernel="k_mutate_v4",
                  pmc="r02_soup_pmc.json",
                  what="closed room with 2000 random triangles (BVH in HBM) %(res)dx%(res)d, drmlt technique=path type=orbital, "
                       "%(chains)d chains/GPU, sampleCount %(spp)d"),
     "soup50k": dict(scene=("triangle_soup", dict(n_tris=50000)), res=512,
-                    cfg=dict(technique="path", type="orbital", max_depth=8, rr_depth=5), spp=64, kernel="k_mutate_v4",
+                    cfg=dict(technique="path", type="orbital", max_depth=8, rr_depth=5), spp=256, kernel="k_mutate_v4",
                     pmc="r02_soup50k_pmc.json",
                     what="closed room with 50000 random triangles (BVH, primitive and shading records: 9.6 MB in HBM / L2; "
                          "32-bit traversal stacks) %(res)dx%(res)d, drmlt technique=path type=orbital, %(chains)d chains/GPU, "
