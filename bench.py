@@ -222,8 +222,8 @@ def main():
 
     def step():
         ctx.run(step_mutations)
-        if use_dist:  # the render's film exchange: reduce-scatter + scalar all-reduce + tile develop, all in C++
-            ctx.exchange_tiled(b, want_tile=False)
+        if use_dist and not os.environ.get("BENCH_SKIP_EXCHANGE"):  # the render's film exchange: reduce-scatter + scalar all-reduce + tile develop, all in C++
+            ctx.exchange_tiled(b, want_tile=False, wait=False)   # enqueued behind the chain kernel; the closing barrier waits for it
 
     for _ in range(args.warmup):
         step()

@@ -163,10 +163,14 @@ class Context:
     def comm_init(self, unique_id, rank, world):
         self._chk(self.L.drmlt_comm_init(self.h, unique_id, rank, world))
 
-    def exchange_tiled(self, b, want_tile=True):
+    def exchange_tiled(self, b, want_tile=True, wait=True):
         """reduce-scatter(sum) of the film + scalar all-reduce + develop of this rank's tile.
-        Returns (tile [rows, W, 3] or None, (row_lo, row_hi), mean b)."""
+        Returns (tile [rows, W, 3] or None, (row_lo, row_hi), mean b). wait=False (with want_tile=False): everything is only
+        ENQUEUED on the context's stream -- a render step's exchange; returns (None, None, b) without touching the host."""
         bb, lo, hi = C.c_double(b), C.c_int(), C.c_int()
+        if not want_tile and not wait:
+            self._chk(self.L.drmlt_exchange_tiled(self.h, C.byref(bb), None, None, None))
+            return None, None, b
         buf = np.zeros((self.height, self.width, 3), dtype=np.float32) if want_tile else None
         self._chk(self.L.drmlt_exchange_tiled(self.h, C.byref(bb), buf.ctypes.data if want_tile else None,
                                               C.byref(lo), C.byref(hi)))

@@ -101,3 +101,6 @@ struct drmlt_ctx {
 void drmlt_comm_release(drmlt_comm *c); // drmlt_node.cpp
 void launch_lum_sum(const float *film, const float *importance, uint32_t n_pixels, double *sum, hipStream_t st);
 void launch_develop(const float *film, const float *direct, const float *importance, float factor, uint32_t n, float *out, hipStream_t st);
+void launch_develop_dev(const float *film, const float *importance, const double *scal, float inv_world, float inv_pixels, int acceptance_map, uint32_t n,
+                        float *out, hipStream_t st);
+void launch_set2(double *p, double a, double b, hipStream_t st);

@@ -121,17 +121,23 @@ void tile_range(const drmlt_ctx *ctx, int rank, int world, int &lo, int &hi) {
 }
 
 // Steps 2-5 of the exchange, once the summed tile sits in comm->tile: tile luminance, scalar all-reduce, develop.
-int finish_tile(drmlt_ctx *ctx, const RcclApi *R, double *b_inout, const float *direct_tile_or_null, float *tile_host_or_null) {
+int finish_tile(drmlt_ctx *ctx, const RcclApi *R, double *b_inout, const float *direct_tile_or_null, float *tile_host_or_null, bool want_results = true) {
     drmlt_comm *c = ctx->comm;
     int lo, hi;
     tile_range(ctx, c->rank, c->world, lo, hi);
     const uint32_t npix = (uint32_t) (hi - lo) * ctx->P.width, n = npix * 3;
     const float *imp = ctx->P.importance ? ctx->P.importance + (size_t) lo * ctx->P.width : nullptr;
     double host[2] = {0.0, b_inout ? *b_inout : ctx->b};
-    HIP_TRY(ctx, hipMemcpyAsync(c->scal.p, host, sizeof host, hipMemcpyHostToDevice, ctx->stream));
+    launch_set2(c->scal.as<double>(), host[0], host[1], ctx->stream); // (a kernel, not a copy from pageable memory: nothing here waits for the host)
     if (npix) launch_lum_sum(c->tile.as<float>(), imp, npix, c->scal.as<double>(), ctx->stream);
     HIP_TRY(ctx, hipGetLastError());
     if (c->comm) NCCL_TRY(ctx, R, R->AllReduce(c->scal.p, c->scal.p, 2, ncclDouble, ncclSum, c->comm, ctx->stream));
+    if (!want_results) { // nobody reads the tile or the mean b now: develop with the device-resident sums, no host round trip
+        if (n) launch_develop_dev(c->tile.as<float>(), imp, c->scal.as<double>(), c->comm ? 1.f / (float) c->world : 1.f,
+                                  1.f / ((float) ctx->P.width * (float) ctx->P.height), ctx->cfg.acceptance_map, n, c->out.as<float>(), ctx->stream);
+        HIP_TRY(ctx, hipGetLastError());
+        return DRMLT_OK;
+    }
     HIP_TRY(ctx, hipMemcpyAsync(host, c->scal.p, sizeof host, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     const double b_mean = c->comm ? host[1] / c->world : host[1]; // loopback: the node hands in the job's b
@@ -197,7 +203,9 @@ int drmlt_exchange_tiled(drmlt_ctx *ctx, double *b_inout, float *tile_host_or_nu
     tile_range(ctx, c->rank, c->world, lo, hi);
     if (row_lo) *row_lo = lo;
     if (row_hi) *row_hi = hi;
-    return finish_tile(ctx, R, b_inout, nullptr, tile_host_or_null);
+    // tile_host_or_null == NULL and row_lo == NULL: fire and forget (a render step's exchange): everything is enqueued on the
+    // context's stream, *b_inout is read but not updated, the developed tile stays on the device
+    return finish_tile(ctx, R, b_inout, nullptr, tile_host_or_null, tile_host_or_null != nullptr || row_lo != nullptr);
 }
 
 } // extern "C"

@@ -1251,8 +1251,25 @@ __global__ void __launch_bounds__(256) k_lum_sum(const float *film, const float 
 
 __global__ void __launch_bounds__(256) k_develop(const float *film, const float *direct, const float *importance, float factor, uint32_t n,
                                                  float *out) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = film[i] * (importance ? factor * importance[i / 3u] : factor) + (direct ? direct[i] : 0.f); // :841-847
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+        out[i] = film[i] * (importance ? factor * importance[i / 3u] : factor) + (direct ? direct[i] : 0.f); // :841-847
+}
+
+__global__ void k_set2(double *p, double a, double b) { p[0] = a; p[1] = b; }
+void launch_set2(double *p, double a, double b, hipStream_t st) { hipLaunchKernelGGL(k_set2, dim3(1), dim3(1), 0, st, p, a, b); }
+
+// Grids of the film kernels are capped (grid-stride loops): a launch of MORE than 2048 workgroups in front of a chain kernel
+// costs that kernel 14 % (k_mutate_v4 41.0 -> 47.0 ms after a 3072-block develop, whatever the develop reads or writes;
+// 2048 blocks and fewer: no effect) -- the chain kernel's 2048 workgroups fill the device exactly, eight to a CU, two to a
+// SIMD, and whatever the dispatcher still holds of the larger grid skews that placement.
+#define AUX_GRID_CAP 1024u
+// the same with the factor taken from device memory: scal = {sum of the film's luminance over all ranks, sum of the ranks' b}
+// (drmlt_exchange_tiled without a host round trip: the exchange of a step is enqueued behind its chain kernel)
+__global__ void __launch_bounds__(256) k_develop_dev(const float *film, const float *importance, const double *scal, float inv_world, float inv_pixels,
+                                                     int acceptance_map, uint32_t n, float *out) {
+    const float factor = acceptance_map ? 1.f : (float) ((scal[1] * (double) inv_world) / (scal[0] * (double) inv_pixels));
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+        out[i] = film[i] * (importance ? factor * importance[i / 3u] : factor);
 }
 
 // dst += src (film tiles of ranks that share a device: drmlt_node.cpp's loopback transport)
@@ -1260,7 +1277,7 @@ __global__ void __launch_bounds__(256) k_accumulate(float *dst, const float *src
     for (size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t) gridDim.x * blockDim.x) dst[i] += src[i];
 }
 void launch_accumulate(float *dst, const float *src, size_t n, hipStream_t st) {
-    hipLaunchKernelGGL(k_accumulate, dim3((unsigned) std::min<size_t>((n + 255) / 256, 4096)), dim3(256), 0, st, dst, src, n);
+    hipLaunchKernelGGL(k_accumulate, dim3((unsigned) std::min<size_t>((n + 255) / 256, AUX_GRID_CAP)), dim3(256), 0, st, dst, src, n);
 }
 
 // ---- host-callable launchers (C++ linkage, used by drmlt_capi.cpp) --------------------------
@@ -1331,6 +1348,10 @@ void launch_render_pt(const DParams &P, uint64_t n_samples, uint32_t stream, flo
 void launch_lum_sum(const float *film, const float *importance, uint32_t n_pixels, double *sum, hipStream_t st) {
     hipLaunchKernelGGL(k_lum_sum, dim3(256), dim3(256), 0, st, film, importance, n_pixels, sum);
 }
+void launch_develop_dev(const float *film, const float *importance, const double *scal, float inv_world, float inv_pixels, int acceptance_map, uint32_t n,
+                        float *out, hipStream_t st) {
+    hipLaunchKernelGGL(k_develop_dev, dim3(std::min((n + 255) / 256, AUX_GRID_CAP)), dim3(256), 0, st, film, importance, scal, inv_world, inv_pixels, acceptance_map, n, out);
+}
 void launch_develop(const float *film, const float *direct, const float *importance, float factor, uint32_t n, float *out, hipStream_t st) {
-    hipLaunchKernelGGL(k_develop, dim3((n + 255) / 256), dim3(256), 0, st, film, direct, importance, factor, n, out);
+    hipLaunchKernelGGL(k_develop, dim3(std::min((n + 255) / 256, AUX_GRID_CAP)), dim3(256), 0, st, film, direct, importance, factor, n, out);
 }

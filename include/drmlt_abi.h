@@ -311,7 +311,10 @@ int drmlt_seed_pool(drmlt_ctx *ctx, uint64_t seed, uint32_t first_chain,
  * drmlt_comm_init on its context. drmlt_exchange_tiled runs the film exchange
  * on the context's stream: *b_inout = this rank's b in, the ranks' mean out;
  * the developed tile (rows [*row_lo, *row_hi), W * 3 floats each) is copied to
- * tile_host_or_null when given. The local film is left untouched. */
+ * tile_host_or_null when given. The local film is left untouched. With
+ * tile_host_or_null, row_lo and row_hi all NULL nothing waits for the host: the
+ * exchange (tile developed with device-resident sums) is only enqueued on the
+ * context's stream behind the chain kernels, and *b_inout is not updated. */
 #define DRMLT_COMM_ID_BYTES 128
 int drmlt_comm_unique_id(char id[DRMLT_COMM_ID_BYTES]);
 int drmlt_comm_init(drmlt_ctx *ctx, const char id[DRMLT_COMM_ID_BYTES], int rank, int world);
