@@ -18,8 +18,8 @@ def _cfg(pkg, n, **kw):
     return pkg.abi.make_config(**base)
 
 
-@pytest.mark.parametrize("kw", [dict(), dict(type="green"), dict(technique="mmlt", max_depth=6)],
-                         ids=["orbital", "green", "mmlt"])
+@pytest.mark.parametrize("kw", [dict(), dict(type="green"), dict(technique="mmlt", max_depth=6), dict(technique="bdpt", max_depth=6)],
+                         ids=["orbital", "green", "mmlt", "bdpt"])
 def test_two_contexts_equal_one_context_with_twice_the_chains(pkg, kw, native_lib):
     """Contexts A (chains [0, n)) and B (chains [n, 2n)) seeded from one pool run exactly the chains of one 2n-chain
     context: their films, summed on the device, develop to the same image (up to the order of the float atomics)."""
@@ -33,7 +33,7 @@ def test_two_contexts_equal_one_context_with_twice_the_chains(pkg, kw, native_li
     assert ba == bb == b_big
     a.run(total // 2); b.run(total // 2)
     # same chains: same current states, chain by chain
-    dim = 27 if kw.get("technique") == "mmlt" else 34
+    dim = big.stats().max_dim if kw.get("technique") == "bdpt" else (27 if kw.get("technique") == "mmlt" else 34)
     (cb_, ub), (ca, ua), (cbb, ubb) = big.chain_state(dim), a.chain_state(dim), b.chain_state(dim)
     assert np.array_equal(ub[:n], ua) and np.array_equal(ub[n:], ubb)
     assert np.array_equal(cb_["luminance"][:n], ca["luminance"]) and np.array_equal(cb_["luminance"][n:], cbb["luminance"])
