@@ -510,6 +510,7 @@ struct Trav {
     Hit h;
     int cur, sp;      // cur >= 0 inner node, < 0 leaf reference
     int ovf;          // entries of this lane's stack that sit in the overflow area (0 for trees the LDS column holds)
+    uint32_t rx, ry, rz; // 1 where the ray runs against the axis: the NEAR plane of a box is then its upper one (row lo/hi swapped at the load)
     bool active, any_hit;
     uint32_t n_nodes, n_prims; // fetched so far by this lane (k_mutate_v4 reports them: the scene part of the algorithmic bytes)
     uint32_t it_inner, it_leaf; // wave-uniform: traversal iterations of each kind (lane occupancy = n_nodes / (64 it_inner) ...)
@@ -522,6 +523,7 @@ DEV void trav_begin(Trav &T, f3 o, f3 d, float tmin, float tmax, bool any_hit) {
     T.tmin = tmin;
     T.h = Hit{-1, tmax, 0.f, 0.f};
     T.cur = 0; T.sp = 0; T.ovf = 0;
+    T.rx = T.inv.x < 0.f ? 1u : 0u; T.ry = T.inv.y < 0.f ? 1u : 0u; T.rz = T.inv.z < 0.f ? 1u : 0u;
     T.active = true; T.any_hit = any_hit;
 }
 DEV void trav_reset_counters(Trav &T) { T.n_nodes = T.n_prims = T.it_inner = T.it_leaf = 0u; }
@@ -567,30 +569,44 @@ template <class StackT, class PT, bool OVF = true, int CAP = BVH_STACK> DEV void
         if (__popcll(m_inner) * P.trace_vote >= __popcll(m_leaf) * 16) { // a leaf test costs about 0.4 node tests: see drmlt_capi.cpp
             T.it_inner++;
             if (run && T.cur >= 0) {
-                const DBvh4Node N = load_global16(P.bvh + T.cur);
+                // The node's rows (16 bytes each: lox, hix, loy, hiy, loz, hiz, child) are fetched with the lo / hi rows of an
+                // axis SWAPPED where the ray runs against it: the first of each pair then holds the four NEAR planes, the second
+                // the four FAR ones, and the slab test needs no per-axis min / max (24 of ~110 vector instructions per node).
+                typedef const u32x4_t __attribute__((address_space(1))) *GRow;
+                const GRow rows = (GRow) (uintptr_t) P.bvh + (size_t) T.cur * 8u;
+                const u32x4_t nxr = rows[T.rx], fxr = rows[T.rx ^ 1u], nyr = rows[2u + T.ry], fyr = rows[2u + (T.ry ^ 1u)];
+                const u32x4_t nzr = rows[4u + T.rz], fzr = rows[4u + (T.rz ^ 1u)], chr = rows[6];
                 T.n_nodes++;
                 if (has_ovf && T.sp > CAP - 3) spill();
+                typedef float f2 __attribute__((ext_vector_type(2)));
+                const f2 ix = {T.inv.x, T.inv.x}, iy = {T.inv.y, T.inv.y}, iz = {T.inv.z, T.inv.z};
+                const f2 ox = {T.oi.x, T.oi.x}, oy = {T.oi.y, T.oi.y}, oz = {T.oi.z, T.oi.z};
+                float tn[4];
+                bool hitc[4];
+                int childc[4] = {(int) chr.x, (int) chr.y, (int) chr.z, (int) chr.w};
+#pragma unroll
+                for (int h2 = 0; h2 < 2; ++h2) { // children (0, 1), then (2, 3): v_pk_fma_f32
+                    auto pr = [&](const u32x4_t &r) { return h2 == 0 ? (f2){__uint_as_float(r.x), __uint_as_float(r.y)} : (f2){__uint_as_float(r.z), __uint_as_float(r.w)}; };
+                    const f2 t0x = __builtin_elementwise_fma(pr(nxr), ix, ox), t1x = __builtin_elementwise_fma(pr(fxr), ix, ox);
+                    const f2 t0y = __builtin_elementwise_fma(pr(nyr), iy, oy), t1y = __builtin_elementwise_fma(pr(fyr), iy, oy);
+                    const f2 t0z = __builtin_elementwise_fma(pr(nzr), iz, oz), t1z = __builtin_elementwise_fma(pr(fzr), iz, oz);
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        const float a = fmaxf(fmaxf(t0x[q], t0y[q]), fmaxf(t0z[q], T.tmin));
+                        const float f = fminf(fminf(t1x[q], t1y[q]), fminf(t1z[q], T.h.t));
+                        tn[2 * h2 + q] = a;
+                        hitc[2 * h2 + q] = a <= f;
+                    }
+                }
                 if constexpr (sizeof(StackT) == 2) {
                     // 16-bit child references: the sort key carries the child itself -- entry distance in the upper half (its bit
                     // pattern orders like an unsigned: tn >= tmin >= 0; 7 mantissa bits are plenty for an ORDER), reference in
                     // the lower half. Everything below is selects: no exec-mask traffic, no branches but the pop.
-                    typedef float f2 __attribute__((ext_vector_type(2)));
-                    const f2 ix = {T.inv.x, T.inv.x}, iy = {T.inv.y, T.inv.y}, iz = {T.inv.z, T.inv.z};
-                    const f2 ox = {T.oi.x, T.oi.x}, oy = {T.oi.y, T.oi.y}, oz = {T.oi.z, T.oi.z};
                     unsigned key[4];
 #pragma unroll
-                    for (int h2 = 0; h2 < 2; ++h2) { // children (0, 1), then (2, 3): v_pk_fma_f32
-                        const int c = 2 * h2;
-                        const f2 t0x = __builtin_elementwise_fma((f2){N.lox[c], N.lox[c + 1]}, ix, ox), t1x = __builtin_elementwise_fma((f2){N.hix[c], N.hix[c + 1]}, ix, ox);
-                        const f2 t0y = __builtin_elementwise_fma((f2){N.loy[c], N.loy[c + 1]}, iy, oy), t1y = __builtin_elementwise_fma((f2){N.hiy[c], N.hiy[c + 1]}, iy, oy);
-                        const f2 t0z = __builtin_elementwise_fma((f2){N.loz[c], N.loz[c + 1]}, iz, oz), t1z = __builtin_elementwise_fma((f2){N.hiz[c], N.hiz[c + 1]}, iz, oz);
-#pragma unroll
-                        for (int q = 0; q < 2; ++q) {
-                            const float tn = fmaxf(fmaxf(fmaxf(fminf(t0x[q], t1x[q]), fminf(t0y[q], t1y[q])), fminf(t0z[q], t1z[q])), T.tmin);
-                            const float tf = fminf(fminf(fminf(fmaxf(t0x[q], t1x[q]), fmaxf(t0y[q], t1y[q])), fmaxf(t0z[q], t1z[q])), T.h.t);
-                            const unsigned kk = (__float_as_uint(tn) & 0xffff0000u) | ((unsigned) N.child[c + q] & 0xffffu);
-                            key[c + q] = tn <= tf ? kk : 0xffffffffu;
-                        }
+                    for (int c = 0; c < 4; ++c) {
+                        const unsigned kk = (__float_as_uint(tn[c]) & 0xffff0000u) | ((unsigned) childc[c] & 0xffffu);
+                        key[c] = hitc[c] ? kk : 0xffffffffu;
                     }
                     // sorting network (0,1)(2,3)(0,2)(1,3)(1,2)
                     const unsigned a0 = umin2(key[0], key[1]), a1 = umax2(key[0], key[1]), a2 = umin2(key[2], key[3]), a3 = umax2(key[2], key[3]);
@@ -610,18 +626,11 @@ template <class StackT, class PT, bool OVF = true, int CAP = BVH_STACK> DEV void
                     // 32-bit child references: the key carries the SLOT in its two low mantissa bits; selects pick the child
                     unsigned key[4];
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        const float t0x = fmaf(N.lox[c], T.inv.x, T.oi.x), t1x = fmaf(N.hix[c], T.inv.x, T.oi.x);
-                        const float t0y = fmaf(N.loy[c], T.inv.y, T.oi.y), t1y = fmaf(N.hiy[c], T.inv.y, T.oi.y);
-                        const float t0z = fmaf(N.loz[c], T.inv.z, T.oi.z), t1z = fmaf(N.hiz[c], T.inv.z, T.oi.z);
-                        const float tn = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fmaxf(fminf(t0z, t1z), T.tmin));
-                        const float tf = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fminf(fmaxf(t0z, t1z), T.h.t));
-                        key[c] = tn <= tf ? ((__float_as_uint(tn) & 0x7ffffffcu) | (unsigned) c) : 0xffffffffu;
-                    }
+                    for (int c = 0; c < 4; ++c) key[c] = hitc[c] ? ((__float_as_uint(tn[c]) & 0x7ffffffcu) | (unsigned) c) : 0xffffffffu;
                     const unsigned a0 = umin2(key[0], key[1]), a1 = umax2(key[0], key[1]), a2 = umin2(key[2], key[3]), a3 = umax2(key[2], key[3]);
                     const unsigned b0 = umin2(a0, a2), b2 = umax2(a0, a2), b1 = umin2(a1, a3), b3 = umax2(a1, a3);
                     const unsigned k0 = b0, k1 = umin2(b1, b2), k2 = umax2(b1, b2), k3 = b3;
-                    const int c0 = N.child[0], c1 = N.child[1], c2 = N.child[2], c3 = N.child[3];
+                    const int c0 = childc[0], c1 = childc[1], c2 = childc[2], c3 = childc[3];
                     auto child_of = [&](unsigned k) {
                         const int lo = (k & 1u) ? c1 : c0, hi = (k & 1u) ? c3 : c2;
                         return (k & 2u) ? hi : lo;

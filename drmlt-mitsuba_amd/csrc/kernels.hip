@@ -897,7 +897,7 @@ __global__ void __launch_bounds__(CHAIN_BLOCK) k_mutate_v4(DParams P, uint32_t n
     int batch;
     constexpr bool RESUMABLE = (FEAT & 8) != 0; // BVH scenes: traversals survive loop iterations (device_path.h: Trav)
     Trav T;
-    T.active = false; T.cur = 0; T.sp = 0; T.ovf = 0; T.any_hit = false; T.h = h; T.tmin = 0.f;
+    T.active = false; T.cur = 0; T.sp = 0; T.ovf = 0; T.rx = T.ry = T.rz = 0u; T.any_hit = false; T.h = h; T.tmin = 0.f;
     T.o = T.d = T.inv = T.oi = mk3(0.f, 0.f, 0.f);
     trav_reset_counters(T);
     int rstate = 0; // ray of this lane: 0 none, 1 issued, 2 being traversed, 3 result waiting to be consumed
