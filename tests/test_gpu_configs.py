@@ -58,6 +58,30 @@ def test_config4_one_gpu_share_2048(pkg, native_lib):
     assert ctx.film().shape == (2048, 2048, 3)
 
 
+def test_config4_tiled_exchange_at_2048_with_eight_ranks_on_one_gpu(pkg, native_lib, monkeypatch):
+    """Config 4's film (2048 x 2048) through the node API with EIGHT ranks -- all on this GPU (loopback transport for the
+    reduce-scatter arithmetic): one seed pool split eight ways, threaded run, 256-row tiles developed per rank and
+    stitched. The result equals one context running the same 8 x 8192 chains."""
+    sd = pkg.scenes.cornell_c2(2048)
+    n, ranks = 8192, 8
+    mk = lambda w: pkg.abi.make_config(technique="path", type="orbital", max_depth=8, rr_depth=5, direct_samples=-1, work_units=w,
+                                       luminance_samples=100000, sample_count=1)
+    monkeypatch.setenv("DRMLT_NODE_DEVICES", ",".join(["0"] * ranks))
+    node = pkg.Node(mk(n), sd, device_mask=1)
+    monkeypatch.delenv("DRMLT_NODE_DEVICES")
+    assert node.device_count == ranks
+    big = pkg.Context(mk(ranks * n), sd)
+    assert node.seed(0x5EED) == big.seed_pool(0x5EED, 0, ranks * n)
+    total = ranks * n * 64
+    node.run(total); big.run(total)
+    img_n, img_b = node.develop(), big.develop()
+    assert img_n.shape == (2048, 2048, 3)
+    np.testing.assert_allclose(img_n, img_b, rtol=5e-4, atol=1e-6)
+    sn, sb = node.stats(), big.stats()
+    assert sn.mutations == sb.mutations == total and sn.accepted == sb.accepted and sn.rays == sb.rays and sn.n_chains == ranks * n
+    node.close(); big.close()
+
+
 def test_config5_caustic_mmlt_full_size(pkg, native_lib):
     """Glass caustic, mmlt / orbital / fixEmitterPath / acceptanceMap at 512 x 512 with 65 536 chains."""
     sd = pkg.scenes.caustic_c5(512)
