@@ -7,8 +7,8 @@ Default workload = BASELINE.json configs[1]: Cornell box 512x512, `integrator=dr
 before the timed region. Metric = mutations/s (accepted + rejected; one mutation = one first-stage proposal,
 reference drmlt_proc.cpp:541).
 
-  python bench.py --gpus 1 --steps 5 --warmup 1
-  python bench.py --config 3|5|bdpt|soup          # the other kernels, same JSON line (roofline of THAT kernel)
+  python bench.py --gpus 1 --steps 10 --warmup 2      # the defaults
+  python bench.py --config 3|5|bdpt|soup|soup50k  # the other kernels, same JSON line (roofline of THAT kernel)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
       bench.py --gpus N --steps K --warmup W
 
@@ -152,8 +152,8 @@ def cpu_baseline(pkg, conf, res, cfg_kw, target_seconds):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--config", default="2", choices=sorted(CONFIGS))
     ap.add_argument("--res", type=int, default=0, help="film size (default: the configuration's)")
     ap.add_argument("--chains", type=int, default=None, help="chains per GPU (default: the configuration's own, 65536 unless noted)")
