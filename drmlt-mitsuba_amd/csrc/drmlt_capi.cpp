@@ -422,15 +422,15 @@ drmlt_ctx *drmlt_create(const drmlt_config *cfg, const drmlt_scene *scene, int d
     if (work_units <= 0) {
         // "derived" (workUnits = -1, the default). The reference sizes work units for its CPU scheduler -- 200 000 (path) or
         // 100 000 (mmlt, bdpt) mutations each, drmlt.cpp:434-444: a few hundred chains for a whole image. A device wants the
-        // count that fills it: 65 536 chains for the path kernels (32 per wave, two waves per SIMD), 131 072 for the
-        // one-chain-per-lane bidirectional kernels, but never chains shorter than 64 mutations. An explicit workUnits is
+        // count that fills it: 65 536 chains for the path kernels (32 per wave, two waves per SIMD), 131 072 for bdpt's
+        // one-chain-per-lane kernel, 262 144 for mmlt's (two rounds, so that shallow waves make room for the next), but never chains shorter than 64 mutations. An explicit workUnits is
         // taken as given; DRMLT_AUTO_WORK_UNITS=reference restores the reference's formula.
         const char *mode = getenv("DRMLT_AUTO_WORK_UNITS");
         if (mode && !strcmp(mode, "reference")) {
             const uint64_t per_unit = (mmlt || bdpt) ? 100000 : 200000;
             work_units = (int) std::max<uint64_t>(1, (budget + per_unit - 1) / per_unit);
         } else {
-            const uint64_t fill = (mmlt || bdpt) ? 131072 : 65536;
+            const uint64_t fill = mmlt ? 262144 : (bdpt ? 131072 : 65536); // mmlt: two rounds of waves, run in depth order
             work_units = (int) std::min<uint64_t>(fill, std::max<uint64_t>(64, budget / 64 / 64 * 64));
         }
     }
@@ -521,6 +521,7 @@ drmlt_ctx *drmlt_create(const drmlt_config *cfg, const drmlt_scene *scene, int d
     P.mh_batch = P.kernel_variant == 4 ? (P.use_bvh ? 4 : (P.features == 0 ? 12 : 8)) : 32; // v4: chains run free, the bookkeeping branch fires as soon as a few are parked
     if (const char *k = getenv("DRMLT_MH_BATCH")) P.mh_batch = std::max(1, std::min(64, atoi(k)));
     P.bvh_overflow = nullptr; P.bvh_ovf_lanes = 0;
+    P.exec_order = nullptr;
     P.trace_yield = 20; // measured on the 2000-triangle soup: 12 2.69e8, 16 2.78e8, 20 2.82e8, 24 2.82e8 mutations/s
     if (const char *k = getenv("DRMLT_TRACE_YIELD")) P.trace_yield = std::max(0, std::min(64, atoi(k)));
     P.trace_vote = 10; // measured on the 2000-triangle soup: 16 (plain majority) 2.70e8, 10 2.78e8, 5 2.73e8 mutations/s
@@ -630,6 +631,18 @@ static int seed_impl(drmlt_ctx *ctx, uint64_t seed, uint32_t chain_offset, uint3
     HIP_TRY(ctx, hipMemcpyAsync(d_sl.p, seed_lum.data(), seed_lum.size() * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(ctx, hipMemsetAsync(ctx->d_err.p, 0, 64, ctx->stream));
     HIP_TRY(ctx, ensure_overflow(ctx, P, 2 * (size_t) P.n_chains_alloc));
+    if (mmlt && !getenv("DRMLT_MMLT_NO_SORT")) {
+        // execution order of k_mutate_mmlt: chains sorted by their (fixed) path depth, deepest first, whole waves (kernels_mmlt.hip)
+        const uint32_t n = ctx->n_chains, padded = (n + 63u) / 64u * 64u;
+        std::vector<uint32_t> order(padded, n);
+        for (uint32_t j = 0; j < n; ++j) order[j] = j;
+        const uint32_t md = (uint32_t) ctx->cfg.max_depth;
+        std::stable_sort(order.begin(), order.begin() + n, [&](uint32_t a, uint32_t b) { return seed_index[a] % md > seed_index[b] % md; });
+        HIP_TRY(ctx, ctx->d_order.alloc(order.size() * sizeof(uint32_t)));
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->d_order.p, order.data(), order.size() * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); // `order` is a local
+        ctx->P.exec_order = P.exec_order = ctx->d_order.as<uint32_t>();
+    }
     if (mmlt) launch_init_chains_mmlt(P, d_si.as<uint32_t>(), d_sl.as<float>(), ctx->stream);
     else if (bdpt) launch_init_chains_bdpt(P, d_si.as<uint32_t>(), d_sl.as<float>(), ctx->stream);
     else launch_init_chains(P, d_si.as<uint32_t>(), d_sl.as<float>(), ctx->stream);

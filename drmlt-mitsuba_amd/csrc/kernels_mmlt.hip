@@ -70,7 +70,12 @@ __global__ void __launch_bounds__(CHAIN_BLOCK) k_init_chains_mmlt(DParams P, con
 // at 256 registers whatever else the translation unit grows, and flat scenes run the build without any BVH code (FEAT 7).
 template <int FEAT> __global__ void __launch_bounds__(CHAIN_BLOCK, 2) k_mutate_mmlt(DParams P, uint32_t n_mut, uint32_t mut_base) {
     const uint32_t lane = threadIdx.x;
-    const uint32_t c = blockIdx.x * CHAIN_BLOCK + lane;
+    // Execution order: a wave's work is its DEEPEST chain's (every lane walks in lock step), so waves are made of chains of
+    // one depth, deepest first. With more waves than the device holds (262 144 chains = two rounds) the slots that shallow
+    // waves free early are taken by the next ones -- depths 6 5 4 | 3 2 1 pair up to equal sums -- and the kernel costs the
+    // MEAN wave instead of the deepest. Chain ids (state, RNG streams) are untouched: the same chains, bit for bit.
+    const uint32_t slot = blockIdx.x * CHAIN_BLOCK + lane;
+    const uint32_t c = P.exec_order ? P.exec_order[slot] : slot;
     const bool live = c < P.n_chains;
     const uint32_t cc = live ? c : P.n_chains - 1;
     const uint32_t NX = mmlt_nx(P);

@@ -93,7 +93,7 @@ typedef struct drmlt_config {
     int32_t  direct_samples;     /* "directSamples"    default 16; <0: MLT does it */
     int32_t  luminance_samples;  /* "luminanceSamples" default 100000              */
     int32_t  work_units;         /* "workUnits"        default -1: derived -- a device-filling chain count (65 536; 131 072 for
-                                  * mmlt / bdpt), at least 64 mutations per chain; the reference derives ~budget / 200 000 */
+                                  * bdpt, 262 144 for mmlt), at least 64 mutations per chain; the reference derives ~budget / 200 000 */
     int32_t  sample_count;       /* sensor sampler's sampleCount = mutations/pixel */
     float    p_large;            /* "pLarge"           default 0.3                 */
     float    sigma;              /* "sigma"            default 1/64                */
