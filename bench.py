@@ -222,20 +222,28 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def step():
-        ctx.run(step_mutations)
-        if use_dist and not os.environ.get("BENCH_SKIP_EXCHANGE"):  # the render's film exchange: reduce-scatter + scalar all-reduce + tile develop, all in C++
-            ctx.exchange_tiled(b, want_tile=False, wait=False)   # enqueued behind the chain kernel; the closing barrier waits for it
+    def steps(k):
+        """k steps of the render = ONE call into the library, which cuts it into launches of 1024 mutations per chain (one per
+        step at 65 536 chains) -- as a renderer calls it (the adaptor hands drmlt_run its whole budget). Between those launches
+        chains that have reached a launch's target run ahead towards the call's total instead of idling until the slowest chain
+        is there; the call returns with every chain at exactly its count. Followed, for N > 1, by the render's film exchange:
+        reduce-scatter + scalar all-reduce + tile develop, all in C++, enqueued behind the chain kernels."""
+        if os.environ.get("BENCH_CALL_PER_STEP"):
+            for _ in range(k):
+                ctx.run(step_mutations)
+        else:
+            ctx.run(k * step_mutations)
+        if use_dist and not os.environ.get("BENCH_SKIP_EXCHANGE"):
+            ctx.exchange_tiled(b, want_tile=False, wait=False)
 
-    for _ in range(args.warmup):
-        step()
+    if args.warmup:
+        steps(args.warmup)
         ctx.film_clear()
     ctx.kernel_time(reset=True)
     st0 = ctx.stats()
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    steps(args.steps)
     barrier()
     elapsed = time.perf_counter() - t0
     if use_dist:

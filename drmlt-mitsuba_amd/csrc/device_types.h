@@ -121,6 +121,11 @@ struct DParams {
     int32_t mmlt_dmax;        // findMaxDimensions of the deepest chain: draw bases 2 dmax (emitter), 4 dmax (direct)
     int32_t bd_Dd;            // technique=bdpt, directSampling=true: state rows of the direct sampler, 2 (2 maxDepth - 1); else 0
     int32_t *chain_depth;     // [n] path depth of each chain (fixed by its seed)
+    // k_mutate_v4, run-ahead (drmlt_run with more than one launch): per-chain count of decided mutations, the launch's counter
+    // of waves that still have a chain under the launch's target, and the count no chain may exceed (the render's total)
+    uint32_t *chain_done;     // [n] or NULL (then every chain runs exactly n_mut mutations from mutation index mut_base)
+    uint32_t *waves_left;
+    uint32_t run_limit;
     const uint32_t *exec_order; // technique=mmlt: chain run by lane `slot` of the grid, deepest chains first (rounded up to whole waves, padded with n), or NULL
     int32_t *cur_t;           // [n] sensor-subpath length t of the current state (light tracing: t == 1)
     const float *importance;  // [H][W] two-stage MLT luminance image, or NULL (pathsampler.cpp:1001-1020)

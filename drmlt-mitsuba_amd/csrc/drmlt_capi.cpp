@@ -489,6 +489,10 @@ drmlt_ctx *drmlt_create(const drmlt_config *cfg, const drmlt_scene *scene, int d
     if (!ok) return bail(ctx, "device allocation of chain state / film failed");
     if (hipMemset(ctx->d_chain_i.p, 0, (size_t) 2 * ctx->n_chains * sizeof(int32_t)) != hipSuccess) return bail(ctx, "hipMemset of the chain state failed");
     P.chain_depth = ctx->d_chain_i.as<int32_t>(); P.cur_t = P.chain_depth + ctx->n_chains;
+    // run-ahead of k_mutate_v4 (drmlt_run): per-chain mutation counts + the launch's counter of waves short of the target
+    if (ctx->d_done.alloc(((size_t) ctx->n_chains + 1) * sizeof(uint32_t)) != hipSuccess ||
+        hipMemset(ctx->d_done.p, 0, ((size_t) ctx->n_chains + 1) * sizeof(uint32_t)) != hipSuccess) return bail(ctx, "device allocation failed");
+    P.chain_done = nullptr; P.waves_left = ctx->d_done.as<uint32_t>() + ctx->n_chains; P.run_limit = 0;
     P.importance = nullptr;
     P.bd_verts = nullptr; P.bd_lists = nullptr; P.n_chains_alloc = ctx->n_chains;
     if (bdpt) {
@@ -659,6 +663,7 @@ static int seed_impl(drmlt_ctx *ctx, uint64_t seed, uint32_t chain_offset, uint3
     else if (ctx->cfg.average_luminance != -1.0f) ctx->b = ctx->cfg.average_luminance; // drmlt.cpp:555-558
     ctx->seeded = true;
     ctx->mutation_base = 0;
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_done.p, 0, ctx->d_done.bytes, ctx->stream));
     if (b_out) *b_out = ctx->b;
     return DRMLT_OK;
 }
@@ -774,6 +779,13 @@ int drmlt_run(drmlt_ctx *ctx, uint64_t total_mutations, volatile int *stop, drml
     // so they all stop at the first launch boundary after the deadline (the reference stops handing out work units).
     const bool timed = ctx->cfg.timeout_s > 0;
     const auto t_start = std::chrono::steady_clock::now();
+    // Run-ahead (k_mutate_v4, more than one launch to go): a launch ends when every chain has reached its target, and until then
+    // chains that are there keep going -- towards the total of THIS call, at most 4096 mutations beyond the target (16-bit event
+    // counters per chain and launch). The last launch has target = limit = total: every chain ends at exactly its count.
+    // (A single launch has target = limit and is the plain fixed-count launch; the per-chain counts are kept either way.)
+    const bool ahead = ctx->cfg.technique == DRMLT_TECH_PATH && ctx->cfg.algo != DRMLT_ALGO_PSSMLT && ctx->P.kernel_variant == 4 &&
+                       !getenv("DRMLT_NO_RUN_AHEAD");
+    const uint64_t call_base = ctx->mutation_base, call_end = call_base + per_chain;
     while (done < per_chain) {
         if (stop && *stop) { rc = DRMLT_E_CANCELLED; break; }
         if (timed && std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count() >= (double) ctx->cfg.timeout_s) break;
@@ -789,7 +801,14 @@ int drmlt_run(drmlt_ctx *ctx, uint64_t total_mutations, volatile int *stop, drml
         if (ctx->cfg.algo == DRMLT_ALGO_PSSMLT) launch_mutate_pssmlt(ctx->P, n, ctx->mutation_base, ctx->stream);
         else if (ctx->cfg.technique == DRMLT_TECH_MMLT) launch_mutate_mmlt(ctx->P, n, ctx->mutation_base, ctx->stream);
         else if (ctx->cfg.technique == DRMLT_TECH_BDPT) launch_mutate_bdpt(ctx->P, n, ctx->mutation_base, ctx->stream);
-        else launch_mutate(ctx->P, n, ctx->mutation_base, ctx->stream);
+        else if (ahead) {
+            DParams Q = ctx->P;
+            const uint64_t target = call_base + done + n;
+            Q.chain_done = ctx->d_done.as<uint32_t>();
+            Q.run_limit = (uint32_t) std::min<uint64_t>(call_end, target + std::min<uint64_t>(4 * slice, 8192)); // at most four launches ahead (the per-chain event counters of a launch are 16 bits wide)
+            launch_set_u32(Q.waves_left, (ctx->n_chains + 31u) / 32u, ctx->stream);
+            launch_mutate(Q, (uint32_t) target, 0u, ctx->stream);
+        } else launch_mutate(ctx->P, n, ctx->mutation_base, ctx->stream);
         HIP_TRY(ctx, hipGetLastError());
         HIP_TRY(ctx, hipEventRecord(ev.b, ctx->stream));
         ctx->mutation_base += n;
@@ -806,6 +825,25 @@ int drmlt_run(drmlt_ctx *ctx, uint64_t total_mutations, volatile int *stop, drml
         ctx->kernel_ms += ms;
         ctx->kt_ms += ms;
         ctx->kt_launches++;
+    }
+    if (ahead && done < per_chain && done > 0) {
+        // stopped early (cancel / timeout): chains are at the last target or up to four launches beyond it. One catch-up launch
+        // brings everybody to the most advanced chain's count, so that a stopped render, too, has run every chain equally long.
+        std::vector<uint32_t> h(ctx->n_chains);
+        HIP_TRY(ctx, hipMemcpy(h.data(), ctx->d_done.p, h.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        const uint32_t top = *std::max_element(h.begin(), h.end());
+        if (top > ctx->mutation_base) {
+            DParams Q = ctx->P;
+            Q.chain_done = ctx->d_done.as<uint32_t>();
+            Q.run_limit = top;
+            launch_set_u32(Q.waves_left, (ctx->n_chains + 31u) / 32u, ctx->stream);
+            launch_mutate(Q, top, 0u, ctx->stream);
+            HIP_TRY(ctx, hipGetLastError());
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            done += top - ctx->mutation_base;
+            ctx->mutation_base = top;
+            ctx->launches++;
+        }
     }
     ctx->mutations += done * ctx->n_chains;
     if (rc == DRMLT_E_CANCELLED) return ctx->fail(rc, "cancelled");

@@ -61,7 +61,7 @@ struct drmlt_ctx {
     int bvh_depth = 0;
     int ovf_entries = 0;   // capacity per lane of the traversal stacks' overflow area (0: every stack fits its LDS column)
     size_t ovf_lanes = 0;  // columns allocated in d_ovf
-    DevBuf d_prims, d_shade, d_bsdfs, d_emitters, d_bvh, d_lut, d_film, d_x, d_cur, d_stats, d_err, d_scratch, d_chain_i, d_importance, d_bd_verts, d_bd_lists, d_prims_flat, d_ovf, d_order;
+    DevBuf d_prims, d_shade, d_bsdfs, d_emitters, d_bvh, d_lut, d_film, d_x, d_cur, d_stats, d_err, d_scratch, d_chain_i, d_importance, d_bd_verts, d_bd_lists, d_prims_flat, d_ovf, d_order, d_done;
     std::vector<DPrim> prims;
     std::vector<DShade> shade;
     std::vector<uint32_t> seed_indices; // bootstrap sample index of every chain's seed (last drmlt_seed)
@@ -104,3 +104,4 @@ void launch_develop(const float *film, const float *direct, const float *importa
 void launch_develop_dev(const float *film, const float *importance, const double *scal, float inv_world, float inv_pixels, int acceptance_map, uint32_t n,
                         float *out, hipStream_t st);
 void launch_set2(double *p, double a, double b, hipStream_t st);
+void launch_set_u32(uint32_t *p, uint32_t v, hipStream_t st);

@@ -895,6 +895,8 @@ __global__ void __launch_bounds__(CHAIN_BLOCK) k_mutate_v4(DParams P, uint32_t n
     bool helper_has_ray = false;
     Hit h{-1, 0.f, 0.f, 0.f};
     int batch;
+    uint32_t base = 0u, target = 0u, limit = 0u; // mutation index of this chain's first mutation of the launch; see run-ahead below
+    bool reported = false;                       // this wave has told the grid that all its chains are at the target
     constexpr bool RESUMABLE = (FEAT & 8) != 0; // BVH scenes: traversals survive loop iterations (device_path.h: Trav)
     Trav T;
     T.active = false; T.cur = 0; T.sp = 0; T.ovf = 0; T.rx = T.ry = T.rz = 0u; T.any_hit = false; T.h = h; T.tmin = 0.f;
@@ -911,13 +913,21 @@ __global__ void __launch_bounds__(CHAIN_BLOCK) k_mutate_v4(DParams P, uint32_t n
         cs.a1 = 0.f; cs.coin_acc1 = cs.coin_acc2 = cs.coin_mix = 0.f;
         cs.it = 0u; cs.nd1 = cs.nd2 = 0u; cs.stage = -1; cs.large = false; cs.do_second = false;
         path_init(P, ps);
-        ps.phase = (live && n_mut > 0u) ? PH_DONE : PH_IDLE; // helpers stay PH_IDLE for good
+        // Run-ahead (P.chain_done): `n_mut` is then the TARGET every chain must have reached when the launch ends, counted from
+        // the chain's seeding; a chain that is there keeps mutating -- up to P.run_limit, the render's total -- for as long as
+        // some chain of the grid is still short of the target. Every mutation executed is one of the chain's fixed total (its
+        // index, hence its random numbers, is the chain's own count), so lanes that would have idled until the slowest chain of
+        // the slowest wave is done do useful work instead; the render ends with every chain at exactly its total.
+        base = (P.chain_done && live) ? P.chain_done[cc] : mut_base;
+        target = P.chain_done ? n_mut : mut_base + n_mut;
+        limit = P.chain_done ? P.run_limit : target;
+        ps.phase = (live && base < limit) ? PH_DONE : PH_IDLE; // helpers stay PH_IDLE for good
         ps.o = mk3(0.f, 0.f, 0.f); ps.d = mk3(0.f, 0.f, 1.f); ps.tmin = 0.f; ps.tmax = 0.f;
         batch = P.mh_batch > 32 ? 32 : P.mh_batch;
         if (LDS_TABLES) stage_tables(P, Y.LT, lane);
         // coins of every chain's first mutation of this launch (afterwards they are drawn one mutation ahead, beside the proposal)
         if (!helper) {
-            const u4 coins = philox4x32_10(P.key0, P.key1, 0u, mut_base, P.chain_offset + blockIdx.x * 32u + sub, TAG_COIN);
+            const u4 coins = philox4x32_10(P.key0, P.key1, 0u, base, P.chain_offset + blockIdx.x * 32u + sub, TAG_COIN);
             float *dst = &lds_x[Y.L.coin_off + sub];
             dst[0] = u32_to_unit(coins.x); dst[S] = u32_to_unit(coins.y); dst[2u * S] = u32_to_unit(coins.z); dst[3u * S] = u32_to_unit(coins.w);
         }
@@ -975,7 +985,18 @@ __global__ void __launch_bounds__(CHAIN_BLOCK) k_mutate_v4(DParams P, uint32_t n
                     }
                     commit = o.commit;
                 }
-                kind = cs.stage < 0 ? (cs.it < n_mut ? 1 : 0) : (cs.stage == 1 ? 2 : 3);
+                kind = cs.stage < 0 ? 4 : (cs.stage == 1 ? 2 : 3); // 4: between mutations -- resolved below
+            }
+            {
+                // between mutations: go on while short of the target; beyond it (run-ahead) while anybody in the grid is short
+                const uint32_t done_now = base + cs.it;
+                const bool under = __ballot(!helper && live && done_now < target) != 0ull;
+                bool more = under;
+                if (Pm.chain_done) {
+                    if (!under && !reported) { reported = true; if (lane == 0) atomicSub(Pm.waves_left, 1u); }
+                    if (!under) more = __builtin_amdgcn_readfirstlane((int) __hip_atomic_load(Pm.waves_left, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != 0;
+                }
+                if (kind == 4) kind = (done_now < target || (done_now < limit && more)) ? 1 : 0;
             }
             v4_enqueue(L, qn, want0, e0x, e0y, e0r, e0g, e0b);
             v4_enqueue(L, qn, want1, e1x, e1y, e1r, e1g, e1b);
@@ -1024,7 +1045,7 @@ __global__ void __launch_bounds__(CHAIN_BLOCK) k_mutate_v4(DParams P, uint32_t n
             const V4Layout Yg = v4_layout(Pg, QCAP);
             RowSampler smg = Yg.smp;
             const uint32_t chain_base_g = Pg.chain_offset + blockIdx.x * 32u;
-            const uint32_t maj_mine = mut_base + cs.it; // the mutation in flight (cs.it counts decided mutations)
+            const uint32_t maj_mine = base + cs.it; // the mutation in flight (cs.it counts the mutations decided in this launch)
             const unsigned info = cs.large ? 1u : 0u;
             const uint32_t f1mask = (uint32_t) __ballot(kind == 1);
             if (f1mask) {
@@ -1189,15 +1210,18 @@ __global__ void __launch_bounds__(CHAIN_BLOCK) k_mutate_v4(DParams P, uint32_t n
         for (uint32_t k = 0; k < Y.D; ++k) P.x[(size_t) k * P.n_chains + c] = lds_x[k * S + sub];
         P.cur_lum[c] = cs.cur.lum; P.cur_px[c] = cs.cur.px; P.cur_py[c] = cs.cur.py;
         P.cur_r[c] = cs.cur.r; P.cur_g[c] = cs.cur.g; P.cur_b[c] = cs.cur.b;
+        if (P.chain_done) P.chain_done[c] = base + cs.it;
     }
-    unsigned long long v[9];
+    if (P.chain_done && !reported && lane == 0) atomicSub(P.waves_left, 1u); // (a wave none of whose chains had anything to do)
+    unsigned long long v[10];
     v[0] = wave_sum(ct.large_acc1l & 0xffffu); v[1] = wave_sum(ct.large_acc1l >> 16);
     v[2] = wave_sum(ct.acc1b_secl & 0xffffu);  v[3] = wave_sum(ct.acc1b_secl >> 16);
     v[4] = wave_sum(ct.secb_acc2l & 0xffffu);  v[5] = wave_sum(ct.secb_acc2l >> 16);
     v[6] = wave_sum(ct.acc2b_rev & 0xffffu);   v[7] = wave_sum(ct.acc2b_rev >> 16);
     v[8] = wave_sum(ct.rays);
+    v[9] = wave_sum((live && !helper) ? cs.it : 0u); // mutations decided in this launch (with run-ahead: not n_mut per chain)
     if (lane == 0)
-        for (int i = 0; i < 9; ++i) atomicAdd(P.stats + i, v[i]);
+        for (int i = 0; i < 10; ++i) atomicAdd(P.stats + i, v[i]);
     if (RESUMABLE) {
         const unsigned long long nn = wave_sum(T.n_nodes), np = wave_sum(T.n_prims);
         if (lane == 0) { atomicAdd(P.stats + 10, nn); atomicAdd(P.stats + 11, np); atomicAdd(P.stats + 12, (unsigned long long) T.it_inner); atomicAdd(P.stats + 13, (unsigned long long) T.it_leaf); }
@@ -1255,6 +1279,8 @@ __global__ void __launch_bounds__(256) k_develop(const float *film, const float 
         out[i] = film[i] * (importance ? factor * importance[i / 3u] : factor) + (direct ? direct[i] : 0.f); // :841-847
 }
 
+__global__ void k_set_u32(uint32_t *p, uint32_t v) { *p = v; }
+void launch_set_u32(uint32_t *p, uint32_t v, hipStream_t st) { hipLaunchKernelGGL(k_set_u32, dim3(1), dim3(1), 0, st, p, v); }
 __global__ void k_set2(double *p, double a, double b) { p[0] = a; p[1] = b; }
 void launch_set2(double *p, double a, double b, hipStream_t st) { hipLaunchKernelGGL(k_set2, dim3(1), dim3(1), 0, st, p, a, b); }
 

@@ -405,3 +405,37 @@ def test_large_scene_short_stack_column_spills_and_refills(pkg, ob, native_lib, 
     same = a["n_dims"] == b["n_dims"]
     assert same.mean() > 0.995
     assert np.allclose(a["luminance"][same], b["luminance"][same], rtol=1e-4, atol=1e-6)
+
+
+@pytest.mark.parametrize("scene,kw", [("cornell_c2", dict(type="orbital")), ("door_c3", dict(type="green")), ("glass_sphere", dict(type="mira"))],
+                         ids=["c2-orbital", "door-green", "glass-mira"])
+def test_run_ahead_between_launches_changes_no_chain(pkg, ob, scene, kw, native_lib):
+    """drmlt_run cuts a call into launches of DRMLT_SLICE mutations per chain; between them chains that have reached a launch's
+    target run ahead (per-chain mutation counters) instead of idling until the slowest chain of the grid is there. Every
+    chain still runs exactly its count, with the random numbers of its own mutation indices: states, statistics and film
+    equal those of fixed-count launches (and of k_mutate_v3)."""
+    sd = pkg.scenes.SCENES[scene](res=32)
+    n_chains, per_chain = 2048, 700                     # slice 128: 6 launches, the last one short
+    cfg = pkg.abi.make_config(max_depth=8, direct_samples=-1, luminance_samples=20000, work_units=n_chains, sample_count=1, **kw)
+    res = []
+    for env in (dict(DRMLT_SLICE=128), dict(DRMLT_SLICE=128, DRMLT_NO_RUN_AHEAD=1), dict(DRMLT_SLICE=128, DRMLT_KERNEL=3)):
+        ctx = _ctx_with_env(pkg, cfg, sd, **env)
+        ctx.seed(0x1234)
+        for k in env:
+            os.environ[k] = str(env[k])                 # the slice and the switch are read by drmlt_run as well
+        try:
+            ctx.run(n_chains * per_chain)
+            ctx.run(n_chains * 40)                      # a second, single-launch call continues from the counters
+        finally:
+            for k in env:
+                del os.environ[k]
+        res.append((ctx.chain_state(34), ctx.stats(), ctx.film()))
+    (c0, u0), s0, f0 = res[0]
+    assert np.array_equal(res[1][0][0]["luminance"], c0["luminance"])          # with / without run-ahead: the same kernel, bit for bit
+    for (c, u), s, f in res[1:]:
+        assert np.array_equal(u, u0) and np.allclose(c["luminance"], c0["luminance"], rtol=1e-6)   # (v3 rounds the path's last bit differently)
+        assert s.mutations == s0.mutations == n_chains * (per_chain + 40)
+        assert s.accepted == s0.accepted and s.rays == s0.rays and s.first_acc == s0.first_acc and s.second_base == s0.second_base
+        assert lum(f).sum() == pytest.approx(lum(f0).sum(), rel=1e-5)
+        assert np.abs(lum(f) - lum(f0)).sum() / lum(f0).sum() < 1e-3
+    assert res[0][1].launches == 7
