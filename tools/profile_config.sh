@@ -1,7 +1,7 @@
 #!/bin/bash
 # usage (on the GPU box): tools/profile_config.sh <round tag, e.g. r02> <config> [<config> ...]
-# Per config of bench.py: a rocprofv3 --kernel-trace --stats run of the bench's own step (its JSON line is kept beside the
-# stats: HIP-event and profiler durations of the same launches), then one --pmc pass per counter group (tools/pmc_run.sh, 64
+# Per config of bench.py: a rocprofv3 --kernel-trace --stats run of five bench steps without warm-up (its JSON line is kept
+# beside the stats: HIP-event and profiler durations of the SAME launches), then one --pmc pass per counter group (tools/pmc_run.sh, 64
 # mutations/pixel launches: counters are per mutation),
 # then the summary bench.py reads. Outputs land in gpurun_out/; copy what is to be judged into profiles/.
 set -e
@@ -14,9 +14,10 @@ for cfg in "$@"; do
   esac
   cmd="python3 $R/bench.py --config $cfg --steps 1 --warmup 0 --spp 64 --no-cpu-baseline --no-quality"
   echo "== $cfg: kernel trace" >> $R/gpurun_out/profile_progress.txt
-  ( cd /tmp && export TMPDIR=/tmp && timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/kt_${rt}_$cfg -- python3 $R/bench.py --config $cfg --steps 4 --warmup 1 --no-cpu-baseline --no-quality > $R/gpurun_out/kt_${rt}_${cfg}_bench.json 2> $R/gpurun_out/kt_${rt}_$cfg.log )
+  ( cd /tmp && export TMPDIR=/tmp && timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/kt_${rt}_$cfg -- python3 $R/bench.py --config $cfg --steps 5 --warmup 0 --no-cpu-baseline --no-quality > $R/gpurun_out/kt_${rt}_${cfg}_bench.json 2> $R/gpurun_out/kt_${rt}_$cfg.log )
   f=$(find $R/gpurun_out/kt_${rt}_$cfg -name '*kernel_stats.csv' | head -1)
   cp "$f" $R/gpurun_out/${rt}_${name}_kernel_stats.csv
+  [ -n "$SKIP_PMC" ] && continue
   echo "== $cfg: counters" >> $R/gpurun_out/profile_progress.txt
   PMC_CMD="$cmd" $R/tools/pmc_run.sh ${rt}_$cfg \
     "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS SQ_WAVES" \
