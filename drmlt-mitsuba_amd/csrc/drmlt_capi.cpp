@@ -780,7 +780,7 @@ int drmlt_run(drmlt_ctx *ctx, uint64_t total_mutations, volatile int *stop, drml
     const bool timed = ctx->cfg.timeout_s > 0;
     const auto t_start = std::chrono::steady_clock::now();
     // Run-ahead (k_mutate_v4, more than one launch to go): a launch ends when every chain has reached its target, and until then
-    // chains that are there keep going -- towards the total of THIS call, at most 4096 mutations beyond the target (16-bit event
+    // chains that are there keep going -- towards the total of THIS call, at most 8192 mutations beyond the target (16-bit event
     // counters per chain and launch). The last launch has target = limit = total: every chain ends at exactly its count.
     // (A single launch has target = limit and is the plain fixed-count launch; the per-chain counts are kept either way.)
     const bool ahead = ctx->cfg.technique == DRMLT_TECH_PATH && ctx->cfg.algo != DRMLT_ALGO_PSSMLT && ctx->P.kernel_variant == 4 &&
@@ -805,7 +805,7 @@ int drmlt_run(drmlt_ctx *ctx, uint64_t total_mutations, volatile int *stop, drml
             DParams Q = ctx->P;
             const uint64_t target = call_base + done + n;
             Q.chain_done = ctx->d_done.as<uint32_t>();
-            Q.run_limit = (uint32_t) std::min<uint64_t>(call_end, target + std::min<uint64_t>(4 * slice, 8192)); // at most four launches ahead (the per-chain event counters of a launch are 16 bits wide)
+            Q.run_limit = (uint32_t) std::min<uint64_t>(call_end, target + (getenv("DRMLT_AHEAD_CAP") ? (uint64_t) atoi(getenv("DRMLT_AHEAD_CAP")) : std::min<uint64_t>(8 * slice, 8192))); // at most eight launches ahead (the per-chain event counters of a launch are 16 bits wide); measured on config 3: 1024 6.7e8, 4096 7.1e8, 8192 7.14e8
             launch_set_u32(Q.waves_left, (ctx->n_chains + 31u) / 32u, ctx->stream);
             launch_mutate(Q, (uint32_t) target, 0u, ctx->stream);
         } else launch_mutate(ctx->P, n, ctx->mutation_base, ctx->stream);
@@ -827,7 +827,7 @@ int drmlt_run(drmlt_ctx *ctx, uint64_t total_mutations, volatile int *stop, drml
         ctx->kt_launches++;
     }
     if (ahead && done < per_chain && done > 0) {
-        // stopped early (cancel / timeout): chains are at the last target or up to four launches beyond it. One catch-up launch
+        // stopped early (cancel / timeout): chains are at the last target or up to eight launches beyond it. One catch-up launch
         // brings everybody to the most advanced chain's count, so that a stopped render, too, has run every chain equally long.
         std::vector<uint32_t> h(ctx->n_chains);
         HIP_TRY(ctx, hipMemcpy(h.data(), ctx->d_done.p, h.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
