@@ -177,3 +177,31 @@ def test_refused_configurations(pkg, native_lib):
                     (dict(technique="bdpt", max_depth=5, timid_after_large=1), "bdpt")):
         with pytest.raises(pkg.DrmltError, match=msg):
             pkg.Context(pkg.abi.make_config(work_units=64, **kw), sd)
+
+
+def test_depth_ordered_execution_changes_no_chain(pkg, native_lib):
+    """k_mutate_mmlt runs the chains in order of their path depth, deepest first (waves of one depth: a wave costs what its
+    deepest chain costs). Only the wave a chain rides in changes: chain ids, states and random streams are untouched."""
+    import os
+    sd = pkg.scenes.caustic_c5(32)
+    n = 4096 + 37                                        # a ragged last wave
+    cfg = pkg.abi.make_config(technique="mmlt", type="orbital", max_depth=6, direct_samples=-1, fix_emitter_path=1, work_units=n,
+                              sample_count=1, luminance_samples=20000)
+    res = []
+    for no_sort in (False, True):
+        if no_sort:
+            os.environ["DRMLT_MMLT_NO_SORT"] = "1"
+        try:
+            ctx = pkg.Context(cfg, sd)
+            ctx.seed(0xBEEF)
+        finally:
+            os.environ.pop("DRMLT_MMLT_NO_SORT", None)
+        ctx.run(n * 50)
+        res.append((ctx.chain_state(28), ctx.stats(), ctx.film()))
+    (c0, u0), s0, f0 = res[0]
+    (c1, u1), s1, f1 = res[1]
+    assert np.array_equal(u0, u1) and np.array_equal(c0["luminance"], c1["luminance"]) and np.array_equal(c0["n_dims"], c1["n_dims"])
+    assert s0.accepted == s1.accepted and s0.rays == s1.rays and s0.mutations == s1.mutations == n * 50
+    assert lum(f0).sum() == pytest.approx(lum(f1).sum(), rel=1e-5)
+    depths = c0["n_dims"]                                # chain_state reports the chain's path depth there
+    assert depths.min() >= 1 and depths.max() == 6 and len(np.unique(depths)) >= 4      # (depth-1 paths carry nothing here: no seeds)
