@@ -450,6 +450,35 @@ template <int FEAT = 15> DEV void intersect_prim(const DPrim &P, int idx, f3 o, 
     }
 }
 
+// The same test for one record PER LANE (a BVH leaf), as straight-line code: with the kind in a vector register the
+// selects of intersect_prim become branches over the lane mask. `ok`: the lane holds a leaf (the others computed on zeros).
+template <int FEAT = 15> DEV void intersect_leaf(const DPrim &P, bool ok, f3 o, f3 d, float tmin, Hit &h) {
+    const f3 lo = mk3(fmaf(P.m[0], o.x, fmaf(P.m[1], o.y, fmaf(P.m[2], o.z, P.m[3]))),
+                      fmaf(P.m[4], o.x, fmaf(P.m[5], o.y, fmaf(P.m[6], o.z, P.m[7]))),
+                      fmaf(P.m[8], o.x, fmaf(P.m[9], o.y, fmaf(P.m[10], o.z, P.m[11]))));
+    const f3 ld = mk3(fmaf(P.m[0], d.x, fmaf(P.m[1], d.y, P.m[2] * d.z)), fmaf(P.m[4], d.x, fmaf(P.m[5], d.y, P.m[6] * d.z)),
+                      fmaf(P.m[8], d.x, fmaf(P.m[9], d.y, P.m[10] * d.z)));
+    const int type = P.type;
+    const float t = -lo.z * fast_rcp(ld.z);
+    const float u = fmaf(t, ld.x, lo.x), v = fmaf(t, ld.y, lo.y);
+    const float w_tri = 1.f - (u + v), w_par = fminf(1.f - u, 1.f - v);
+    const float w = type == PRIM_TRIANGLE ? w_tri : w_par;
+    bool hit = ok & (fminf(fminf(u, v), w) >= 0.f) & (t >= tmin) & (t <= h.t);
+    if (FEAT & 4) hit = hit & (type != PRIM_SPHERE);
+    const bool quad2 = type == PRIM_QUAD2, second = quad2 & (v > u); // sub-triangle (a,b,c) for v <= u, (a,c,d) otherwise; its own barycentrics
+    const float uq = second ? u : u - v, vq = second ? v - u : v;
+    h.prim = hit ? P.shade + (second ? 1 : 0) : h.prim;
+    h.t = hit ? t : h.t;
+    h.u = hit ? (quad2 ? uq : u) : h.u;
+    h.v = hit ? (quad2 ? vq : v) : h.v;
+    if (FEAT & 4) {
+        const bool sph = ok & (type == PRIM_SPHERE);
+        if (__ballot(sph)) { // wave-uniform: scenes with spheres keep the general test for them
+            if (sph) intersect_prim<FEAT>(P, P.shade, o, d, tmin, h);
+        }
+    }
+}
+
 // closest hit in [tmin, tmax] over all primitives. The loop index is wave-uniform, so the 64 B
 // primitive record is fetched through the SCALAR cache (constant address space => s_load_dwordx16)
 // and feeds the VALU ops as SGPR operands: no VGPRs, no vector-memory latency in the loop.
@@ -542,7 +571,7 @@ DEV unsigned umax2(unsigned a, unsigned b) { return a < b ? b : a; }
 // only has to hold the hot top of the stack, and 3.5 KB instead of 6.5 KB keep eight waves on a CU).
 template <class StackT, class PT, bool OVF = true, int CAP = BVH_STACK> DEV void trav_run(const PT &P, Trav &T, bool mine, int yield_lanes) {
     constexpr int SPILL = CAP / 2; // entries moved at a time
-    __shared__ StackT bvh_stack[(CAP + 2) * 64]; // + 2: the branch-free pushes write one or two entries above the top
+    __shared__ StackT bvh_stack[(CAP + 3) * 64]; // + 3: the branch-free pushes write up to three entries above the top (lanes that hold no node: all three, from row CAP)
     StackT *const stk = bvh_stack + (threadIdx.x & 63u); // every kernel that traces runs one wave per workgroup
     // The LDS column holds CAP entries (+ 2 spare); a tree deeper than CAP / 3 levels can need more. Slow paths: before a
     // node's pushes could run past the column its SPILL OLDEST entries move to this lane's column of an overflow area in
@@ -559,6 +588,10 @@ template <class StackT, class PT, bool OVF = true, int CAP = BVH_STACK> DEV void
         T.sp = SPILL;
     };
     const bool has_ovf = OVF && P.bvh_overflow != nullptr; // wave-uniform
+    // node and primitive records as raw buffers (byte offsets; drmlt_create refuses arrays of 2 GiB and more)
+    const __amdgpu_buffer_rsrc_t r_bvh = __builtin_amdgcn_make_buffer_rsrc((void *) (uintptr_t) P.bvh, 0, 0x80000000u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_prm = __builtin_amdgcn_make_buffer_rsrc((void *) (uintptr_t) P.prims, 0, 0x80000000u, 0x00020000);
+    constexpr unsigned TRAV_NO_FETCH = 0xfffff000u;
     int finished = 0;
     for (;;) {
         const bool run = mine && T.active;
@@ -566,101 +599,109 @@ template <class StackT, class PT, bool OVF = true, int CAP = BVH_STACK> DEV void
         if (!m_inner && !m_leaf) break;
         if (yield_lanes > 0 && finished >= yield_lanes) break;
         bool done_now = false;
+        // Both blocks below are STRAIGHT-LINE code for the whole wave: a lane that does not hold the kind being advanced
+        // computes on whatever its registers hold and keeps nothing of it (its pushes land in the spare rows above the
+        // column, every state update is a select on `ok`). Only the fetches sit under the lane mask. As per-lane branches
+        // the same code cost ~30 register copies and ~50 scalar instructions per iteration at the merges of its nested
+        // conditions -- about as much as the node test itself.
         if (__popcll(m_inner) * P.trace_vote >= __popcll(m_leaf) * 16) { // a leaf test costs about 0.4 node tests: see drmlt_capi.cpp
             T.it_inner++;
-            if (run && T.cur >= 0) {
-                // The node's rows (16 bytes each: lox, hix, loy, hiy, loz, hiz, child) are fetched with the lo / hi rows of an
-                // axis SWAPPED where the ray runs against it: the first of each pair then holds the four NEAR planes, the second
-                // the four FAR ones, and the slab test needs no per-axis min / max (24 of ~110 vector instructions per node).
-                typedef const u32x4_t __attribute__((address_space(1))) *GRow;
-                const GRow rows = (GRow) (uintptr_t) P.bvh + (size_t) T.cur * 8u;
-                const u32x4_t nxr = rows[T.rx], fxr = rows[T.rx ^ 1u], nyr = rows[2u + T.ry], fyr = rows[2u + (T.ry ^ 1u)];
-                const u32x4_t nzr = rows[4u + T.rz], fzr = rows[4u + (T.rz ^ 1u)], chr = rows[6];
-                T.n_nodes++;
-                if (has_ovf && T.sp > CAP - 3) spill();
-                typedef float f2 __attribute__((ext_vector_type(2)));
-                const f2 ix = {T.inv.x, T.inv.x}, iy = {T.inv.y, T.inv.y}, iz = {T.inv.z, T.inv.z};
-                const f2 ox = {T.oi.x, T.oi.x}, oy = {T.oi.y, T.oi.y}, oz = {T.oi.z, T.oi.z};
-                float tn[4];
-                bool hitc[4];
-                int childc[4] = {(int) chr.x, (int) chr.y, (int) chr.z, (int) chr.w};
+            const bool ok = run && T.cur >= 0;
+            if (has_ovf) { if (ok && T.sp > CAP - 3) spill(); }
+            // The node's rows (16 bytes each: lox, hix, loy, hiy, loz, hiz, child) are fetched with the lo / hi rows of an
+            // axis SWAPPED where the ray runs against it: the first of each pair then holds the four NEAR planes, the second
+            // the four FAR ones, and the slab test needs no per-axis min / max (24 of ~110 vector instructions per node).
+            // Fetched through a buffer resource: a lane that holds no node offers an offset beyond the resource's range, for which
+            // the load returns zeros without a memory access -- no lane mask, no branch, no register to initialise.
+            const unsigned nb = ok ? (unsigned) T.cur << 7 : TRAV_NO_FETCH;
+            const u32x4_t nxr = __builtin_amdgcn_raw_buffer_load_b128(r_bvh, nb + (T.rx << 4), 0, 0), fxr = __builtin_amdgcn_raw_buffer_load_b128(r_bvh, nb + ((T.rx ^ 1u) << 4), 0, 0);
+            const u32x4_t nyr = __builtin_amdgcn_raw_buffer_load_b128(r_bvh, nb + 32u + (T.ry << 4), 0, 0), fyr = __builtin_amdgcn_raw_buffer_load_b128(r_bvh, nb + 32u + ((T.ry ^ 1u) << 4), 0, 0);
+            const u32x4_t nzr = __builtin_amdgcn_raw_buffer_load_b128(r_bvh, nb + 64u + (T.rz << 4), 0, 0), fzr = __builtin_amdgcn_raw_buffer_load_b128(r_bvh, nb + 64u + ((T.rz ^ 1u) << 4), 0, 0);
+            const u32x4_t chr = __builtin_amdgcn_raw_buffer_load_b128(r_bvh, nb + 96u, 0, 0);
+            T.n_nodes += ok ? 1u : 0u;
+            typedef float f2 __attribute__((ext_vector_type(2)));
+            const f2 ix = {T.inv.x, T.inv.x}, iy = {T.inv.y, T.inv.y}, iz = {T.inv.z, T.inv.z};
+            const f2 ox = {T.oi.x, T.oi.x}, oy = {T.oi.y, T.oi.y}, oz = {T.oi.z, T.oi.z};
+            float tn[4];
+            bool hitc[4];
+            const int childc[4] = {(int) chr.x, (int) chr.y, (int) chr.z, (int) chr.w};
 #pragma unroll
-                for (int h2 = 0; h2 < 2; ++h2) { // children (0, 1), then (2, 3): v_pk_fma_f32
-                    auto pr = [&](const u32x4_t &r) { return h2 == 0 ? (f2){__uint_as_float(r.x), __uint_as_float(r.y)} : (f2){__uint_as_float(r.z), __uint_as_float(r.w)}; };
-                    const f2 t0x = __builtin_elementwise_fma(pr(nxr), ix, ox), t1x = __builtin_elementwise_fma(pr(fxr), ix, ox);
-                    const f2 t0y = __builtin_elementwise_fma(pr(nyr), iy, oy), t1y = __builtin_elementwise_fma(pr(fyr), iy, oy);
-                    const f2 t0z = __builtin_elementwise_fma(pr(nzr), iz, oz), t1z = __builtin_elementwise_fma(pr(fzr), iz, oz);
+            for (int h2 = 0; h2 < 2; ++h2) { // children (0, 1), then (2, 3): v_pk_fma_f32
+                auto pr = [&](const u32x4_t &r) { return h2 == 0 ? (f2){__uint_as_float(r.x), __uint_as_float(r.y)} : (f2){__uint_as_float(r.z), __uint_as_float(r.w)}; };
+                const f2 t0x = __builtin_elementwise_fma(pr(nxr), ix, ox), t1x = __builtin_elementwise_fma(pr(fxr), ix, ox);
+                const f2 t0y = __builtin_elementwise_fma(pr(nyr), iy, oy), t1y = __builtin_elementwise_fma(pr(fyr), iy, oy);
+                const f2 t0z = __builtin_elementwise_fma(pr(nzr), iz, oz), t1z = __builtin_elementwise_fma(pr(fzr), iz, oz);
 #pragma unroll
-                    for (int q = 0; q < 2; ++q) {
-                        const float a = fmaxf(fmaxf(t0x[q], t0y[q]), fmaxf(t0z[q], T.tmin));
-                        const float f = fminf(fminf(t1x[q], t1y[q]), fminf(t1z[q], T.h.t));
-                        tn[2 * h2 + q] = a;
-                        hitc[2 * h2 + q] = a <= f;
-                    }
-                }
-                if constexpr (sizeof(StackT) == 2) {
-                    // 16-bit child references: the sort key carries the child itself -- entry distance in the upper half (its bit
-                    // pattern orders like an unsigned: tn >= tmin >= 0; 7 mantissa bits are plenty for an ORDER), reference in
-                    // the lower half. Everything below is selects: no exec-mask traffic, no branches but the pop.
-                    unsigned key[4];
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        const unsigned kk = (__float_as_uint(tn[c]) & 0xffff0000u) | ((unsigned) childc[c] & 0xffffu);
-                        key[c] = hitc[c] ? kk : 0xffffffffu;
-                    }
-                    // sorting network (0,1)(2,3)(0,2)(1,3)(1,2)
-                    const unsigned a0 = umin2(key[0], key[1]), a1 = umax2(key[0], key[1]), a2 = umin2(key[2], key[3]), a3 = umax2(key[2], key[3]);
-                    const unsigned b0 = umin2(a0, a2), b2 = umax2(a0, a2), b1 = umin2(a1, a3), b3 = umax2(a1, a3);
-                    const unsigned k0 = b0, k1 = umin2(b1, b2), k2 = umax2(b1, b2), k3 = b3;
-                    // far ones first, so that the nearest pending child ends on top; a write above the top of the stack is harmless
-                    int sp = T.sp;
-                    stk[sp * 64] = (StackT) k3; sp += k3 != 0xffffffffu ? 1 : 0;
-                    stk[sp * 64] = (StackT) k2; sp += k2 != 0xffffffffu ? 1 : 0;
-                    stk[sp * 64] = (StackT) k1; sp += k1 != 0xffffffffu ? 1 : 0;
-                    T.sp = sp;
-                    if (k0 != 0xffffffffu) T.cur = (int) (short) (k0 & 0xffffu);
-                    else if (T.sp != 0) T.cur = stk[--T.sp * 64];
-                    else if (has_ovf && T.ovf > 0) { refill(); T.cur = stk[--T.sp * 64]; }
-                    else { T.active = false; done_now = true; }
-                } else {
-                    // 32-bit child references: the key carries the SLOT in its two low mantissa bits; selects pick the child
-                    unsigned key[4];
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) key[c] = hitc[c] ? ((__float_as_uint(tn[c]) & 0x7ffffffcu) | (unsigned) c) : 0xffffffffu;
-                    const unsigned a0 = umin2(key[0], key[1]), a1 = umax2(key[0], key[1]), a2 = umin2(key[2], key[3]), a3 = umax2(key[2], key[3]);
-                    const unsigned b0 = umin2(a0, a2), b2 = umax2(a0, a2), b1 = umin2(a1, a3), b3 = umax2(a1, a3);
-                    const unsigned k0 = b0, k1 = umin2(b1, b2), k2 = umax2(b1, b2), k3 = b3;
-                    const int c0 = childc[0], c1 = childc[1], c2 = childc[2], c3 = childc[3];
-                    auto child_of = [&](unsigned k) {
-                        const int lo = (k & 1u) ? c1 : c0, hi = (k & 1u) ? c3 : c2;
-                        return (k & 2u) ? hi : lo;
-                    };
-                    int sp = T.sp;
-                    stk[sp * 64] = (StackT) child_of(k3); sp += k3 != 0xffffffffu ? 1 : 0;
-                    stk[sp * 64] = (StackT) child_of(k2); sp += k2 != 0xffffffffu ? 1 : 0;
-                    stk[sp * 64] = (StackT) child_of(k1); sp += k1 != 0xffffffffu ? 1 : 0;
-                    T.sp = sp;
-                    if (k0 != 0xffffffffu) T.cur = child_of(k0);
-                    else if (T.sp != 0) T.cur = stk[--T.sp * 64];
-                    else if (has_ovf && T.ovf > 0) { refill(); T.cur = stk[--T.sp * 64]; }
-                    else { T.active = false; done_now = true; }
+                for (int q = 0; q < 2; ++q) {
+                    const float a = fmaxf(fmaxf(t0x[q], t0y[q]), fmaxf(t0z[q], T.tmin));
+                    const float f = fminf(fminf(t1x[q], t1y[q]), fminf(t1z[q], T.h.t));
+                    tn[2 * h2 + q] = a;
+                    hitc[2 * h2 + q] = a <= f;
                 }
             }
+            // Sort keys, nearest first. 16-bit child references: the key carries the child itself -- entry distance in the
+            // upper half (its bit pattern orders like an unsigned: tn >= tmin >= 0; 7 mantissa bits are plenty for an ORDER),
+            // reference in the lower half. 32-bit references: the key carries the SLOT in its two low mantissa bits.
+            unsigned key[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const unsigned kk = sizeof(StackT) == 2 ? ((__float_as_uint(tn[c]) & 0xffff0000u) | ((unsigned) childc[c] & 0xffffu))
+                                                        : ((__float_as_uint(tn[c]) & 0x7ffffffcu) | (unsigned) c);
+                key[c] = hitc[c] ? kk : 0xffffffffu;
+            }
+            // sorting network (0,1)(2,3)(0,2)(1,3)(1,2)
+            const unsigned a0 = umin2(key[0], key[1]), a1 = umax2(key[0], key[1]), a2 = umin2(key[2], key[3]), a3 = umax2(key[2], key[3]);
+            const unsigned b0 = umin2(a0, a2), b2 = umax2(a0, a2), b1 = umin2(a1, a3), b3 = umax2(a1, a3);
+            const unsigned k0 = b0, k1 = umin2(b1, b2), k2 = umax2(b1, b2), k3 = b3;
+            auto child_of = [&](unsigned k) -> int {
+                if constexpr (sizeof(StackT) == 2) return (int) (short) (k & 0xffffu);
+                else {
+                    const int lo = (k & 1u) ? childc[1] : childc[0], hi = (k & 1u) ? childc[3] : childc[2];
+                    return (k & 2u) ? hi : lo;
+                }
+            };
+            // far ones first, so that the nearest pending child ends on top; a write above the top of the stack is harmless
+            int sp = ok ? T.sp : CAP;
+            stk[sp * 64] = (StackT) child_of(k3); sp += k3 != 0xffffffffu ? 1 : 0;
+            stk[sp * 64] = (StackT) child_of(k2); sp += k2 != 0xffffffffu ? 1 : 0;
+            stk[sp * 64] = (StackT) child_of(k1); sp += k1 != 0xffffffffu ? 1 : 0;
+            const bool has0 = k0 != 0xffffffffu;
+            const int below = sp > 0 ? sp - 1 : 0;
+            const int top = stk[below * 64]; // the pop, should the node have no child to descend into
+            bool fin = !has0 && sp == 0;
+            T.cur = ok && !fin ? (has0 ? child_of(k0) : top) : T.cur;
+            T.sp = ok ? (has0 ? sp : below) : T.sp;
+            if (has_ovf) { if (ok && fin && T.ovf > 0) { refill(); T.cur = stk[--T.sp * 64]; fin = false; } }
+            done_now = ok && fin;
+            T.active = T.active && !done_now;
         } else {
             T.it_leaf++;
-            if (run && T.cur < 0) {
-                // leaf reference: ~(first << shift | count); shift = 0 when every leaf holds one primitive (the default build)
-                const int first = ~T.cur >> P.bvh_leaf_shift, n = P.bvh_leaf_shift ? (~T.cur & 7) : 1;
-                T.n_prims += (uint32_t) n;
+            const bool ok = run && T.cur < 0;
+            // leaf reference: ~(first << shift | count); shift = 0 when every leaf holds one primitive (the default build)
+            const int first = ~T.cur >> P.bvh_leaf_shift, n = P.bvh_leaf_shift ? (~T.cur & 7) : 1;
+            T.n_prims += ok ? (uint32_t) n : 0u;
+            if (P.bvh_leaf_shift == 0) { // wave-uniform
+                union { DPrim v; u32x4_t w[4]; } G;
+                const unsigned pb = ok ? (unsigned) first << 6 : TRAV_NO_FETCH;
+#pragma unroll
+                for (unsigned k = 0; k < 4u; ++k) G.w[k] = __builtin_amdgcn_raw_buffer_load_b128(r_prm, pb + 16u * k, 0, 0);
+                intersect_leaf(G.v, ok, T.o, T.d, T.tmin, T.h);
+            } else if (ok) {
                 for (int i = 0; i < n; ++i) {
                     const DPrim G = load_global16(P.prims + first + i);
                     intersect_prim(G, G.shade, T.o, T.d, T.tmin, T.h);
                 }
-                if (T.any_hit && T.h.prim >= 0) { T.active = false; done_now = true; }
-                else if (T.sp != 0) T.cur = stk[--T.sp * 64];
-                else if (has_ovf && T.ovf > 0) { refill(); T.cur = stk[--T.sp * 64]; }
-                else { T.active = false; done_now = true; }
             }
+            const bool found = T.any_hit && T.h.prim >= 0;
+            const int sp = ok ? T.sp : 0;
+            const int below = sp > 0 ? sp - 1 : 0;
+            const int top = stk[below * 64];
+            bool fin = found || sp == 0;
+            T.cur = ok && !fin ? top : T.cur;
+            T.sp = ok ? below : T.sp;
+            if (has_ovf) { if (ok && !found && sp == 0 && T.ovf > 0) { refill(); T.cur = stk[--T.sp * 64]; fin = false; } }
+            done_now = ok && fin;
+            T.active = T.active && !done_now;
         }
         finished += __popcll(__ballot(done_now));
     }

@@ -774,7 +774,7 @@ __global__ void __launch_bounds__(CHAIN_BLOCK) k_mutate_v3(DParams P, uint32_t n
 // Chains are the same as k_mutate_v2/v3's (same addressed draws, same arithmetic per chain).
 #define V4_STRIDE 33u // row stride of the sampler rows: (row + chain) mod 32 banks serve per-chain AND per-dimension access patterns
 #define V4_QCAP 160u  // splat queue entries: flushed when a bookkeeping branch (at most 3 x 32 new entries) might not fit
-#define V4_STACK32_CAP 12 // LDS entries of a 32-bit traversal stack (the rest spills): 14 rows of 256 B keep eight waves on a CU
+#define V4_STACK32_CAP 11 // LDS entries of a 32-bit traversal stack (the rest spills): 11 + 3 spare rows of 256 B keep eight waves on a CU
 #define V4_QCAP_BVH 100u // BVH scenes: their kernel also keeps the traversal stack in LDS (6 KB); flushes are a negligible part of it
 
 // field-by-field copy of the parameter block out of the kernarg segment (constant address space: scalar loads)
