@@ -569,7 +569,7 @@ DEV unsigned umax2(unsigned a, unsigned b) { return a < b ? b : a; }
 // 4 % there even when never taken).
 // CAP: entries of the LDS column (k_mutate_v4 gives its 32-bit stacks 12 instead of 24 -- with the overflow paths the column
 // only has to hold the hot top of the stack, and 3.5 KB instead of 6.5 KB keep eight waves on a CU).
-template <class StackT, class PT, bool OVF = true, int CAP = BVH_STACK> DEV void trav_run(const PT &P, Trav &T, bool mine, int yield_lanes) {
+template <class StackT, class PT, bool OVF = true, int CAP = BVH_STACK, int FEAT = 15> DEV void trav_run(const PT &P, Trav &T, bool mine, int yield_lanes) {
     constexpr int SPILL = CAP / 2; // entries moved at a time
     __shared__ StackT bvh_stack[(CAP + 3) * 64]; // + 3: the branch-free pushes write up to three entries above the top (lanes that hold no node: all three, from row CAP)
     StackT *const stk = bvh_stack + (threadIdx.x & 63u); // every kernel that traces runs one wave per workgroup
@@ -685,7 +685,7 @@ template <class StackT, class PT, bool OVF = true, int CAP = BVH_STACK> DEV void
                 const unsigned pb = ok ? (unsigned) first << 6 : TRAV_NO_FETCH;
 #pragma unroll
                 for (unsigned k = 0; k < 4u; ++k) G.w[k] = __builtin_amdgcn_raw_buffer_load_b128(r_prm, pb + 16u * k, 0, 0);
-                intersect_leaf(G.v, ok, T.o, T.d, T.tmin, T.h);
+                intersect_leaf<FEAT>(G.v, ok, T.o, T.d, T.tmin, T.h);
             } else if (ok) {
                 for (int i = 0; i < n; ++i) {
                     const DPrim G = load_global16(P.prims + first + i);

@@ -1155,8 +1155,8 @@ __global__ void __launch_bounds__(CHAIN_BLOCK) k_mutate_v4(DParams P, uint32_t n
             {
                 SECTION_PARAMS(Pt);
                 if (rstate == 1) { trav_begin(T, ps.o, ps.d, ps.tmin, ps.tmax, helper); rstate = 2; }
-                if (STACK16) trav_run<short, DParams, OVF>(Pt, T, rstate == 2, Pt.trace_yield);
-                else trav_run<int, DParams, true, V4_STACK32_CAP>(Pt, T, rstate == 2, Pt.trace_yield); // always with the overflow paths
+                if (STACK16) trav_run<short, DParams, OVF, BVH_STACK, FEAT>(Pt, T, rstate == 2, Pt.trace_yield);
+                else trav_run<int, DParams, true, V4_STACK32_CAP, FEAT>(Pt, T, rstate == 2, Pt.trace_yield); // always with the overflow paths
                 if (rstate == 2 && !T.active) rstate = 3;
             }
             if (prio) __builtin_amdgcn_s_setprio(3);
@@ -1342,6 +1342,7 @@ void launch_mutate(const DParams &P, uint32_t n_mut, uint32_t mut_base, hipStrea
         } else if (!P.bvh_stack16) hipLaunchKernelGGL((k_mutate_v4<15, false, false, false, true>), g4, block, lds, st, P, n_mut, mut_base);
         else if (P.bvh_overflow) hipLaunchKernelGGL((k_mutate_v4<15, false, false, true, true>), g4, block, lds, st, P, n_mut, mut_base);
         else if (P.debug & 128) hipLaunchKernelGGL((k_mutate_v4<15, false, true, true>), g4, block, lds, st, P, n_mut, mut_base); // diagnostic stamps
+        else if (P.features == 8) hipLaunchKernelGGL((k_mutate_v4<8, false, false, true>), g4, block, lds, st, P, n_mut, mut_base); // triangle meshes with diffuse surfaces only
         else hipLaunchKernelGGL((k_mutate_v4<15, false, false, true>), g4, block, lds, st, P, n_mut, mut_base);
     } else if (P.kernel_variant == 3) { // 32 chains per wave, rows of 32 floats
         size_t lds = (D + 2 * D4) * 32 * sizeof(float);
