@@ -1339,7 +1339,8 @@ void launch_mutate(const DParams &P, uint32_t n_mut, uint32_t mut_base, hipStrea
             else if (!P.bvh_stack16) hipLaunchKernelGGL((k_mutate_v4<15, true, false, false, true>), g4, block, lds, st, P, n_mut, mut_base);
             else if (P.bvh_overflow) hipLaunchKernelGGL((k_mutate_v4<15, true, false, true, true>), g4, block, lds, st, P, n_mut, mut_base);
             else hipLaunchKernelGGL((k_mutate_v4<15, true, false, true>), g4, block, lds, st, P, n_mut, mut_base);
-        } else if (!P.bvh_stack16) hipLaunchKernelGGL((k_mutate_v4<15, false, false, false, true>), g4, block, lds, st, P, n_mut, mut_base);
+        } else if (!P.bvh_stack16 && P.features == 8) hipLaunchKernelGGL((k_mutate_v4<8, false, false, false, true>), g4, block, lds, st, P, n_mut, mut_base);
+        else if (!P.bvh_stack16) hipLaunchKernelGGL((k_mutate_v4<15, false, false, false, true>), g4, block, lds, st, P, n_mut, mut_base);
         else if (P.bvh_overflow) hipLaunchKernelGGL((k_mutate_v4<15, false, false, true, true>), g4, block, lds, st, P, n_mut, mut_base);
         else if (P.debug & 128) hipLaunchKernelGGL((k_mutate_v4<15, false, true, true>), g4, block, lds, st, P, n_mut, mut_base); // diagnostic stamps
         else if (P.features == 8) hipLaunchKernelGGL((k_mutate_v4<8, false, false, true>), g4, block, lds, st, P, n_mut, mut_base); // triangle meshes with diffuse surfaces only
