@@ -522,11 +522,13 @@ drmlt_ctx *drmlt_create(const drmlt_config *cfg, const drmlt_scene *scene, int d
     for (const DPrim &g : ctx->prims) if (g.type == PRIM_SPHERE) P.features |= 4;
     if (P.use_bvh) P.features |= 8;
     if (getenv("DRMLT_FEAT_ALL")) P.features = 15;
-    P.mh_batch = P.kernel_variant == 4 ? (P.use_bvh ? 6 : (P.features == 0 ? 12 : 8)) : 32; // v4: chains run free, the bookkeeping branch fires as soon as a few are parked
+    P.mh_batch = P.kernel_variant == 4 ? (P.use_bvh ? (P.bvh_stack16 ? 6 : 4) : (P.features == 0 ? 12 : 8)) : 32; // v4: chains run free, the bookkeeping branch fires as soon as a few are parked
     if (const char *k = getenv("DRMLT_MH_BATCH")) P.mh_batch = std::max(1, std::min(64, atoi(k)));
     P.bvh_overflow = nullptr; P.bvh_ovf_lanes = 0;
     P.exec_order = nullptr;
-    P.trace_yield = 24; // measured on the 2000-triangle soup (5-launch calls): 16 3.69e8, 20 3.80e8, 24 3.84e8, 28 3.84e8 mutations/s
+    // measured (5-launch calls) on the 2000-triangle soup: 16 3.69e8, 20 3.80e8, 24 3.84e8, 28 3.84e8 mutations/s; on 50 000 triangles (32-bit
+    // stacks, longer traversals): 20 1.90e8, 24 1.86e8, 28 1.79e8; bookkeeping batch there 4 1.89e8, 6 1.86e8, 8 1.82e8
+    P.trace_yield = P.bvh_stack16 ? 24 : 20;
     if (const char *k = getenv("DRMLT_TRACE_YIELD")) P.trace_yield = std::max(0, std::min(64, atoi(k)));
     P.trace_vote = 10; // measured on the 2000-triangle soup: 16 (plain majority) 2.70e8, 10 2.78e8, 5 2.73e8 mutations/s
     if (const char *k = getenv("DRMLT_TRACE_VOTE")) P.trace_vote = std::max(1, std::min(1024, atoi(k)));
