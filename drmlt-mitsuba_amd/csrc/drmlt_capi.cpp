@@ -367,13 +367,16 @@ drmlt_ctx *drmlt_create(const drmlt_config *cfg, const drmlt_scene *scene, int d
         int leaf_shift = 0;
         const int depth4 = build_bvh4(nodes, nodes4, &leaf_shift);
         P.bvh_leaf_shift = leaf_shift;
+        // the traversal addresses node and primitive records by 32-bit byte offsets into buffer resources of 2 GiB (trav_run)
+        if (nodes4.size() * sizeof(DBvh4Node) >= (1ull << 31) || ctx->prims.size() * sizeof(DPrim) >= (1ull << 31))
+            return bail(ctx, "scene too large: the BVH node and primitive arrays must stay below 2 GiB each");
         // 16-bit stack entries when every node index and leaf reference fits (k_mutate_v4: 3 KB of LDS instead of 6)
         P.bvh_stack16 = (nodes4.size() < 32768 && ((order.size() << leaf_shift) | 7u) < 32768 && !getenv("DRMLT_BVH_STACK32")) ? 1 : 0;
         // a 4-wide node pushes at most 3 entries, so a node at level l is entered with at most 3 (l - 1) on the stack and
-        // 3 * depth4 bound it: up to BVH_STACK that is the LDS column (the branch-free pushes use its two spare rows); deeper
+        // 3 * depth4 bound it: up to BVH_STACK that is the LDS column (the branch-free pushes use its spare rows); deeper
         // trees get an overflow area in memory, sized per launch (ensure_overflow)
         ctx->bvh_depth = depth4;
-        // (k_mutate_v4 keeps only 12 entries of a 32-bit stack in LDS: those scenes always have the area)
+        // (k_mutate_v4 keeps only 11 entries of a 32-bit stack in LDS: those scenes always have the area)
         ctx->ovf_entries = (3 * depth4 > BVH_STACK || !P.bvh_stack16) ? (3 * depth4 + 3 + BVH_SPILL - 1) / BVH_SPILL * BVH_SPILL : 0;
         if (getenv("DRMLT_VERBOSE")) fprintf(stderr, "[drmlt] BVH: %zu primitives, %zu binary / %zu 4-wide nodes, 4-wide depth %d (stack %d in LDS + %d in memory), %d median splits, %d-bit stack entries\n", order.size(), nodes.size(), nodes4.size(), depth4, BVH_STACK, ctx->ovf_entries, median_splits, P.bvh_stack16 ? 16 : 32);
         // intersection records go into leaf order; shading records stay where the emitters expect them
