@@ -13,7 +13,7 @@ import numpy as np
 from . import abi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "libdrmlt_amd.so")
+_LIB_PATH = os.environ.get("DRMLT_LIBRARY") or os.path.join(_HERE, "libdrmlt_amd.so")  # DRMLT_LIBRARY: another build of the same ABI (codegen experiments)
 _lib = None
 
 SPLAT_DTYPE = np.dtype([("luminance", "<f4"), ("x", "<f4"), ("y", "<f4"), ("rgb", "<f4", (3,)),
