@@ -439,3 +439,30 @@ def test_run_ahead_between_launches_changes_no_chain(pkg, ob, scene, kw, native_
         assert lum(f).sum() == pytest.approx(lum(f0).sum(), rel=1e-5)
         assert np.abs(lum(f) - lum(f0)).sum() / lum(f0).sum() < 1e-3
     assert res[0][1].launches == 7
+
+
+@pytest.mark.parametrize("scene,kw", [("caustic_c5", dict(type="orbital")), ("glass_sphere", dict(type="mira")), ("door_c3", dict(type="green"))],
+                         ids=["caustic-spheres", "glass-sphere", "door-conductor"])
+def test_forced_bvh_on_scenes_with_spheres_and_glossy_surfaces(pkg, ob, scene, kw, native_lib):
+    """The general build of the traversal (k_mutate_v4<15>: leaves may hold spheres, surfaces may be dielectric or rough
+    conductors) on scenes small enough for the brute-force loop: with the BVH forced on, f(u) equals the brute-force
+    loop's, and the free-running kernel runs the chains of the lock-step one."""
+    sd = pkg.scenes.SCENES[scene](res=32)
+    n_chains = 2048
+    cfg = pkg.abi.make_config(max_depth=8, direct_samples=-1, luminance_samples=20000, work_units=n_chains, sample_count=1, **kw)
+    u = np.random.default_rng(11).random((8192, 50), dtype=np.float32)
+    brute = _ctx_with_env(pkg, cfg, sd, DRMLT_BVH_THRESHOLD=1000000).eval_paths(u)
+    bvh = _ctx_with_env(pkg, cfg, sd, DRMLT_BVH_THRESHOLD=0).eval_paths(u)
+    same = brute["n_dims"] == bvh["n_dims"]
+    assert same.mean() > 0.995
+    assert np.allclose(brute["luminance"][same], bvh["luminance"][same], rtol=1e-4, atol=1e-6)
+    res = []
+    for env in (dict(DRMLT_BVH_THRESHOLD=0), dict(DRMLT_BVH_THRESHOLD=0, DRMLT_KERNEL=3)):
+        ctx = _ctx_with_env(pkg, cfg, sd, **env)
+        ctx.seed(0x4242)
+        ctx.run(n_chains * 120)
+        res.append((ctx.chain_state(34), ctx.stats(), ctx.film()))
+    ((c4, u4), s4, f4), ((c3, u3), s3, f3) = res
+    assert s4.bvh_node_visits > 0 and s4.bvh_prim_tests > 0
+    assert np.array_equal(u4, u3) and s4.accepted == s3.accepted and s4.rays == s3.rays
+    assert lum(f4).sum() == pytest.approx(lum(f3).sum(), rel=1e-5)
