@@ -45,7 +45,7 @@ def library_path():
 def build_native(force=False):
     """Compile the HIP kernels + C-ABI for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
     src = os.path.join(_HERE, "csrc")
-    args = ["make", "-C", src]
+    args = ["make", "-C", src, "-j%d" % min(4, os.cpu_count() or 1)]
     if force:
         args.append("-B")
     subprocess.check_call(args, stdout=subprocess.DEVNULL)
