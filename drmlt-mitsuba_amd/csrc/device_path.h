@@ -750,10 +750,23 @@ template <bool TRI> DEV void test_flat(const FlatRec &G, f3 o, f3 d, float tmin,
 
 template <bool TRI> DEV Hit trace_flat(const DParams &P, f3 o, f3 d, float tmin, float tmax) {
     ScalarFlatPtr p = (ScalarFlatPtr) (uintptr_t) P.prims_flat;
+    // VOLATILE scalar loads (three per record: 8 + 4 + 1 dwords): they stay where the pipeline below puts them. Left to its
+    // scheduler the compiler sinks the read-ahead of a record to just before its first use and the wave then waits out a
+    // scalar-cache access per record.
     auto load = [](ScalarFlatPtr q, FlatRec &G) {
+#ifdef DRMLT_FLAT_PLAIN_LOADS
         G.cx = float2v{q->c[0], q->c[1]}; G.cy = float2v{q->c[2], q->c[3]}; G.cz = float2v{q->c[4], q->c[5]}; G.cw = float2v{q->c[6], q->c[7]};
         G.z0 = q->rz[0]; G.z1 = q->rz[1]; G.z2 = q->rz[2]; G.z3 = q->rz[3];
         G.ks = q->kind_shade;
+#else
+        typedef float f8v __attribute__((ext_vector_type(8)));
+        typedef float f4v __attribute__((ext_vector_type(4)));
+        const f8v c = *(const volatile f8v __attribute__((address_space(4))) *) &q->c[0];
+        const f4v z = *(const volatile f4v __attribute__((address_space(4))) *) &q->rz[0];
+        G.ks = *(const volatile int __attribute__((address_space(4))) *) &q->kind_shade;
+        G.cx = float2v{c[0], c[1]}; G.cy = float2v{c[2], c[3]}; G.cz = float2v{c[4], c[5]}; G.cw = float2v{c[6], c[7]};
+        G.z0 = z[0]; G.z1 = z[1]; G.z2 = z[2]; G.z3 = z[3];
+#endif
     };
 #define PINF(G) asm volatile("" ::"s"(G.cx.x), "s"(G.cz.x), "s"(G.z0), "s"(G.ks))
     float best_t = tmax;
