@@ -314,7 +314,9 @@ def main():
                                  "scene (scalar cache / LDS) and chain state (LDS) are on chip, compulsory HBM traffic is the film "
                                  "atomics (SURVEY 8d); the kernel is bound by VALU issue x lane utilisation"
                          if not args.config.startswith("soup") else
-                         "BVH and primitive records live in HBM/L2 here: hbm_measured_frac is the meaningful figure"},
+                         "BVH and primitive records live in HBM/L2 here: hbm_measured_frac is the meaningful figure; "
+                         "valu_lane_utilisation is the exec-mask figure and the traversal blocks run every lane (straight-line code, "
+                         "lanes without a ray keep nothing): ~25 of 64 lanes hold a node per node iteration (DRMLT_VERBOSE=1 prints it)"},
             "accepted_mutations_per_s": world * accepted / elapsed,
             "path_evals_per_s": world * evals / elapsed, "rays_per_s": world * rays / elapsed,
             "acceptance": {k: (round(v, 5) if v is not None else None) for k, v in st1.ratios().items()},
