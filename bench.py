@@ -65,6 +65,14 @@ CONFIGS = {
                     what="closed room with 50000 random triangles (BVH, primitive and shading records: 9.6 MB in HBM / L2; "
                          "32-bit traversal stacks) %(res)dx%(res)d, drmlt technique=path type=orbital, %(chains)d chains/GPU, "
                          "sampleCount %(spp)d"),
+    # a scene whose node / primitive / shading records (188 MB) exceed the L2 caches: the regime SURVEY 8(d) names as the one
+    # where memory, not instruction issue, would bound the path. 64 mutations/pixel per step (the scene is slow to traverse).
+    "soup1m": dict(scene=("triangle_soup", dict(n_tris=1000000)), res=512,
+                   cfg=dict(technique="path", type="orbital", max_depth=8, rr_depth=5), spp=64, kernel="k_mutate_v4",
+                   pmc="r02_soup1m_pmc.json", no_cpu_baseline="the CPU restatement has no acceleration structure: brute force over "
+                   "1e6 triangles per ray is not a baseline (soup50k already runs 3e3 mutations/s on 16 threads)", no_quality=True,
+                   what="closed room with 1000000 random triangles (BVH, primitive and shading records: 188 MB, beyond L2, inside "
+                        "the MALL) %(res)dx%(res)d, drmlt technique=path type=orbital, %(chains)d chains/GPU, sampleCount %(spp)d"),
 }
 
 
@@ -331,7 +339,7 @@ def main():
     # ---- image quality at the accumulated budget (outside the timed region)
     # (technique=path only: the device path tracer used as reference shares the path integrator's treatment of maxDepth;
     # the bidirectional techniques are held to the oracle's bdpt / mmlt renders in tests/test_gpu_bdpt.py, test_gpu_mmlt.py)
-    if not args.no_quality and not cfg_kw.get("acceptance_map") and cfg_kw.get("technique", "path") == "path":
+    if not args.no_quality and not conf.get("no_quality") and not cfg_kw.get("acceptance_map") and cfg_kw.get("technique", "path") == "path":
         if use_dist:  # every rank develops its tile of the summed film; rank 0 collects them
             tile, rows, b_mean = ctx.exchange_tiled(b)
             parts = [None] * world
@@ -349,7 +357,9 @@ def main():
                               "DEVICE, 2048 spp (its own noise is in the figure); device vs CPU-oracle protocol: parity_protocol",
                               "mutations_per_pixel": spp * args.steps * world, "b": b_mean, "mean_luminance": float(li.mean())}
 
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and conf.get("no_cpu_baseline"):
+        out["cpu_baseline"] = {"value": None, "unit": "mutations/s", "cores": 0, "kind": "port", "sample": "not measured: " + conf["no_cpu_baseline"]}
+    elif rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(pkg, conf, res, cfg_kw, args.cpu_seconds)
     elif rank == 0:
         out["cpu_baseline"] = None
