@@ -12,7 +12,7 @@ per_chain = int(sys.argv[3]) if len(sys.argv) > 3 else 256
 amap = int(sys.argv[4]) if len(sys.argv) > 4 else 1
 sd = pkg.scenes.SCENES[sys.argv[5] if len(sys.argv) > 5 else 'caustic_c5'](res)
 cfg = abi.make_config(technique='mmlt', type='orbital', max_depth=6, direct_samples=-1, fix_emitter_path=1,
-                      acceptance_map=amap, work_units=chains, sample_count=1, luminance_samples=1000)
+                      acceptance_map=amap, work_units=chains, sample_count=1, luminance_samples=1000, p_large=float(os.environ.get('PLARGE', 0.3)))
 ctx = pkg.Context(cfg, sd)
 t0 = time.time(); b = ctx.seed(0x5EED); t_seed = time.time() - t0
 ctx.run(chains * 16)
