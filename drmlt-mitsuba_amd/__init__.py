@@ -3,5 +3,5 @@
 The directory name is not a valid Python identifier; load it with
 `__graft_entry__.load_package()` (registers it as module `drmlt_mitsuba_amd`).
 """
-from . import abi, exchange, heatmap, scenes  # noqa: F401
+from . import abi, heatmap, scenes  # noqa: F401
 from .binding import Context, DrmltError, Node, build_native, comm_unique_id, library_path  # noqa: F401

@@ -9,7 +9,7 @@ BSDF_DIFFUSE, BSDF_DIELECTRIC, BSDF_ROUGHCONDUCTOR, BSDF_CONDUCTOR = 0, 1, 2, 3
 EMITTER_AREA = 0
 FILTER_BOX, FILTER_GAUSSIAN = 0, 1
 
-ABI_VERSION = 2  # include/drmlt_abi.h: DRMLT_ABI_VERSION
+ABI_VERSION = 3  # include/drmlt_abi.h: DRMLT_ABI_VERSION
 OK, E_INVALID, E_DEVICE, E_STATE, E_ZERO_LUM, E_REPLAY, E_CANCELLED = 0, -1, -2, -3, -4, -5, -6
 
 TYPE_NAMES = {"green": TYPE_GREEN, "mira": TYPE_MIRA, "orbital": TYPE_ORBITAL, "mirasym": TYPE_ORBITAL}

@@ -28,7 +28,7 @@ ABI_SYMBOLS = (
     "drmlt_seed_pool", "drmlt_comm_unique_id", "drmlt_comm_init", "drmlt_exchange_tiled",
     "drmlt_node_create", "drmlt_node_seed", "drmlt_node_run", "drmlt_node_develop", "drmlt_node_stats_get",
     "drmlt_node_set_importance_map", "drmlt_node_device_count", "drmlt_node_context", "drmlt_node_last_error",
-    "drmlt_node_destroy", "drmlt_bootstrap_luminances", "drmlt_seed_indices",
+    "drmlt_node_destroy", "drmlt_bootstrap_luminances", "drmlt_seed_indices", "drmlt_comm_info", "drmlt_film_tile",
 )
 
 
@@ -102,6 +102,8 @@ def load_library():
     L.drmlt_node_destroy.argtypes = [C.c_void_p]
     L.drmlt_bootstrap_luminances.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_void_p]
     L.drmlt_seed_indices.argtypes = [C.c_void_p, C.c_void_p]
+    L.drmlt_comm_info.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.drmlt_film_tile.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
     _lib = L
     return L
 
@@ -176,6 +178,22 @@ class Context:
                                               C.byref(lo), C.byref(hi)))
         tile = buf[:hi.value - lo.value] if want_tile else None
         return tile, (lo.value, hi.value), bb.value
+
+    def comm_info(self):
+        """(ranks, rank) as the communicator itself reports them (ncclCommCount / ncclCommUserRank)."""
+        n, r = C.c_int(), C.c_int()
+        self._chk(self.L.drmlt_comm_info(self.h, C.byref(n), C.byref(r)))
+        return n.value, r.value
+
+    @staticmethod
+    def comm_info_of(node, rank):
+        """comm_info of rank `rank` of a Node (borrowed context)."""
+        n, r = C.c_int(), C.c_int()
+        h = node.L.drmlt_node_context(node.h, rank)
+        rc = node.L.drmlt_comm_info(h, C.byref(n), C.byref(r))
+        if rc != 0:
+            raise DrmltError(rc, node.L.drmlt_last_error(h).decode())
+        return n.value, r.value
 
     def run(self, total_mutations, stop=None, progress=None):
         cb = abi.PROGRESS_CB(lambda d, t, u: progress(d, t)) if progress else None
@@ -317,6 +335,16 @@ def render_two_stage(cfg, scene_data, seed, size_reduction=16, device=0):
     b = ctx.seed(seed)
     ctx.run(cam.width * cam.height * cfg.sample_count)
     return ctx.develop(), lum, b
+
+
+def film_tile(height, rank, world):
+    """(row_lo, row_hi, rows_per_rank) of the tiled exchange: the library's own arithmetic (csrc/film_tiles.h), no device."""
+    L = load_library()
+    lo, hi, rows = C.c_int(), C.c_int(), C.c_int()
+    rc = L.drmlt_film_tile(height, rank, world, C.byref(lo), C.byref(hi), C.byref(rows))
+    if rc != 0:
+        raise DrmltError(rc, "no valid partition of %d rows over %d ranks (rank %d)" % (height, world, rank))
+    return lo.value, hi.value, rows.value
 
 
 def comm_unique_id():

@@ -108,7 +108,8 @@ DEV void eval_bdpt(const DParams &P, const TablesT &T, MSampler &smp, uint32_t c
     const BdptStore W{P.bd_verts, n, chain, NVS};
     auto mis = [&](int group, int slot) -> float & { return lds_x[(mis_row + (uint32_t) group * NVS + (uint32_t) slot) * 64u + lane]; };
     auto lrow = [&](int r) -> float & { return list[(size_t) r * n]; };
-    unsigned long long flagbits = 0ull; // two bits per vertex slot: BF_CONN, BF_DEGEN
+    static_assert(2 * (2 * BDPT_MAX_DEPTH + 1) <= 64, "two flag bits per vertex slot in one 64-bit register");
+    unsigned long long flagbits = 0ull; // two bits per vertex slot: BF_CONN, BF_DEGEN (drmlt_create refuses maxDepth > BDPT_MAX_DEPTH)
     auto set_flags = [&](int slot, unsigned v) { flagbits = (flagbits & ~(3ull << (2 * slot))) | ((unsigned long long) v << (2 * slot)); };
     auto flags = [&](int slot) -> unsigned { return (unsigned) (flagbits >> (2 * slot)) & 3u; };
 

@@ -319,7 +319,8 @@ drmlt_ctx *drmlt_create(const drmlt_config *cfg, const drmlt_scene *scene, int d
     if (cfg->scale_second > 1.0f) return bail(nullptr, "scaleSecond is bigger than the first stage");
     const bool mmlt = cfg->technique == DRMLT_TECH_MMLT, bdpt = cfg->technique == DRMLT_TECH_BDPT;
     if (bdpt && cfg->timid_after_large) return bail(nullptr, "timidAfterLarge is not supported for technique=bdpt");
-    if (bdpt && cfg->max_depth > 16) return bail(nullptr, "technique=bdpt: maxDepth above 16 is not supported on the device");
+    // device_bdpt.h keeps two flag bits per stored vertex in ONE 64-bit register: 2 maxDepth + 1 slots fit up to maxDepth 15
+    if (bdpt && cfg->max_depth > BDPT_MAX_DEPTH) return bail(nullptr, "technique=bdpt: maxDepth above 15 is not supported on the device");
     if (cfg->max_depth <= 0) return bail(nullptr, "technique=path needs a finite maxDepth (pssmlt_utils.h:63)");
     if (mmlt && cfg->max_depth > 24) return bail(nullptr, "technique=mmlt: maxDepth above 24 is not supported on the device");
     // a rejected large step re-draws the strategy; its second stage would read an emitter state that may be
@@ -485,7 +486,7 @@ drmlt_ctx *drmlt_create(const drmlt_config *cfg, const drmlt_scene *scene, int d
     }
 
     ctx->film_floats = (size_t) cam.width * cam.height * 3;
-    const size_t film_bytes = ((size_t) cam.height + FILM_PAD_ROWS) * cam.width * 3 * sizeof(float); // zero rows behind the film: see FILM_PAD_ROWS
+    const size_t film_bytes = film_alloc_floats(cam.width, cam.height) * sizeof(float); // zero rows behind the film: film_tiles.h
     ok = ctx->d_film.alloc(film_bytes) == hipSuccess && ctx->d_x.alloc((size_t) P.eff_dim * ctx->n_chains * sizeof(float)) == hipSuccess &&
          ctx->d_cur.alloc((size_t) 6 * ctx->n_chains * sizeof(float)) == hipSuccess && ctx->d_stats.alloc(32 * sizeof(unsigned long long)) == hipSuccess &&
          ctx->d_err.alloc(64) == hipSuccess && ctx->d_chain_i.alloc((size_t) 2 * ctx->n_chains * sizeof(int32_t)) == hipSuccess;
@@ -519,7 +520,7 @@ drmlt_ctx *drmlt_create(const drmlt_config *cfg, const drmlt_scene *scene, int d
     P.debug = 0;
     if (const char *d = getenv("DRMLT_DEBUG")) P.debug = atoi(d);
     P.kernel_variant = 4;
-    if (const char *k = getenv("DRMLT_KERNEL")) { int kv = atoi(k); P.kernel_variant = (kv >= 1 && kv <= 4) ? kv : 2; }
+    if (const char *k = getenv("DRMLT_KERNEL")) { int kv = atoi(k); P.kernel_variant = kv == 3 ? 3 : 4; }
     P.features = 0;
     for (const DBsdf &b : bsdfs) P.features |= b.type == DRMLT_BSDF_ROUGHCONDUCTOR ? 1 : (b.type == DRMLT_BSDF_DIELECTRIC ? 2 : 0);
     for (const DPrim &g : ctx->prims) if (g.type == PRIM_SPHERE) P.features |= 4;

@@ -3,6 +3,7 @@
 #pragma once
 #include "../../include/drmlt_abi.h"
 #include "device_types.h"
+#include "film_tiles.h" // FILM_PAD_ROWS, film_tile(): the row partition of the tiled exchange
 
 #include <hip/hip_runtime.h>
 
@@ -90,7 +91,6 @@ struct drmlt_ctx {
     }
 };
 
-#define FILM_PAD_ROWS 16 // reduce-scatter wants equal counts per rank: ceil(H / N) * N <= H + N - 1 rows, N <= 16
 
 #define HIP_TRY(ctx, expr)                                                                         \
     do {                                                                                           \

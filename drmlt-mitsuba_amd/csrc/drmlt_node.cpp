@@ -15,6 +15,7 @@
 // RCCL is loaded at run time (dlopen) the first time a communicator is needed: a single-GPU host without RCCL can
 // still use the library.
 #include "drmlt_ctx.h"
+#include "film_tiles.h"
 
 #include <dlfcn.h>
 #include <rccl/rccl.h>
@@ -37,6 +38,9 @@ struct RcclApi {
     ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommInitAll)(ncclComm_t *, int, const int *) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int *) = nullptr;
+    ncclResult_t (*CommUserRank)(const ncclComm_t, int *) = nullptr;
     ncclResult_t (*ReduceScatter)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
@@ -48,13 +52,19 @@ const RcclApi *rccl(std::string &err) {
     static std::string load_error;
     static std::once_flag once;
     std::call_once(once, [] {
-        const char *names[] = {getenv("DRMLT_RCCL_LIB"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
-        for (const char *n : names) {
-            if (!n || !*n) continue;
-            api.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL);
-            if (api.lib) break;
+        const char *forced = getenv("DRMLT_RCCL_LIB"); // an explicit choice is final: no fall-back to the system's library
+        const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        if (forced && *forced) api.lib = dlopen(forced, RTLD_NOW | RTLD_LOCAL);
+        else
+            for (const char *n : names) {
+                api.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+                if (api.lib) break;
+            }
+        if (!api.lib) {
+            const char *why = dlerror(); // ONE call: dlerror() hands the message out once and then returns NULL
+            load_error = std::string("RCCL is not available: ") + (why ? why : "librccl.so.1 not found");
+            return;
         }
-        if (!api.lib) { load_error = std::string("RCCL is not available: ") + (dlerror() ? dlerror() : "librccl.so.1 not found"); return; }
         auto sym = [&](const char *name) -> void * {
             void *p = dlsym(api.lib, name);
             if (!p && load_error.empty()) load_error = std::string("RCCL lacks the symbol ") + name;
@@ -64,6 +74,9 @@ const RcclApi *rccl(std::string &err) {
         api.CommInitRank = reinterpret_cast<decltype(api.CommInitRank)>(sym("ncclCommInitRank"));
         api.CommInitAll = reinterpret_cast<decltype(api.CommInitAll)>(sym("ncclCommInitAll"));
         api.CommDestroy = reinterpret_cast<decltype(api.CommDestroy)>(sym("ncclCommDestroy"));
+        api.CommAbort = reinterpret_cast<decltype(api.CommAbort)>(sym("ncclCommAbort"));
+        api.CommCount = reinterpret_cast<decltype(api.CommCount)>(sym("ncclCommCount"));
+        api.CommUserRank = reinterpret_cast<decltype(api.CommUserRank)>(sym("ncclCommUserRank"));
         api.ReduceScatter = reinterpret_cast<decltype(api.ReduceScatter)>(sym("ncclReduceScatter"));
         api.AllReduce = reinterpret_cast<decltype(api.AllReduce)>(sym("ncclAllReduce"));
         api.GetErrorString = reinterpret_cast<decltype(api.GetErrorString)>(sym("ncclGetErrorString"));
@@ -102,8 +115,9 @@ int comm_attach(drmlt_ctx *ctx, ncclComm_t comm, int rank, int world) {
     if (ctx->comm) { drmlt_comm_release(ctx->comm); ctx->comm = nullptr; }
     std::unique_ptr<drmlt_comm> c(new drmlt_comm());
     c->comm = comm; c->rank = rank; c->world = world;
-    c->tile_rows = (ctx->P.height + world - 1) / world;
-    if (c->tile_rows * world > ctx->P.height + FILM_PAD_ROWS) return ctx->fail(DRMLT_E_INVALID, "world size %d is too large for the film's row padding", world);
+    FilmTile ft;
+    if (!film_tile(ctx->P.height, rank, world, ft)) return ctx->fail(DRMLT_E_INVALID, "world size %d is too large for the film's row padding", world);
+    c->tile_rows = ft.rows_per_rank;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const size_t n = (size_t) c->tile_rows * ctx->P.width * 3;
     HIP_TRY(ctx, c->tile.alloc(n * sizeof(float)));
@@ -115,9 +129,9 @@ int comm_attach(drmlt_ctx *ctx, ncclComm_t comm, int rank, int world) {
 
 // rows [lo, hi) of the film that rank `rank` of `world` owns after the reduce-scatter (hi clipped to the film)
 void tile_range(const drmlt_ctx *ctx, int rank, int world, int &lo, int &hi) {
-    const int rows = (ctx->P.height + world - 1) / world;
-    lo = std::min(rank * rows, ctx->P.height);
-    hi = std::min(lo + rows, ctx->P.height);
+    FilmTile ft{0, 0, 0};
+    (void) film_tile(ctx->P.height, rank, world, ft); // validated when the communicator was attached
+    lo = ft.lo; hi = ft.hi;
 }
 
 // Steps 2-5 of the exchange, once the summed tile sits in comm->tile: tile luminance, scalar all-reduce, develop.
@@ -189,6 +203,35 @@ int drmlt_comm_init(drmlt_ctx *ctx, const char id[DRMLT_COMM_ID_BYTES], int rank
     return rc;
 }
 
+// Pure arithmetic (no device, no context): the rows of an H-row film that `rank` of `world` owns after the exchange and
+// the per-rank row count of the reduce-scatter -- film_tiles.h, the copy every path of the library uses.
+int drmlt_film_tile(int height, int rank, int world, int *row_lo, int *row_hi, int *rows_per_rank) {
+    FilmTile ft;
+    if (!film_tile(height, rank, world, ft)) return DRMLT_E_INVALID;
+    if (row_lo) *row_lo = ft.lo;
+    if (row_hi) *row_hi = ft.hi;
+    if (rows_per_rank) *rows_per_rank = ft.rows_per_rank;
+    return DRMLT_OK;
+}
+
+// What the communicator itself says (ncclCommCount / ncclCommUserRank), not what the caller asked for: bench.py prints it
+// and fails when it differs from --gpus.
+int drmlt_comm_info(drmlt_ctx *ctx, int *nranks, int *rank) {
+    if (!ctx) return DRMLT_E_INVALID;
+    if (!ctx->comm) return ctx->fail(DRMLT_E_STATE, "drmlt_comm_info needs a communicator (drmlt_comm_init / drmlt_node_create)");
+    int n = ctx->comm->world, r = ctx->comm->rank; // loopback transport: the node's own bookkeeping
+    if (ctx->comm->comm) {
+        std::string err;
+        const RcclApi *R = rccl(err);
+        if (!R) return ctx->fail(DRMLT_E_DEVICE, "%s", err.c_str());
+        NCCL_TRY(ctx, R, R->CommCount(ctx->comm->comm, &n));
+        NCCL_TRY(ctx, R, R->CommUserRank(ctx->comm->comm, &r));
+    }
+    if (nranks) *nranks = n;
+    if (rank) *rank = r;
+    return DRMLT_OK;
+}
+
 int drmlt_exchange_tiled(drmlt_ctx *ctx, double *b_inout, float *tile_host_or_null, int *row_lo, int *row_hi) {
     if (!ctx) return DRMLT_E_INVALID;
     if (!ctx->comm || !ctx->comm->comm) return ctx->fail(DRMLT_E_STATE, "drmlt_exchange_tiled needs drmlt_comm_init first");
@@ -250,8 +293,22 @@ drmlt_node *drmlt_node_create(const drmlt_config *cfg, const drmlt_scene *scene,
         return nullptr;
     };
     std::vector<int> devs;
-    if (const char *e = getenv("DRMLT_NODE_DEVICES")) { // explicit list, may repeat a device ("0,0": two ranks on one GPU, loopback transport)
-        for (const char *p = e; *p;) { devs.push_back(atoi(p)); while (*p && *p != ',') ++p; if (*p) ++p; }
+    // Test hook, honoured only together with DRMLT_TEST_HOOKS=1 (a stale variable must not redirect a production render):
+    // an explicit rank -> device list that may repeat a device ("0,0": two ranks on one GPU, loopback transport).
+    const char *hook = getenv("DRMLT_NODE_DEVICES");
+    const char *hooks_on = getenv("DRMLT_TEST_HOOKS");
+    if (hook && *hook && hooks_on && atoi(hooks_on) == 1) {
+        int n_dev = 0;
+        if (hipGetDeviceCount(&n_dev) != hipSuccess) n_dev = 0;
+        for (const char *p = hook; *p;) {
+            char *end = nullptr;
+            const long d = strtol(p, &end, 10);
+            if (end == p || (*end && *end != ',') || d < 0 || d >= n_dev)
+                return bail(nullptr, std::string("DRMLT_NODE_DEVICES: bad entry in \"") + hook + "\" (" + std::to_string(n_dev) + " devices visible)");
+            devs.push_back((int) d);
+            p = *end ? end + 1 : end;
+        }
+        fprintf(stderr, "[drmlt] test hook: DRMLT_NODE_DEVICES=%s overrides device mask 0x%x\n", hook, device_mask);
     } else {
         for (int d = 0; d < 32; ++d) if (device_mask & (1u << d)) devs.push_back(d);
     }
@@ -371,17 +428,43 @@ int drmlt_node_develop(drmlt_node *node, const float *direct_rgb_or_null, float 
         }
         return DRMLT_OK;
     }
-    // RCCL: one host thread per device, each issues its rank's reduce-scatter + all-reduce and develops its tile
+    // RCCL: one host thread per device, each issues its rank's reduce-scatter + all-reduce and develops its tile. A rank
+    // that fails BEFORE its collective is enqueued would leave the others waiting in it for ever, so (1) everything that can
+    // fail without RCCL is checked on all ranks first, (2) a rank whose enqueue fails aborts every communicator of the
+    // node (ncclCommAbort releases the peers' pending operations); the node cannot exchange films after that.
+    for (int r = 0; r < n; ++r) {
+        drmlt_ctx *c = node->subs[r];
+        if (!c->comm || !c->comm->comm) return node->fail(DRMLT_E_STATE, "the node's communicators are gone (an earlier exchange failed)");
+        if (hipSetDevice(c->device) != hipSuccess) return node->fail(DRMLT_E_DEVICE, "device " + std::to_string(c->device) + ": hipSetDevice failed");
+        if (hipStreamQuery(c->stream) == hipErrorInvalidResourceHandle) return node->fail(DRMLT_E_DEVICE, "device " + std::to_string(c->device) + ": stream is gone");
+    }
+    std::mutex abort_mutex;
+    bool aborted = false;
+    auto abort_all = [&]() {
+        std::lock_guard<std::mutex> g(abort_mutex);
+        if (aborted) return;
+        aborted = true;
+        for (drmlt_ctx *c : node->subs)
+            if (c->comm && c->comm->comm) { (void) R->CommAbort(c->comm->comm); c->comm->comm = nullptr; }
+    };
     return for_each_rank(node, [&](int r) {
         drmlt_ctx *c = node->subs[r];
-        if (hipSetDevice(c->device) != hipSuccess) return c->fail(DRMLT_E_DEVICE, "hipSetDevice failed");
+        int rc = DRMLT_OK;
+        if (hipSetDevice(c->device) != hipSuccess) rc = c->fail(DRMLT_E_DEVICE, "hipSetDevice failed");
         const size_t count = (size_t) c->comm->tile_rows * W * 3;
-        NCCL_TRY(c, R, R->ReduceScatter(c->d_film.p, c->comm->tile.p, count, ncclFloat, ncclSum, c->comm->comm, c->stream));
-        int lo, hi;
-        tile_range(c, r, n, lo, hi);
-        const size_t off = (size_t) lo * W * 3;
-        double b = node->b;
-        return finish_tile(c, R, &b, direct_rgb_or_null ? direct_rgb_or_null + off : nullptr, out_rgb + off);
+        if (rc == DRMLT_OK) {
+            const ncclResult_t nr = R->ReduceScatter(c->d_film.p, c->comm->tile.p, count, ncclFloat, ncclSum, c->comm->comm, c->stream);
+            if (nr != ncclSuccess) rc = c->fail(DRMLT_E_DEVICE, "ncclReduceScatter: %s", R->GetErrorString(nr));
+        }
+        if (rc == DRMLT_OK) {
+            int lo, hi;
+            tile_range(c, r, n, lo, hi);
+            const size_t off = (size_t) lo * W * 3;
+            double b = node->b;
+            rc = finish_tile(c, R, &b, direct_rgb_or_null ? direct_rgb_or_null + off : nullptr, out_rgb + off);
+        }
+        if (rc != DRMLT_OK) abort_all();
+        return rc;
     });
 }
 

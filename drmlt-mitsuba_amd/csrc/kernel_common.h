@@ -1,6 +1,8 @@
-// Helpers shared by the chain kernels of both techniques (kernels.hip, kernels_mmlt.hip).
+// Helpers shared by the chain kernels of all techniques (kernels.hip, kernels_mmlt.hip, kernels_bdpt.hip): film splats,
+// splat normalisation, wave reductions. The decision logic they share is device_mh.h.
 #pragma once
 #include "device_path.h"
+#include "device_mh.h"
 
 #define CHAIN_BLOCK 64 // one wave per workgroup: no barriers anywhere on the chain path
 
@@ -62,15 +64,14 @@ DEV unsigned long long wave_sum(uint32_t v) {
     return s;
 }
 
-DEV bool lum_invalid(float x) { return isnan(x) || isinf(x) || x <= 0.f; }        // drmlt_proc.cpp:428
-DEV bool lum_invalid_mix(float x) { return isnan(x) || isinf(x) || x < 0.f; }     // drmlt_proc.cpp:181
-
-// Per-lane event counters of one launch, packed 2 x 16 bit (launch length is capped at 32768).
-struct Counters {
-    uint32_t large_acc1l; // lo: large steps                hi: accepted first stage after large
-    uint32_t acc1b_secl;  // lo: accepted first stage, bold  hi: second stages after large
-    uint32_t secb_acc2l;  // lo: second stages after bold    hi: accepted second stage after large
-    uint32_t acc2b_rev;   // lo: accepted second, bold       hi: Green reverse evaluations
-    uint32_t rays;
-};
-
+// wave-reduce the event counters of a launch, one atomic per counter per wave (layout of DParams::stats)
+DEV void flush_counters(const DParams &P, const Counters &ct, uint32_t lane) {
+    unsigned long long v[9];
+    v[0] = wave_sum(ct.large_acc1l & 0xffffu); v[1] = wave_sum(ct.large_acc1l >> 16);
+    v[2] = wave_sum(ct.acc1b_secl & 0xffffu);  v[3] = wave_sum(ct.acc1b_secl >> 16);
+    v[4] = wave_sum(ct.secb_acc2l & 0xffffu);  v[5] = wave_sum(ct.secb_acc2l >> 16);
+    v[6] = wave_sum(ct.acc2b_rev & 0xffffu);   v[7] = wave_sum(ct.acc2b_rev >> 16);
+    v[8] = wave_sum(ct.rays);
+    if (lane == 0)
+        for (int i = 0; i < 9; ++i) if (v[i]) atomicAdd(P.stats + i, v[i]);
+}

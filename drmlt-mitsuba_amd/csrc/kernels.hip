@@ -2,7 +2,8 @@
 //
 //   k_bootstrap     luminance samples of PathSampler::generateSeeds (pathsampler.cpp:879-920)
 //   k_init_chains   seed replay + fillReplay + luminance sanity check (drmlt_proc.cpp:467-514)
-//   k_mutate        DRMLTRenderer::process / processMixture chain loop (drmlt_proc.cpp:161-380,518-770)
+//   k_mutate_v4     DRMLTRenderer::process / processMixture chain loop (drmlt_proc.cpp:161-380,518-770); k_mutate_v3 = its
+//                   predecessor, kept as the bit-equality cross-check; k_mutate_pssmlt = PSSMLTRenderer::process
 //   k_eval_paths    PathSampler::sampleSplats on caller-supplied PSS points (pathsampler.cpp:529-567)
 //   k_render_pt     independent samples of the same integrand (validation image)
 //   k_lum_sum / k_develop   DRMLTProcess::develop (drmlt_proc.cpp:824-849)
@@ -49,161 +50,6 @@ __global__ void __launch_bounds__(64) k_init_chains(DParams P, const uint32_t *s
     // replayed components + fillReplay top-up: dimension k of bootstrap sample i is U(BOOT, i, k)
     smp.reset_caches();
     for (uint32_t k = 0; k < (uint32_t) P.eff_dim; ++k) P.x[(size_t) k * P.n_chains + c] = smp.u_boot(k, TAG_BOOT);
-}
-
-__global__ void __launch_bounds__(CHAIN_BLOCK) k_mutate(DParams P, uint32_t n_mut, uint32_t mut_base) {
-    const uint32_t lane = threadIdx.x;
-    const uint32_t c = blockIdx.x * CHAIN_BLOCK + lane;
-    const bool live = c < P.n_chains;
-    const uint32_t cc = live ? c : P.n_chains - 1;
-    const int D = P.eff_dim;
-    for (int k = 0; k < D; ++k) lds_x[k * 64 + lane] = P.x[(size_t) k * P.n_chains + cc];
-
-    DSplat cur;
-    cur.lum = P.cur_lum[cc]; cur.px = P.cur_px[cc]; cur.py = P.cur_py[cc];
-    cur.r = P.cur_r[cc]; cur.g = P.cur_g[cc]; cur.b = P.cur_b[cc];
-
-    Sampler smp;
-    smp.key0 = P.key0; smp.key1 = P.key1; smp.chain = P.chain_offset + cc;
-    smp.type = P.type; smp.sigma2 = P.sigma2; smp.lane = lane; smp.arr = nullptr;
-    Counters ct = {0u, 0u, 0u, 0u, 0u};
-    const bool amap = P.acceptance_map != 0;
-
-    if (live && !(P.debug & 8)) for (uint32_t it = 0; it < n_mut; ++it) {
-        const uint32_t m = mut_base + it;
-        const u4 coins = philox4x32_10(P.key0, P.key1, 0u, m, smp.chain, TAG_COIN);
-        const bool large = u32_to_unit(coins.x) < P.p_large;
-        smp.major = m;
-        smp.large = large;
-        uint32_t nd1 = 0, nd2 = 0;
-        DSplat y, z;
-        y.lum = 0.f; y.px = y.py = y.r = y.g = y.b = 0.f;
-        z = y;
-        float a1 = 0.f, a2 = 0.f;
-        bool acc1 = false, acc2 = false, doSecond = false;
-        const bool mix = P.use_mixture != 0;
-
-        // Stage loop with ONE path-evaluation site: 0 = first stage, 1 = second stage,
-        // 2 = Green's reverse move. Lanes leave the loop as soon as their mutation is decided.
-#pragma nounroll
-        for (int stage = 0; stage < 3; ++stage) {
-            smp.mode = stage == 0 ? SM_STAGE1 : (stage == 1 ? SM_STAGE2 : SM_REVERSE);
-            uint32_t nr, nd;
-            DSplat res = eval_path(P, smp, nr, nd);
-            ct.rays += nr;
-            normalize_splat(res, P);
-            if (stage == 0) {
-                y = res; nd1 = nd;
-                if (!(mix ? lum_invalid_mix(y.lum) : lum_invalid(y.lum))) { // Eq. 5, drmlt_proc.cpp:544-550 / :285-293
-                    a1 = fminf(1.f, y.lum / cur.lum);
-                    acc1 = a1 >= 1.f || u32_to_unit(coins.y) < a1;
-                }
-                if (!mix) doSecond = !acc1 && (P.timid_after_large || !large);   // :553-558
-                else doSecond = !large && u32_to_unit(coins.w) < 0.5f;           // :296-299
-                if (!doSecond) break;
-            } else if (stage == 1) {
-                z = res; nd2 = nd;
-                if (mix) { // processMixture: the second-stage proposal replaces the first (:313-324)
-                    acc1 = false;
-                    a1 = 0.f;
-                    if (!lum_invalid_mix(z.lum)) {
-                        a2 = fminf(1.f, z.lum / cur.lum);
-                        acc2 = a2 >= 1.f || u32_to_unit(coins.z) < a2;
-                    }
-                    break;
-                }
-                if (lum_invalid(z.lum)) break;
-                if (P.type == 0) continue; // Green & Mira (2001): needs the reverse path y* = z - (y - x)
-                if (P.type == 1) { // Tierney & Mira (1999), drmlt_proc.cpp:625-650
-                    float aRev = fminf(1.f, y.lum / z.lum);
-                    if (!(aRev >= 1.f)) {
-                        float ratio = 1.f;
-                        if (!large) { // Q1(y|z) / Q1(y|x) over the used dimensions (drmlt_sampler.cpp:400-414)
-                            uint32_t dimStage = max(nd1, nd2) - 1u;
-                            float num = 0.f, den = 0.f;
-                            for (uint32_t i = 0; i < dimStage; ++i) {
-                                float yi = smp.y_raw(i);
-                                num += kelemen_logpdf(smp.z_raw(i) - yi);
-                                den += kelemen_logpdf(smp.x(i) - yi);
-                            }
-                            ratio = __expf(num - den);
-                        }
-                        if (!lum_invalid(ratio)) {
-                            a2 = fminf(1.f, (z.lum / cur.lum) * ratio * (1.f - aRev) / (1.f - a1));
-                            acc2 = a2 >= 1.f || u32_to_unit(coins.z) < a2;
-                        }
-                    }
-                } else { // pairwise orbital, DRMLT Eq. 11 (drmlt_proc.cpp:655-669)
-                    if (z.lum < y.lum) { a2 = 0.f; }
-                    else if (z.lum >= cur.lum) { a2 = 1.f; acc2 = true; }
-                    else {
-                        a2 = (z.lum - y.lum) / (cur.lum - y.lum);
-                        acc2 = a2 >= 1.f || u32_to_unit(coins.z) < a2;
-                    }
-                }
-                break;
-            } else { // Green's second-stage acceptance, Eq. 13-14 (drmlt_proc.cpp:599-615)
-                ct.acc2b_rev += 1u << 16;
-                float aRev = lum_invalid(res.lum) ? 0.f : fminf(1.f, res.lum / z.lum);
-                if (aRev != 1.f) {
-                    a2 = fminf(1.f, (z.lum / cur.lum) * (1.f - aRev) / (1.f - a1));
-                    acc2 = a2 >= 1.f || u32_to_unit(coins.z) < a2;
-                }
-            }
-        }
-
-        if (!mix) {
-            // expectation weights, drmlt_proc.cpp:677-688
-            float w1 = a1, w2 = (1.f - a1) * a2, w0 = 1.f - w1 - w2;
-            if (!amap) {
-                if (w0 > 0.f) film_put(P, cur.px, cur.py, mk3(cur.r * w0, cur.g * w0, cur.b * w0));
-                if (w1 > 0.f) film_put(P, y.px, y.py, mk3(y.r * w1, y.g * w1, y.b * w1));
-                if (doSecond && w2 > 0.f) film_put(P, z.px, z.py, mk3(z.r * w2, z.g * w2, z.b * w2));
-            }
-        } else {
-            // processMixture splats, drmlt_proc.cpp:327-333: a = acceptance of whichever proposal was tested
-            const float a = doSecond ? a2 : a1;
-            const DSplat &pr = doSecond ? z : y;
-            if (1.f - a > 0.f) film_put(P, cur.px, cur.py, mk3(cur.r * (1.f - a), cur.g * (1.f - a), cur.b * (1.f - a)));
-            if (a > 0.f) film_put(P, pr.px, pr.py, mk3(pr.r * a, pr.g * a, pr.b * a));
-        }
-
-        // bookkeeping (event counts; the 7 ratios are assembled on the host)
-        if (large) {
-            ct.large_acc1l += 1u + (acc1 ? 1u << 16 : 0u);
-            if (doSecond) ct.acc1b_secl += 1u << 16;
-            if (acc2) ct.secb_acc2l += 1u << 16;
-        } else {
-            if (acc1) ct.acc1b_secl += 1u;
-            if (doSecond) ct.secb_acc2l += 1u;
-            if (acc2) ct.acc2b_rev += 1u;
-        }
-
-        if (acc1 || acc2) {
-            // DRMLTSampler::accept: uCurrent = wrap(chosen proposal), every kept dimension
-            if (acc1) { for (int k = 0; k < D; ++k) lds_x[k * 64 + lane] = wrap01(smp.y_raw((uint32_t) k)); cur = y; }
-            else { for (int k = 0; k < D; ++k) lds_x[k * 64 + lane] = wrap01(smp.z_raw((uint32_t) k)); cur = z; }
-            if (amap) { // drmlt_proc.cpp:697-709
-                if (acc1) { if (!large && !P.use_mixture) film_put(P, cur.px, cur.py, mk3(1.f, 0.f, 0.f)); }
-                else if (!P.use_mixture) film_put(P, cur.px, cur.py, mk3(0.f, 1.f, 0.f));
-            }
-        }
-    }
-
-    if (live && !(P.debug & 4)) {
-        for (int k = 0; k < D; ++k) P.x[(size_t) k * P.n_chains + c] = lds_x[k * 64 + lane];
-        P.cur_lum[c] = cur.lum; P.cur_px[c] = cur.px; P.cur_py[c] = cur.py;
-        P.cur_r[c] = cur.r; P.cur_g[c] = cur.g; P.cur_b[c] = cur.b;
-    }
-    // wave-reduce the event counters, one atomic per counter per wave
-    unsigned long long v[9];
-    v[0] = wave_sum(ct.large_acc1l & 0xffffu); v[1] = wave_sum(ct.large_acc1l >> 16);
-    v[2] = wave_sum(ct.acc1b_secl & 0xffffu);  v[3] = wave_sum(ct.acc1b_secl >> 16);
-    v[4] = wave_sum(ct.secb_acc2l & 0xffffu);  v[5] = wave_sum(ct.secb_acc2l >> 16);
-    v[6] = wave_sum(ct.acc2b_rev & 0xffffu);   v[7] = wave_sum(ct.acc2b_rev >> 16);
-    v[8] = wave_sum(ct.rays);
-    if (lane == 0 && !(P.debug & 2))
-        for (int i = 0; i < 9; ++i) atomicAdd(P.stats + i, v[i]);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -256,8 +102,7 @@ __global__ void __launch_bounds__(CHAIN_BLOCK) k_mutate_pssmlt(DParams P, uint32
             wc = P.kelemen_weights ? cur.lum / (cur.lum / b + pLarge) : 1.f;
         }
         cumulative += wc;
-        if (large) ct.large_acc1l += 1u + (accept ? 1u << 16 : 0u);
-        else if (accept) ct.acc1b_secl += 1u;
+        mh_count(ct, large, accept, false, false);
         // the whole vector was rewritten by the proposal; components that did not exist yet stay even on rejection
         const uint32_t n_exist = smp.n_exist;
         if (accept) {
@@ -277,25 +122,10 @@ __global__ void __launch_bounds__(CHAIN_BLOCK) k_mutate_pssmlt(DParams P, uint32
         P.cur_lum[c] = cur.lum; P.cur_px[c] = cur.px; P.cur_py[c] = cur.py;
         P.cur_r[c] = cur.r; P.cur_g[c] = cur.g; P.cur_b[c] = cur.b;
     }
-    unsigned long long v[9];
-    v[0] = wave_sum(ct.large_acc1l & 0xffffu); v[1] = wave_sum(ct.large_acc1l >> 16);
-    v[2] = wave_sum(ct.acc1b_secl & 0xffffu);  v[3] = 0; v[4] = 0; v[5] = 0; v[6] = 0; v[7] = 0;
-    v[8] = wave_sum(ct.rays);
-    if (lane == 0)
-        for (int i = 0; i < 9; ++i) if (v[i]) atomicAdd(P.stats + i, v[i]);
+    flush_counters(P, ct, lane);
 }
 
 // ------------------------------------------------------------------------------------------
-// k_mutate_v2: the same chain loop as k_mutate, restructured for the wave.
-//
-// k_mutate nests "for every stage: run the path to completion": a wave then runs as long as its
-// longest path, and the second stage (needed by a few lanes only) costs the whole wave a second
-// full evaluation -- measured VALU lane utilisation 22 %. Here every lane is an independent
-// state machine and one loop iteration is ONE ray step for all lanes, whatever path, stage or
-// mutation each of them is in. Lanes whose path has finished park until at least
-// `P.mh_batch` of them can take the Metropolis-Hastings bookkeeping branch together (the branch
-// is divergent, so its cost is amortised over the lanes that share it). Per lane the arithmetic
-// is identical to k_mutate: both kernels produce the same chains.
 struct ChainState {
     DSplat cur, y, z;
     float a1, coin_acc1, coin_acc2, coin_mix;
@@ -304,34 +134,41 @@ struct ChainState {
     bool large, do_second;
 };
 
-struct MhStamps { unsigned long long digest, splat, commit, start; };
-
 // The bookkeeping branch in four pieces so that k_mutate_v3 can share the two heavy ones
 // (committing D_eff dimensions, drawing the next mutation's uniforms) between a chain lane and
 // its helper lane:
-//   mh_decide  digest the finished evaluation; if the mutation is decided: splats + counters,
+//   mh_decide  digest the finished evaluation; if the mutation is decided: weights + counters,
 //              returns the commit mode (0 none, SM_STAGE1 = adopt y, SM_STAGE2 = adopt z)
 //   commit     x[k] = wrap(proposal[k]) for a range of dimensions           (shareable)
 //   mh_start   advance to the next evaluation (next stage or next mutation); returns which
 //              uniforms must be drawn (0 none, 1 first stage, 2 second stage)
 //   fill       Philox draws into LDS for a range of blocks                    (shareable)
-// Outcome of one digested evaluation. `decided`: the mutation is over and w0 / w1 / w2 are the expectation weights of
-// the current state, the first-stage and the second-stage proposal (drmlt_proc.cpp:677-688, mixture :327-333);
-// `commit`: 0 none, SM_STAGE1 = adopt y, SM_STAGE2 = adopt z; `amap`: acceptance-map mark at the adopted state's pixel
-// (1 red = first stage, 2 green = second stage, drmlt_proc.cpp:697-709). The caller splats: k_mutate_v2/v3 at once,
-// k_mutate_v4 through its LDS queue.
+// Outcome of one digested evaluation. `decided`: the mutation is over and w = the expectation weights of the current
+// state, the first-stage and the second-stage proposal; `commit`: 0 none, SM_STAGE1 = adopt y, SM_STAGE2 = adopt z;
+// `amap`: acceptance-map mark (AMAP_*) for the pixel of the state that is being REPLACED (device_mh.h: mh_amap_mark).
+// The caller splats: k_mutate_v3 at once, k_mutate_v4 through its LDS queue.
 struct MhOutcome {
     bool decided;
     int commit, amap;
-    float w0, w1, w2;
+    MhWeights w;
 };
+
+// Tierney & Mira's transition ratio Q1(y|z) / Q1(y|x) over the dimensions either stage used (drmlt_sampler.cpp:400-414)
+template <class SamplerT> DEV float mira_ratio(SamplerT &smp, uint32_t nd1, uint32_t nd2) {
+    const uint32_t dimStage = max(nd1, nd2) - 1u;
+    float num = 0.f, den = 0.f;
+    for (uint32_t i = 0; i < dimStage; ++i) {
+        const float yi = smp.y_raw(i);
+        num += kelemen_logpdf(smp.z_raw(i) - yi);
+        den += kelemen_logpdf(smp.x(i) - yi);
+    }
+    return __expf(num - den);
+}
 
 template <class SamplerT> DEV MhOutcome mh_decide(const DParams &P, ChainState &cs, SamplerT &smp, PathState &ps, Counters &ct) {
     const bool mix = P.use_mixture != 0;
-    const bool amap = P.acceptance_map != 0;
-    MhOutcome out{false, 0, 0, 0.f, 0.f, 0.f};
+    MhOutcome out{false, 0, AMAP_NONE, {0.f, 0.f, 0.f}};
     if (cs.stage < 0) return out; // nothing evaluated yet (first call of a launch)
-    bool decided = false;
     float a2 = 0.f;
     bool acc1 = false, acc2 = false;
     DSplat res;
@@ -341,91 +178,38 @@ template <class SamplerT> DEV MhOutcome mh_decide(const DParams &P, ChainState &
     ct.rays += ps.nrays;
     if (cs.stage == 0) {
         cs.y = res; cs.nd1 = ps.k;
-        cs.a1 = 0.f;
-        if (!(mix ? lum_invalid_mix(res.lum) : lum_invalid(res.lum))) cs.a1 = fminf(1.f, res.lum / cs.cur.lum);
-        acc1 = cs.a1 >= 1.f || (cs.a1 > 0.f && cs.coin_acc1 < cs.a1);
-        if (!mix) cs.do_second = !acc1 && (P.timid_after_large || !cs.large);
-        else cs.do_second = !cs.large && cs.coin_mix < 0.5f;
+        mh_first(mix, P.timid_after_large != 0, cs.large, res.lum, cs.cur.lum, cs.coin_acc1, cs.coin_mix, cs.a1, acc1, cs.do_second);
         if (cs.do_second) { cs.stage = 1; return out; }
-        decided = true;
     } else if (cs.stage == 1) {
         cs.z = res; cs.nd2 = ps.k;
-        acc1 = false;
         if (mix) {
-            cs.a1 = 0.f;
-            if (!lum_invalid_mix(res.lum)) {
-                a2 = fminf(1.f, res.lum / cs.cur.lum);
-                acc2 = a2 >= 1.f || cs.coin_acc2 < a2;
-            }
+            cs.a1 = 0.f; // the second proposal replaces the first
+            mh_second_mixture(res.lum, cs.cur.lum, cs.coin_acc2, a2, acc2);
         } else if (!lum_invalid(res.lum)) {
             if (P.type == 0) { cs.stage = 2; return out; } // Green: evaluate the reverse move first
             if (P.type == 1) {
-                float aRev = fminf(1.f, cs.y.lum / res.lum);
-                if (!(aRev >= 1.f)) {
-                    float ratio = 1.f;
-                    if (!cs.large) {
-                        uint32_t dimStage = max(cs.nd1, cs.nd2) - 1u;
-                        float num = 0.f, den = 0.f;
-                        for (uint32_t i = 0; i < dimStage; ++i) {
-                            float yi = smp.y_raw(i);
-                            num += kelemen_logpdf(smp.z_raw(i) - yi);
-                            den += kelemen_logpdf(smp.x(i) - yi);
-                        }
-                        ratio = __expf(num - den);
-                    }
-                    if (!lum_invalid(ratio)) {
-                        a2 = fminf(1.f, (res.lum / cs.cur.lum) * ratio * (1.f - aRev) / (1.f - cs.a1));
-                        acc2 = a2 >= 1.f || cs.coin_acc2 < a2;
-                    }
-                }
+                float ratio = 1.f;
+                if (!cs.large && !(fminf(1.f, cs.y.lum / res.lum) >= 1.f)) ratio = mira_ratio(smp, cs.nd1, cs.nd2);
+                mh_second_mira(cs.y.lum, res.lum, cs.cur.lum, cs.a1, ratio, cs.coin_acc2, a2, acc2);
             } else {
-                if (res.lum < cs.y.lum) { a2 = 0.f; }
-                else if (res.lum >= cs.cur.lum) { a2 = 1.f; acc2 = true; }
-                else {
-                    a2 = (res.lum - cs.y.lum) / (cs.cur.lum - cs.y.lum);
-                    acc2 = a2 >= 1.f || cs.coin_acc2 < a2;
-                }
+                mh_second_orbital(cs.y.lum, res.lum, cs.cur.lum, cs.coin_acc2, a2, acc2);
             }
         }
-        decided = true;
     } else {
         ct.acc2b_rev += 1u << 16;
-        float aRev = lum_invalid(res.lum) ? 0.f : fminf(1.f, res.lum / cs.z.lum);
-        if (aRev != 1.f) {
-            a2 = fminf(1.f, (cs.z.lum / cs.cur.lum) * (1.f - aRev) / (1.f - cs.a1));
-            acc2 = a2 >= 1.f || cs.coin_acc2 < a2;
-        }
-        decided = true;
+        mh_second_green(res.lum, cs.z.lum, cs.cur.lum, cs.a1, cs.coin_acc2, a2, acc2);
     }
-    if (!decided) return out;
     out.decided = true;
-    if (!mix) { // expectation weights, drmlt_proc.cpp:677-688
-        out.w1 = cs.a1; out.w2 = (1.f - cs.a1) * a2; out.w0 = 1.f - out.w1 - out.w2;
-        if (!cs.do_second) out.w2 = 0.f;
-        if (amap) out.w0 = out.w1 = out.w2 = 0.f;
-    } else { // processMixture, :327-333: a = acceptance of whichever proposal was tested
-        const float a = cs.do_second ? a2 : cs.a1;
-        out.w0 = 1.f - a; out.w1 = cs.do_second ? 0.f : a; out.w2 = cs.do_second ? a : 0.f;
-    }
-    if (cs.large) {
-        ct.large_acc1l += 1u + (acc1 ? 1u << 16 : 0u);
-        if (cs.do_second) ct.acc1b_secl += 1u << 16;
-        if (acc2) ct.secb_acc2l += 1u << 16;
-    } else {
-        if (acc1) ct.acc1b_secl += 1u;
-        if (cs.do_second) ct.secb_acc2l += 1u;
-        if (acc2) ct.acc2b_rev += 1u;
-    }
-    if (acc1 || acc2) {
-        out.commit = acc1 ? SM_STAGE1 : SM_STAGE2;
-        if (amap && !mix) out.amap = acc1 ? (cs.large ? 0 : 1) : 2;
-    }
+    out.w = mh_weights(mix, P.acceptance_map != 0, cs.do_second, cs.a1, a2);
+    mh_count(ct, cs.large, acc1, acc2, cs.do_second);
+    if (acc1 || acc2) out.commit = acc1 ? SM_STAGE1 : SM_STAGE2;
+    out.amap = mh_amap_mark(mix, P.acceptance_map != 0, cs.large, acc1, acc2);
     cs.it++;
     cs.stage = -1;
     return out;
 }
 
-// k_mutate_v2 / v3: splat the decided mutation at once and adopt the accepted proposal. The three splats go through ONE
+// k_mutate_v3: splat the decided mutation at once and adopt the accepted proposal. The three splats go through ONE
 // film_put site (the call expands to ~150 instructions; six inlined copies of it were a sixth of the kernel's code):
 // slot 0 current state, 1 first-stage, 2 second-stage proposal.
 DEV int mh_decide_splat(const DParams &P, ChainState &cs, LdsSampler &smp, PathState &ps, Counters &ct) {
@@ -433,13 +217,13 @@ DEV int mh_decide_splat(const DParams &P, ChainState &cs, LdsSampler &smp, PathS
     if (!o.decided) return 0;
 #pragma nounroll
     for (int i = 0; i < 3; ++i) {
-        const float w = i == 0 ? o.w0 : (i == 1 ? o.w1 : o.w2);
+        const float w = i == 0 ? o.w.w0 : (i == 1 ? o.w.w1 : o.w.w2);
         const DSplat sp = select_splat(i == 0, cs.cur, select_splat(i == 1, cs.y, cs.z));
         if (w > 0.f) film_put(P, sp.px, sp.py, mk3(sp.r * w, sp.g * w, sp.b * w));
     }
     if (o.commit) {
+        if (o.amap) film_put(P, cs.cur.px, cs.cur.py, mh_amap_colour(o.amap)); // the state that is LEFT (device_mh.h)
         cs.cur = select_splat(o.commit == SM_STAGE1, cs.y, cs.z);
-        if (o.amap) film_put(P, cs.cur.px, cs.cur.py, o.amap == 1 ? mk3(1.f, 0.f, 0.f) : mk3(0.f, 1.f, 0.f));
     }
     return o.commit;
 }
@@ -483,112 +267,6 @@ DEV int mh_start(const DParams &P, ChainState &cs, LdsSampler &smp, PathState &p
     smp.mode = cs.stage == 0 ? SM_STAGE1 : (cs.stage == 1 ? SM_STAGE2 : SM_REVERSE);
     path_init(P, ps);
     return fill;
-}
-
-// one lane does everything (k_mutate_v2)
-DEV void mh_advance(const DParams &P, ChainState &cs, LdsSampler &smp, PathState &ps, Counters &ct, uint32_t n_mut,
-                    uint32_t mut_base, uint32_t lane, MhStamps &ms, bool stamps) {
-    const unsigned long long m0 = stamps ? __builtin_amdgcn_s_memtime() : 0ull;
-    const int commit = mh_decide_splat(P, cs, smp, ps, ct);
-    const unsigned long long m1 = stamps ? __builtin_amdgcn_s_memtime() : 0ull;
-    if (commit) commit_range(smp, commit, 0u, (uint32_t) P.eff_dim);
-    const unsigned long long m2 = stamps ? __builtin_amdgcn_s_memtime() : 0ull;
-    const int fill = mh_start(P, cs, smp, ps, n_mut, mut_base);
-    const uint32_t D4 = ((uint32_t) P.eff_dim + 3u) & ~3u;
-    if (fill == 1) smp.fill_stage1(0u, D4 / 4u);
-    else if (fill == 2) smp.fill_stage2(D4, 0u, 1u);
-    ms.digest += m1 - m0; ms.commit += m2 - m1;
-    ms.start += (stamps ? __builtin_amdgcn_s_memtime() : 0ull) - m2;
-}
-
-__global__ void __launch_bounds__(CHAIN_BLOCK) k_mutate_v2(DParams P, uint32_t n_mut, uint32_t mut_base) {
-    const uint32_t lane = threadIdx.x;
-    // experiment (DRMLT_DEBUG bit 512): 32 chains per wave in lanes 0..31, twice the waves
-    const uint32_t per_wave = (P.debug & 512) ? 32u : 64u;
-    const uint32_t c = blockIdx.x * per_wave + lane;
-    const bool live = lane < per_wave && c < P.n_chains;
-    const uint32_t cc = live ? c : P.n_chains - 1;
-    const int D = P.eff_dim;
-    for (int k = 0; k < D; ++k) lds_x[(uint32_t) k * per_wave + lane] = P.x[(size_t) k * P.n_chains + cc];
-
-    ChainState cs;
-    cs.cur.lum = P.cur_lum[cc]; cs.cur.px = P.cur_px[cc]; cs.cur.py = P.cur_py[cc];
-    cs.cur.r = P.cur_r[cc]; cs.cur.g = P.cur_g[cc]; cs.cur.b = P.cur_b[cc];
-    cs.y = cs.cur; cs.z = cs.cur;
-    cs.a1 = 0.f; cs.coin_acc1 = cs.coin_acc2 = cs.coin_mix = 0.f;
-    cs.it = 0u; cs.nd1 = cs.nd2 = 0u; cs.stage = -1; cs.large = false; cs.do_second = false;
-
-    LdsSampler smp;
-    smp.key0 = P.key0; smp.key1 = P.key1; smp.chain = P.chain_offset + cc; smp.major = 0u;
-    smp.mode = SM_STAGE1; smp.type = P.type; smp.large = false; smp.sigma2 = P.sigma2; smp.lane = lane;
-    const uint32_t D4 = ((uint32_t) D + 3u) & ~3u;
-    smp.stride = per_wave;
-    smp.u1_off = (uint32_t) D * per_wave;
-    smp.s2_off = smp.u1_off + D4 * per_wave;
-    smp.timing_probe = (P.debug & 256) != 0;
-    Counters ct = {0u, 0u, 0u, 0u, 0u};
-    PathState ps;
-    path_init(P, ps);
-    ps.phase = (live && n_mut > 0u) ? PH_DONE : PH_IDLE; // PH_DONE with stage -1: "start the first mutation"
-    Hit h{-1, 0.f, 0.f, 0.f};
-    ShadowRay sr_unused;
-    const int batch = P.mh_batch;
-    // scene tables: staged in LDS behind the sampler rows when they are small
-    LdsTables LT;
-    LT.shade_off = smp.s2_off + D4 * per_wave;
-    LT.bsdf_off = LT.shade_off + (uint32_t) P.n_shade * 16u;
-    LT.emit_off = LT.bsdf_off + (uint32_t) P.n_bsdfs * 12u;
-    const GlobalTables GT{P.shade, P.bsdfs, P.emitters};
-    const bool lds_tables = P.tables_in_lds != 0;
-    if (lds_tables) stage_tables(P, LT, lane);
-
-    // diagnostic stamps (DRMLT_DEBUG bit 128): per-wave cycle shares of the three loop sections
-    const bool stamps = (P.debug & 128) != 0;
-    unsigned long long t_mh = 0, t_trace = 0, t_step = 0, n_iter = 0, n_mh = 0, n_busy = 0;
-    MhStamps ms = {0, 0, 0, 0};
-#define STAMP() (stamps ? __builtin_amdgcn_s_memtime() : 0ull)
-    for (;;) {
-        const bool parked = ps.phase == PH_DONE;
-        const unsigned long long pmask = __ballot(parked);
-        const unsigned long long rmask = __ballot(ps.phase != PH_DONE && ps.phase != PH_IDLE);
-        if (!pmask && !rmask) break;
-        const unsigned long long s0 = STAMP();
-        if (pmask && (__popcll(pmask) >= batch || !rmask)) {
-            if (parked) mh_advance(P, cs, smp, ps, ct, n_mut, mut_base, lane, ms, stamps);
-            n_mh++;
-        }
-        const unsigned long long s1 = STAMP();
-        const bool tracing = ps.phase == PH_CLOSEST || ps.phase == PH_SHADOW;
-        if (stamps) n_busy += __popcll(__ballot(tracing));
-        if (tracing) h = trace(P, ps.o, ps.d, ps.tmin, ps.tmax, ps.phase == PH_SHADOW);
-        const unsigned long long s2 = STAMP();
-        if (ps.phase != PH_DONE && ps.phase != PH_IDLE) {
-            if (lds_tables) path_step<false, 15>(P, LT, ps, smp, h, false, sr_unused);
-            else path_step<false, 15>(P, GT, ps, smp, h, false, sr_unused);
-        }
-        const unsigned long long s3 = STAMP();
-        t_mh += s1 - s0; t_trace += s2 - s1; t_step += s3 - s2; n_iter++;
-    }
-#undef STAMP
-    if (stamps && lane == 0) {
-        atomicAdd(P.stats + 16, t_mh); atomicAdd(P.stats + 17, t_trace); atomicAdd(P.stats + 18, t_step);
-        atomicAdd(P.stats + 19, n_iter); atomicAdd(P.stats + 20, n_mh); atomicAdd(P.stats + 21, n_busy);
-        atomicAdd(P.stats + 22, ms.digest); atomicAdd(P.stats + 23, ms.splat); atomicAdd(P.stats + 24, ms.commit); atomicAdd(P.stats + 25, ms.start);
-    }
-
-    if (live) {
-        for (int k = 0; k < D; ++k) P.x[(size_t) k * P.n_chains + c] = lds_x[(uint32_t) k * per_wave + lane];
-        P.cur_lum[c] = cs.cur.lum; P.cur_px[c] = cs.cur.px; P.cur_py[c] = cs.cur.py;
-        P.cur_r[c] = cs.cur.r; P.cur_g[c] = cs.cur.g; P.cur_b[c] = cs.cur.b;
-    }
-    unsigned long long v[9];
-    v[0] = wave_sum(ct.large_acc1l & 0xffffu); v[1] = wave_sum(ct.large_acc1l >> 16);
-    v[2] = wave_sum(ct.acc1b_secl & 0xffffu);  v[3] = wave_sum(ct.acc1b_secl >> 16);
-    v[4] = wave_sum(ct.secb_acc2l & 0xffffu);  v[5] = wave_sum(ct.secb_acc2l >> 16);
-    v[6] = wave_sum(ct.acc2b_rev & 0xffffu);   v[7] = wave_sum(ct.acc2b_rev >> 16);
-    v[8] = wave_sum(ct.rays);
-    if (lane == 0)
-        for (int i = 0; i < 9; ++i) atomicAdd(P.stats + i, v[i]);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -744,14 +422,7 @@ __global__ void __launch_bounds__(CHAIN_BLOCK) k_mutate_v3(DParams P, uint32_t n
         P.cur_lum[c] = cs.cur.lum; P.cur_px[c] = cs.cur.px; P.cur_py[c] = cs.cur.py;
         P.cur_r[c] = cs.cur.r; P.cur_g[c] = cs.cur.g; P.cur_b[c] = cs.cur.b;
     }
-    unsigned long long v[9];
-    v[0] = wave_sum(ct.large_acc1l & 0xffffu); v[1] = wave_sum(ct.large_acc1l >> 16);
-    v[2] = wave_sum(ct.acc1b_secl & 0xffffu);  v[3] = wave_sum(ct.acc1b_secl >> 16);
-    v[4] = wave_sum(ct.secb_acc2l & 0xffffu);  v[5] = wave_sum(ct.secb_acc2l >> 16);
-    v[6] = wave_sum(ct.acc2b_rev & 0xffffu);   v[7] = wave_sum(ct.acc2b_rev >> 16);
-    v[8] = wave_sum(ct.rays);
-    if (lane == 0)
-        for (int i = 0; i < 9; ++i) atomicAdd(P.stats + i, v[i]);
+    flush_counters(P, ct, lane);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -966,21 +637,21 @@ __global__ void __launch_bounds__(CHAIN_BLOCK) k_mutate_v4(DParams P, uint32_t n
             if (parked) {
                 const MhOutcome o = mh_decide(Pm, cs, smp, ps, ct);
                 if (o.decided) {
-                    cum += o.w0;
+                    cum += o.w.w0;
                     const bool a1st = o.commit == SM_STAGE1, a2nd = o.commit == SM_STAGE2;
                     // rejected proposals are splatted now, an adopted one carries its weight into `cum`
-                    want1 = !a1st && o.w1 > 0.f;
-                    e1x = cs.y.px; e1y = cs.y.py; e1r = cs.y.r * o.w1; e1g = cs.y.g * o.w1; e1b = cs.y.b * o.w1;
-                    want2 = !a2nd && o.w2 > 0.f;
-                    e2x = cs.z.px; e2y = cs.z.py; e2r = cs.z.r * o.w2; e2g = cs.z.g * o.w2; e2b = cs.z.b * o.w2;
+                    want1 = !a1st && o.w.w1 > 0.f;
+                    e1x = cs.y.px; e1y = cs.y.py; e1r = cs.y.r * o.w.w1; e1g = cs.y.g * o.w.w1; e1b = cs.y.b * o.w.w1;
+                    want2 = !a2nd && o.w.w2 > 0.f;
+                    e2x = cs.z.px; e2y = cs.z.py; e2r = cs.z.r * o.w.w2; e2g = cs.z.g * o.w.w2; e2b = cs.z.b * o.w.w2;
                     if (o.commit) {
                         want0 = cum > 0.f;
                         e0x = cs.cur.px; e0y = cs.cur.py; e0r = cs.cur.r * cum; e0g = cs.cur.g * cum; e0b = cs.cur.b * cum;
-                        cum = a1st ? o.w1 : o.w2;
+                        cum = a1st ? o.w.w1 : o.w.w2;
                         cs.cur = select_splat(a1st, cs.y, cs.z);
-                        if (o.amap) { // acceptance map: a mark at the adopted state's pixel (the weights are all zero)
-                            want1 = true; e1x = cs.cur.px; e1y = cs.cur.py;
-                            e1r = o.amap == 1 ? 1.f : 0.f; e1g = o.amap == 1 ? 0.f : 1.f; e1b = 0.f;
+                        if (o.amap) { // acceptance map: a mark at the pixel of the state that was LEFT (the weights are all zero)
+                            const f3 mc = mh_amap_colour(o.amap);
+                            want1 = true; e1x = e0x; e1y = e0y; e1r = mc.x; e1g = mc.y; e1b = mc.z;
                         }
                     }
                     commit = o.commit;
@@ -1213,15 +884,9 @@ __global__ void __launch_bounds__(CHAIN_BLOCK) k_mutate_v4(DParams P, uint32_t n
         if (P.chain_done) P.chain_done[c] = base + cs.it;
     }
     if (P.chain_done && !reported && lane == 0) atomicSub(P.waves_left, 1u); // (a wave none of whose chains had anything to do)
-    unsigned long long v[10];
-    v[0] = wave_sum(ct.large_acc1l & 0xffffu); v[1] = wave_sum(ct.large_acc1l >> 16);
-    v[2] = wave_sum(ct.acc1b_secl & 0xffffu);  v[3] = wave_sum(ct.acc1b_secl >> 16);
-    v[4] = wave_sum(ct.secb_acc2l & 0xffffu);  v[5] = wave_sum(ct.secb_acc2l >> 16);
-    v[6] = wave_sum(ct.acc2b_rev & 0xffffu);   v[7] = wave_sum(ct.acc2b_rev >> 16);
-    v[8] = wave_sum(ct.rays);
-    v[9] = wave_sum((live && !helper) ? cs.it : 0u); // mutations decided in this launch (with run-ahead: not n_mut per chain)
-    if (lane == 0)
-        for (int i = 0; i < 10; ++i) atomicAdd(P.stats + i, v[i]);
+    flush_counters(P, ct, lane);
+    const unsigned long long decided = wave_sum((live && !helper) ? cs.it : 0u); // mutations decided in this launch (with run-ahead: not n_mut per chain)
+    if (lane == 0) atomicAdd(P.stats + 9, decided);
     if (RESUMABLE) {
         const unsigned long long nn = wave_sum(T.n_nodes), np = wave_sum(T.n_prims);
         if (lane == 0) { atomicAdd(P.stats + 10, nn); atomicAdd(P.stats + 11, np); atomicAdd(P.stats + 12, (unsigned long long) T.it_inner); atomicAdd(P.stats + 13, (unsigned long long) T.it_leaf); }
@@ -1319,10 +984,8 @@ void launch_mutate_pssmlt(const DParams &P, uint32_t n_mut, uint32_t mut_base, h
 }
 void launch_mutate(const DParams &P, uint32_t n_mut, uint32_t mut_base, hipStream_t st) {
     const size_t D = (size_t) P.eff_dim, D4 = (D + 3) & ~(size_t) 3;
-    dim3 grid((P.n_chains + CHAIN_BLOCK - 1) / CHAIN_BLOCK), block(CHAIN_BLOCK);
-    if (P.kernel_variant == 1) {
-        hipLaunchKernelGGL(k_mutate, grid, block, D * 64 * sizeof(float), st, P, n_mut, mut_base);
-    } else if (P.kernel_variant == 4) { // free-running chains, flattened bookkeeping, queued splats (rows of 33 floats)
+    const dim3 block(CHAIN_BLOCK);
+    if (P.kernel_variant == 4) { // free-running chains, flattened bookkeeping, queued splats (rows of 33 floats)
         const size_t qcap = (P.features & 8) || !P.tables_in_lds ? V4_QCAP_BVH : V4_QCAP; // as the kernel variants below
         size_t lds = ((D + 2 * D4 + 4) * V4_STRIDE + 32 + 5 * qcap + 3) / 4 * 4 * sizeof(float);
         if (P.tables_in_lds) lds += (size_t) P.n_shade * 64 + (size_t) P.n_bsdfs * 48 + (size_t) P.n_emitters * 32;
@@ -1345,7 +1008,7 @@ void launch_mutate(const DParams &P, uint32_t n_mut, uint32_t mut_base, hipStrea
         else if (P.debug & 128) hipLaunchKernelGGL((k_mutate_v4<15, false, true, true>), g4, block, lds, st, P, n_mut, mut_base); // diagnostic stamps
         else if (P.features == 8) hipLaunchKernelGGL((k_mutate_v4<8, false, false, true>), g4, block, lds, st, P, n_mut, mut_base); // triangle meshes with diffuse surfaces only
         else hipLaunchKernelGGL((k_mutate_v4<15, false, false, true>), g4, block, lds, st, P, n_mut, mut_base);
-    } else if (P.kernel_variant == 3) { // 32 chains per wave, rows of 32 floats
+    } else { // k_mutate_v3, the cross-check: 32 chains per wave, rows of 32 floats
         size_t lds = (D + 2 * D4) * 32 * sizeof(float);
         if (P.tables_in_lds) lds += (size_t) P.n_shade * 64 + (size_t) P.n_bsdfs * 48 + (size_t) P.n_emitters * 32;
         if (getenv("DRMLT_VERBOSE")) fprintf(stderr, "[drmlt] k_mutate_v3: %zu B of LDS per wave\n", lds);
@@ -1360,11 +1023,6 @@ void launch_mutate(const DParams &P, uint32_t n_mut, uint32_t mut_base, hipStrea
         } else { // large scenes (BVH, tables in HBM/L2): one general variant
             hipLaunchKernelGGL((k_mutate_v3<15, false>), g3, block, lds, st, P, n_mut, mut_base);
         }
-    } else { // x + first-stage uniforms + second-stage values, one 256 B row per dimension
-        size_t lds = (D + 2 * D4) * 64 * sizeof(float);
-        if (P.debug & 512) { grid = dim3((P.n_chains + 31) / 32); lds /= 2; }
-        if (P.tables_in_lds) lds += (size_t) P.n_shade * 64 + (size_t) P.n_bsdfs * 48 + (size_t) P.n_emitters * 32;
-        hipLaunchKernelGGL(k_mutate_v2, grid, block, lds, st, P, n_mut, mut_base);
     }
 }
 void launch_eval_paths(const DParams &P, const float *u, uint32_t n, uint32_t dim, float *out8, hipStream_t st) {

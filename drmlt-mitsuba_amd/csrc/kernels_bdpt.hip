@@ -175,22 +175,13 @@ template <int FEAT, int OCC> __global__ void __launch_bounds__(CHAIN_BLOCK, OCC)
             const float lum = list_finalize(P, target, R.lum);
             if (stage == 0) {
                 y_lum = lum; ns1 = R.n_sensor; ne1 = R.n_emitter; nd1 = R.n_direct;
-                if (!(mix ? lum_invalid_mix(y_lum) : lum_invalid(y_lum))) {
-                    a1 = fminf(1.f, y_lum / cur_lum);
-                    acc1 = a1 >= 1.f || u32_to_unit(coins.y) < a1;
-                }
-                if (!mix) doSecond = !acc1 && !large;
-                else doSecond = !large && u32_to_unit(coins.w) < 0.5f;
+                mh_first(mix, false, large, y_lum, cur_lum, u32_to_unit(coins.y), u32_to_unit(coins.w), a1, acc1, doSecond); // timidAfterLarge is refused for bdpt
                 if (!doSecond) break;
             } else if (stage == 1) {
                 z_lum = lum; ns2 = R.n_sensor; ne2 = R.n_emitter; nd2 = R.n_direct;
-                if (mix) {
-                    acc1 = false;
-                    a1 = 0.f;
-                    if (!lum_invalid_mix(z_lum)) {
-                        a2 = fminf(1.f, z_lum / cur_lum);
-                        acc2 = a2 >= 1.f || u32_to_unit(coins.z) < a2;
-                    }
+                if (mix) { // the second proposal replaces the first
+                    acc1 = false; a1 = 0.f;
+                    mh_second_mixture(z_lum, cur_lum, u32_to_unit(coins.z), a2, acc2);
                     break;
                 }
                 if (lum_invalid(z_lum)) break;
@@ -200,8 +191,8 @@ template <int FEAT, int OCC> __global__ void __launch_bounds__(CHAIN_BLOCK, OCC)
                     continue;
                 }
                 if (P.type == 1) {
-                    float aRev = fminf(1.f, y_lum / z_lum);
-                    if (!(aRev >= 1.f)) {
+                    float ratio = 1.f;
+                    if (!(fminf(1.f, y_lum / z_lum) >= 1.f)) { // (a large step never gets here: no second stage after it)
                         float num = 0.f, den = 0.f;
                         for (int sg = 0; sg < 3; ++sg) {
                             const uint32_t nmax = sg == 0 ? max(ns1, ns2) : (sg == 1 ? max(ne1, ne2) : max(nd1, nd2));
@@ -213,67 +204,33 @@ template <int FEAT, int OCC> __global__ void __launch_bounds__(CHAIN_BLOCK, OCC)
                                 den += kelemen_logpdf(smp.x(i) - yi);
                             }
                         }
-                        float ratio = __expf(num - den);
-                        if (!lum_invalid(ratio)) {
-                            a2 = fminf(1.f, (z_lum / cur_lum) * ratio * (1.f - aRev) / (1.f - a1));
-                            acc2 = a2 >= 1.f || u32_to_unit(coins.z) < a2;
-                        }
+                        ratio = __expf(num - den);
                     }
+                    mh_second_mira(y_lum, z_lum, cur_lum, a1, ratio, u32_to_unit(coins.z), a2, acc2);
                 } else {
-                    if (z_lum < y_lum) { a2 = 0.f; }
-                    else if (z_lum >= cur_lum) { a2 = 1.f; acc2 = true; }
-                    else {
-                        a2 = (z_lum - y_lum) / (cur_lum - y_lum);
-                        acc2 = a2 >= 1.f || u32_to_unit(coins.z) < a2;
-                    }
+                    mh_second_orbital(y_lum, z_lum, cur_lum, u32_to_unit(coins.z), a2, acc2);
                 }
                 break;
             } else {
                 ct.acc2b_rev += 1u << 16;
-                float aRev = lum_invalid(lum) ? 0.f : fminf(1.f, lum / z_lum);
-                if (aRev != 1.f) {
-                    a2 = fminf(1.f, (z_lum / cur_lum) * (1.f - aRev) / (1.f - a1));
-                    acc2 = a2 >= 1.f || u32_to_unit(coins.z) < a2;
-                }
+                mh_second_green(lum, z_lum, cur_lum, a1, u32_to_unit(coins.z), a2, acc2);
             }
         }
         const unsigned long long b1 = BSTAMP();
-        const bool y_splatted = !mix && P.type == 0 && doSecond && !lum_invalid(z_lum); // Green went on to the reverse move
+        const bool y_splatted = !mix && !amap && P.type == 0 && doSecond && !lum_invalid(z_lum); // Green went on to the reverse move
 
-        // Expectation weights. The current state's share is accumulated and its list splatted once, when the state is
-        // replaced or the launch ends (the reference's pssmlt loop does the same, pssmlt_proc.cpp:205-228): the same film,
-        // one list splat per mutation instead of two or three. Acceptance-map runs keep one splat per event.
-        if (!mix) {
-            float w1 = a1, w2 = (1.f - a1) * a2, w0 = 1.f - w1 - w2;
-            if (!amap) {
-                cum += w0;
-                if (acc1 || acc2) { list_splat(P, L0, cur_lum, cum); cum = acc1 ? w1 : w2; }
-                if (!acc1 && !y_splatted) list_splat(P, L1, y_lum, w1);
-                if (doSecond && !acc2) list_splat(P, L2, z_lum, w2);
-            }
-        } else {
-            const float a = doSecond ? a2 : a1;
-            if (amap) {
-                list_splat(P, L0, cur_lum, 1.f - a);
-                if (doSecond) list_splat(P, L2, z_lum, a); else list_splat(P, L1, y_lum, a);
-            } else {
-                cum += 1.f - a;
-                if (acc1 || acc2) { list_splat(P, L0, cur_lum, cum); cum = a; }
-                else if (doSecond) list_splat(P, L2, z_lum, a);
-                else list_splat(P, L1, y_lum, a);
-            }
-        }
+        // Expectation weights (device_mh.h). The current state's share is accumulated and its list splatted once, when the
+        // state is replaced or the launch ends (the reference's pssmlt loop does the same, pssmlt_proc.cpp:205-228): the
+        // same film, one list splat per mutation instead of two or three. An adopted proposal carries its weight into
+        // `cum`. In an acceptance-map run of the delayed-rejection loop all three weights are zero.
+        const MhWeights w = mh_weights(mix, amap, doSecond, a1, a2);
+        cum += w.w0;
+        if (acc1 || acc2) { list_splat(P, L0, cur_lum, cum); cum = acc1 ? w.w1 : w.w2; }
+        if (!acc1 && !y_splatted) list_splat(P, L1, y_lum, w.w1);
+        if (!acc2) list_splat(P, L2, z_lum, w.w2);
 
         const unsigned long long b2 = BSTAMP();
-        if (large) {
-            ct.large_acc1l += 1u + (acc1 ? 1u << 16 : 0u);
-            if (doSecond) ct.acc1b_secl += 1u << 16;
-            if (acc2) ct.secb_acc2l += 1u << 16;
-        } else {
-            if (acc1) ct.acc1b_secl += 1u;
-            if (doSecond) ct.secb_acc2l += 1u;
-            if (acc2) ct.acc2b_rev += 1u;
-        }
+        mh_count(ct, large, acc1, acc2, doSecond);
 
         if (acc1 || acc2) {
             for (int sg = 0; sg < 3; ++sg) { // every component of the three samplers (DRMLTSampler::accept, drmlt_sampler.cpp:189-199)
@@ -288,29 +245,22 @@ template <int FEAT, int OCC> __global__ void __launch_bounds__(CHAIN_BLOCK, OCC)
             }
             { float *t = L0; if (acc1) { L0 = L1; L1 = t; } else { L0 = L2; L2 = t; } } // the accepted list becomes the current one: swap, do not copy
             cur_lum = acc1 ? y_lum : z_lum;
-            if (amap) {
-                if (acc1) { if (!large && !mix) list_splat_const(P, L0, mk3(1.f, 0.f, 0.f)); }
-                else if (!mix) list_splat_const(P, L0, mk3(0.f, 1.f, 0.f));
-            }
+            // acceptance map: every splat position of the list that WAS current -- after the swap that is the proposal's
+            // slot, exactly as in the reference (drmlt_proc.cpp:693-709; device_mh.h)
+            const int mark = mh_amap_mark(mix, amap, large, acc1, acc2);
+            if (mark) list_splat_const(P, acc1 ? L1 : L2, mh_amap_colour(mark));
         }
         const unsigned long long b3 = BSTAMP();
         t_stages += b1 - b0; t_splat += b2 - b1; t_commit += b3 - b2;
     }
 
     if (live) {
-        if (!amap) list_splat(P, L0, cur_lum, cum); // "perform the last splat"
+        list_splat(P, L0, cur_lum, cum); // "perform the last splat" (cum stays 0 through an acceptance-map run)
         if (L0 != list_col(P, 0, cc)) list_copy(P, list_col(P, 0, cc), L0); // slot 0 is where the next launch (and drmlt_chain_state) look
         for (uint32_t k = 0; k < NX; ++k) P.x[(size_t) k * P.n_chains + c] = lds_x[k * 64u + lane];
         P.cur_lum[c] = cur_lum;
     }
-    unsigned long long v[9];
-    v[0] = wave_sum(ct.large_acc1l & 0xffffu); v[1] = wave_sum(ct.large_acc1l >> 16);
-    v[2] = wave_sum(ct.acc1b_secl & 0xffffu);  v[3] = wave_sum(ct.acc1b_secl >> 16);
-    v[4] = wave_sum(ct.secb_acc2l & 0xffffu);  v[5] = wave_sum(ct.secb_acc2l >> 16);
-    v[6] = wave_sum(ct.acc2b_rev & 0xffffu);   v[7] = wave_sum(ct.acc2b_rev >> 16);
-    v[8] = wave_sum(ct.rays);
-    if (lane == 0)
-        for (int i = 0; i < 9; ++i) atomicAdd(P.stats + i, v[i]);
+    flush_counters(P, ct, lane);
     if (dbg && lane == 0) { atomicAdd(P.stats + 18, __builtin_amdgcn_s_memtime() - k0); atomicAdd(P.stats + 20, t_stages); atomicAdd(P.stats + 21, t_splat); atomicAdd(P.stats + 22, t_commit); } // per wave
 #undef BSTAMP
 }

@@ -122,29 +122,20 @@ template <int FEAT> __global__ void __launch_bounds__(CHAIN_BLOCK, 2) k_mutate_m
             normalize_splat(res, P);
             if (stage == 0) {
                 y = res; y_t = R.t; ns1 = R.n_sensor; ne1 = R.n_emitter;
-                if (!(mix ? lum_invalid_mix(y.lum) : lum_invalid(y.lum))) {
-                    a1 = fminf(1.f, y.lum / cur.lum);
-                    acc1 = a1 >= 1.f || u32_to_unit(coins.y) < a1;
-                }
-                if (!mix) doSecond = !acc1 && !large;                  // timidAfterLarge is refused for mmlt
-                else doSecond = !large && u32_to_unit(coins.w) < 0.5f;
+                mh_first(mix, false, large, y.lum, cur.lum, u32_to_unit(coins.y), u32_to_unit(coins.w), a1, acc1, doSecond); // timidAfterLarge is refused for mmlt
                 if (!doSecond) break;
             } else if (stage == 1) {
                 z = res; z_t = R.t; ns2 = R.n_sensor; ne2 = R.n_emitter;
-                if (mix) {
-                    acc1 = false;
-                    a1 = 0.f;
-                    if (!lum_invalid_mix(z.lum)) {
-                        a2 = fminf(1.f, z.lum / cur.lum);
-                        acc2 = a2 >= 1.f || u32_to_unit(coins.z) < a2;
-                    }
+                if (mix) { // the second proposal replaces the first
+                    acc1 = false; a1 = 0.f;
+                    mh_second_mixture(z.lum, cur.lum, u32_to_unit(coins.z), a2, acc2);
                     break;
                 }
                 if (lum_invalid(z.lum)) break;
-                if (P.type == 0) continue;
+                if (P.type == 0) continue; // Green: the reverse move first
                 if (P.type == 1) { // Tierney & Mira: product of the three samplers' ratios (drmlt_proc.cpp:633-637)
-                    float aRev = fminf(1.f, y.lum / z.lum);
-                    if (!(aRev >= 1.f)) {
+                    float ratio = 1.f;
+                    if (!(fminf(1.f, y.lum / z.lum) >= 1.f)) { // (a large step never gets here: no second stage after it)
                         float num = 0.f, den = 0.f;
                         for (int sg = 0; sg < 2; ++sg) { // the direct sampler's first stage is the identity: ratio 1
                             const uint32_t nmax = sg == 0 ? max(ns1, ns2) : max(ne1, ne2);
@@ -156,54 +147,24 @@ template <int FEAT> __global__ void __launch_bounds__(CHAIN_BLOCK, 2) k_mutate_m
                                 den += kelemen_logpdf(smp.x(i) - yi);
                             }
                         }
-                        float ratio = __expf(num - den);
-                        if (!lum_invalid(ratio)) {
-                            a2 = fminf(1.f, (z.lum / cur.lum) * ratio * (1.f - aRev) / (1.f - a1));
-                            acc2 = a2 >= 1.f || u32_to_unit(coins.z) < a2;
-                        }
+                        ratio = __expf(num - den);
                     }
+                    mh_second_mira(y.lum, z.lum, cur.lum, a1, ratio, u32_to_unit(coins.z), a2, acc2);
                 } else {
-                    if (z.lum < y.lum) { a2 = 0.f; }
-                    else if (z.lum >= cur.lum) { a2 = 1.f; acc2 = true; }
-                    else {
-                        a2 = (z.lum - y.lum) / (cur.lum - y.lum);
-                        acc2 = a2 >= 1.f || u32_to_unit(coins.z) < a2;
-                    }
+                    mh_second_orbital(y.lum, z.lum, cur.lum, u32_to_unit(coins.z), a2, acc2);
                 }
                 break;
             } else {
                 ct.acc2b_rev += 1u << 16;
-                float aRev = lum_invalid(res.lum) ? 0.f : fminf(1.f, res.lum / z.lum);
-                if (aRev != 1.f) {
-                    a2 = fminf(1.f, (z.lum / cur.lum) * (1.f - aRev) / (1.f - a1));
-                    acc2 = a2 >= 1.f || u32_to_unit(coins.z) < a2;
-                }
+                mh_second_green(res.lum, z.lum, cur.lum, a1, u32_to_unit(coins.z), a2, acc2);
             }
         }
 
-        if (!mix) {
-            float w1 = a1, w2 = (1.f - a1) * a2, w0 = 1.f - w1 - w2;
-            if (!amap) {
-                if (w0 > 0.f) film_put(P, cur.px, cur.py, mk3(cur.r * w0, cur.g * w0, cur.b * w0));
-                if (w1 > 0.f) film_put(P, y.px, y.py, mk3(y.r * w1, y.g * w1, y.b * w1));
-                if (doSecond && w2 > 0.f) film_put(P, z.px, z.py, mk3(z.r * w2, z.g * w2, z.b * w2));
-            }
-        } else {
-            const float a = doSecond ? a2 : a1;
-            const DSplat pr = select_splat(doSecond, z, y);
-            if (1.f - a > 0.f) film_put(P, cur.px, cur.py, mk3(cur.r * (1.f - a), cur.g * (1.f - a), cur.b * (1.f - a)));
-            if (a > 0.f) film_put(P, pr.px, pr.py, mk3(pr.r * a, pr.g * a, pr.b * a));
-        }
-
-        if (large) {
-            ct.large_acc1l += 1u + (acc1 ? 1u << 16 : 0u);
-            if (doSecond) ct.acc1b_secl += 1u << 16;
-            if (acc2) ct.secb_acc2l += 1u << 16;
-        } else {
-            if (acc1) ct.acc1b_secl += 1u;
-            if (doSecond) ct.secb_acc2l += 1u;
-            if (acc2) ct.acc2b_rev += 1u;
-        }
+        const MhWeights w = mh_weights(mix, amap, doSecond, a1, a2);
+        if (w.w0 > 0.f) film_put(P, cur.px, cur.py, mk3(cur.r * w.w0, cur.g * w.w0, cur.b * w.w0));
+        if (w.w1 > 0.f) film_put(P, y.px, y.py, mk3(y.r * w.w1, y.g * w.w1, y.b * w.w1));
+        if (w.w2 > 0.f) film_put(P, z.px, z.py, mk3(z.r * w.w2, z.g * w.w2, z.b * w.w2));
+        mh_count(ct, large, acc1, acc2, doSecond);
 
         if (acc1 || acc2) {
             // DRMLTSampler::accept on the three samplers: every component a path of this depth can consume
@@ -216,12 +177,10 @@ template <int FEAT> __global__ void __launch_bounds__(CHAIN_BLOCK, 2) k_mutate_m
                     if (smp.type == 2 && (k & 1u)) smp.pair_base = 0xffffffffu; // the pair cache holds the old x
                 }
             }
+            const int mark = mh_amap_mark(mix, amap, large, acc1, acc2);
+            if (mark) film_put(P, cur.px, cur.py, mh_amap_colour(mark)); // at the state that is LEFT (device_mh.h)
             cur = select_splat(acc1, y, z);
             cur_t = acc1 ? y_t : z_t;
-            if (amap) {
-                if (acc1) { if (!large && !mix) film_put(P, cur.px, cur.py, mk3(1.f, 0.f, 0.f)); }
-                else if (!mix) film_put(P, cur.px, cur.py, mk3(0.f, 1.f, 0.f));
-            }
         }
     }
 
@@ -231,14 +190,7 @@ template <int FEAT> __global__ void __launch_bounds__(CHAIN_BLOCK, 2) k_mutate_m
         P.cur_r[c] = cur.r; P.cur_g[c] = cur.g; P.cur_b[c] = cur.b;
         P.cur_t[c] = cur_t;
     }
-    unsigned long long v[9];
-    v[0] = wave_sum(ct.large_acc1l & 0xffffu); v[1] = wave_sum(ct.large_acc1l >> 16);
-    v[2] = wave_sum(ct.acc1b_secl & 0xffffu);  v[3] = wave_sum(ct.acc1b_secl >> 16);
-    v[4] = wave_sum(ct.secb_acc2l & 0xffffu);  v[5] = wave_sum(ct.secb_acc2l >> 16);
-    v[6] = wave_sum(ct.acc2b_rev & 0xffffu);   v[7] = wave_sum(ct.acc2b_rev >> 16);
-    v[8] = wave_sum(ct.rays);
-    if (lane == 0)
-        for (int i = 0; i < 9; ++i) atomicAdd(P.stats + i, v[i]);
+    flush_counters(P, ct, lane);
 }
 
 // u: [sensor S | emitter E | direct | depth] per point, dim >= S + E + 2

@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define DRMLT_ABI_VERSION 2
+#define DRMLT_ABI_VERSION 3
 
 /* ---- enums (values are ABI) ------------------------------------------- */
 
@@ -320,6 +320,17 @@ int drmlt_comm_unique_id(char id[DRMLT_COMM_ID_BYTES]);
 int drmlt_comm_init(drmlt_ctx *ctx, const char id[DRMLT_COMM_ID_BYTES], int rank, int world);
 int drmlt_exchange_tiled(drmlt_ctx *ctx, double *b_inout, float *tile_host_or_null,
                          int *row_lo, int *row_hi);
+/* What the communicator itself reports (ncclCommCount / ncclCommUserRank), not
+ * what the caller asked for: a launcher checks it against its own world size. */
+int drmlt_comm_info(drmlt_ctx *ctx, int *nranks, int *rank);
+/* The row partition of the exchange as pure arithmetic (no device needed):
+ * rank `rank` of `world` owns rows [*row_lo, *row_hi) of an H-row film, the
+ * reduce-scatter moves *rows_per_rank = ceil(H / world) rows per rank (the film
+ * allocation carries the zero rows that pads H to world * rows_per_rank).
+ * DRMLT_E_INVALID when world is not a valid partition (world > 16, rank out
+ * of range). Replaces the row bookkeeping a caller of the reference's
+ * processResult (drmlt_proc.cpp:856-867) never needed: it merged whole frames. */
+int drmlt_film_tile(int height, int rank, int world, int *row_lo, int *row_hi, int *rows_per_rank);
 
 /* (b) one process drives the GPUs of `device_mask` (bit d = HIP device d): what
  * the Mitsuba plugin uses, so that `-D integrator=drmlt` renders on the whole

@@ -48,6 +48,7 @@ def lib(native=False):
         L.oracle_last_error.argtypes = [C.c_void_p]
         L.oracle_eval_paths.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
         L.oracle_seed.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, C.POINTER(C.c_double)]
+        L.oracle_seed_pool.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.POINTER(C.c_double)]
         L.oracle_run.argtypes = [C.c_void_p, C.c_uint64, C.c_int]
         L.oracle_film_read.argtypes = [C.c_void_p, C.c_void_p]
         L.oracle_develop.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
@@ -70,6 +71,8 @@ def lib(native=False):
                                            C.c_uint32, C.c_int, C.c_uint32, C.c_uint32] + [C.c_void_p] * 7
         L.oracle_toy_run.argtypes = [C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_uint64,
                                      C.c_uint32, C.c_uint64, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        L.oracle_toy_amap.argtypes = [C.c_int, C.c_double, C.c_double, C.c_double, C.c_uint64, C.c_uint32, C.c_uint64, C.c_int,
+                                      C.c_int, C.c_void_p, C.c_void_p]
         L.oracle_toy_target.restype = C.c_double
         L.oracle_toy_target.argtypes = [C.c_double, C.c_double]
         L.oracle_film_put.argtypes = [C.c_int, C.c_int, C.c_int, C.c_double, C.c_uint32, C.c_void_p, C.c_void_p,
@@ -126,6 +129,12 @@ class Oracle:
     def seed(self, seed, chain_offset=0):
         b = C.c_double()
         self._chk(self.L.oracle_seed(self.h, seed, chain_offset, C.byref(b)))
+        return b.value
+
+    def seed_pool(self, seed, first_chain, pool_chains):
+        """Seeds [first_chain, first_chain + work_units) of ONE pool drawn for `pool_chains` chains (mirrors Context.seed_pool)."""
+        b = C.c_double()
+        self._chk(self.L.oracle_seed_pool(self.h, seed, first_chain, pool_chains, C.byref(b)))
         return b.value
 
     def run(self, total_mutations, nthreads=1):
@@ -265,6 +274,16 @@ def toy_run(abi, type_, mixture, timid, p_large, sigma, scale_second, seed, n_ch
     if rc != 0:
         raise OracleError("toy_run failed: %d" % rc)
     return hist, st
+
+
+def toy_amap(type_, p_large, sigma, scale_second, seed, n_chains, n_mut, w, h):
+    """Acceptance map (H x W x 3) of toy-target chains + their initial states (n_chains x 2)."""
+    rgb = np.zeros((h, w, 3), dtype=np.float64)
+    x0 = np.zeros((n_chains, 2), dtype=np.float64)
+    rc = lib().oracle_toy_amap(type_, p_large, sigma, scale_second, seed, n_chains, n_mut, w, h, rgb.ctypes.data, x0.ctypes.data)
+    if rc != 0:
+        raise OracleError("toy_amap failed: %d" % rc)
+    return rgb, x0
 
 
 def toy_target(x, y):

@@ -27,7 +27,7 @@ template <typename F> struct ArraySampler : Sampler<F> {
 struct CtxBase {
     virtual ~CtxBase() = default;
     virtual int evalPaths(const float *u, uint32_t n, uint32_t dim, drmlt_splat *out) = 0;
-    virtual int seed(uint64_t seed, uint32_t chainOffset, double *b) = 0;
+    virtual int seed(uint64_t seed, uint32_t chainOffset, double *b, uint32_t poolChains = 0) = 0;
     virtual int run(uint64_t total, int nthreads) = 0;
     virtual int filmRead(float *out) = 0;
     virtual int developImage(const float *direct, float *out) = 0;
@@ -125,15 +125,23 @@ template <typename F> struct Ctx : CtxBase {
         return 0;
     }
 
-    int seed(uint64_t seedv, uint32_t chainOffset, double *bOut) override {
-        Random boot(seedv, chainOffset);
+    // poolChains > 0: ONE seed pool for a job split over several participants (the product's drmlt_seed_pool):
+    // bootstrap stream 0, sized for poolChains chains, poolChains seeds drawn and sorted; this context takes seeds and
+    // chain ids [chainOffset, chainOffset + work_units). Every participant finds the same list and the same b.
+    int seed(uint64_t seedv, uint32_t chainOffset, double *bOut, uint32_t poolChains = 0) override {
+        const bool pool = poolChains > 0;
+        if (pool && (uint64_t) chainOffset + (uint64_t) cfg.work_units > poolChains) { error = "seed pool does not cover this context's chains"; return DRMLT_E_INVALID; }
+        const uint32_t bootStream = pool ? 0u : chainOffset;
+        const size_t nSelect = pool ? (size_t) poolChains : (size_t) cfg.work_units;
+        Random boot(seedv, bootStream);
         std::vector<PathSeed> seeds;
         // drmlt.cpp:454-473; technique=mmlt: x50 and one share per depth (initialisation on one core)
-        size_t lumSamples = (size_t) std::max(cfg.luminance_samples, cfg.work_units * (mmlt ? 50 : 10));
+        size_t lumSamples = (size_t) std::max<long long>(cfg.luminance_samples, (long long) nSelect * (mmlt ? 50 : 10));
         if (mmlt) lumSamples *= (size_t) cfg.max_depth;
-        b = mmlt ? generateSeeds<F>(meval, boot, lumSamples, (size_t) cfg.work_units, seeds, nullptr, cfg.max_depth)
-            : bdpt ? generateSeeds<F>(beval, boot, lumSamples, (size_t) cfg.work_units, seeds)
-                   : generateSeeds<F>(eval, boot, lumSamples, (size_t) cfg.work_units, seeds);
+        b = mmlt ? generateSeeds<F>(meval, boot, lumSamples, nSelect, seeds, nullptr, cfg.max_depth)
+            : bdpt ? generateSeeds<F>(beval, boot, lumSamples, nSelect, seeds)
+                   : generateSeeds<F>(eval, boot, lumSamples, nSelect, seeds);
+        if (pool && b != 0) seeds.assign(seeds.begin() + chainOffset, seeds.begin() + chainOffset + cfg.work_units);
         if (b == 0) { error = "The average image luminance appears to be zero!"; return DRMLT_E_ZERO_LUM; }
         if (cfg.acceptance_map) b = 1.0;                               // drmlt.cpp:550-552
         else if (cfg.average_luminance != -1.0f) b = cfg.average_luminance; // :555-558
@@ -142,16 +150,16 @@ template <typename F> struct Ctx : CtxBase {
         for (int i = 0; i < cfg.work_units; ++i) {
             bool ok;
             if (bdpt) {
-                bchains.emplace_back(new BChain(c, beval, seedv, chainOffset + i, chainOffset));
+                bchains.emplace_back(new BChain(c, beval, seedv, chainOffset + i, bootStream));
                 ok = bchains.back()->init(seeds[i]);
             } else if (mmlt) {
-                mchains.emplace_back(new MChain(c, meval, seedv, chainOffset + i, chainOffset));
+                mchains.emplace_back(new MChain(c, meval, seedv, chainOffset + i, bootStream));
                 ok = mchains.back()->init(seeds[i]);
             } else if (cfg.algo == DRMLT_ALGO_PSSMLT) {
-                pchains.emplace_back(new PSSMLTChain<F, SceneEvaluator<F>>(c, eval, seedv, chainOffset + i, chainOffset));
+                pchains.emplace_back(new PSSMLTChain<F, SceneEvaluator<F>>(c, eval, seedv, chainOffset + i, bootStream));
                 ok = pchains.back()->init(seeds[i]);
             } else {
-                chains.emplace_back(new DRChain<F, SceneEvaluator<F>>(c, eval, seedv, chainOffset + i, chainOffset));
+                chains.emplace_back(new DRChain<F, SceneEvaluator<F>>(c, eval, seedv, chainOffset + i, bootStream));
                 ok = chains.back()->init(seeds[i]);
             }
             if (!ok) { error = "Error when reconstructing a seed path"; return DRMLT_E_REPLAY; }
@@ -450,6 +458,7 @@ const char *oracle_last_error(void *p) { return static_cast<CtxBase *>(p)->error
 
 int oracle_eval_paths(void *p, const float *u, uint32_t n, uint32_t dim, drmlt_splat *out) { GUARD(static_cast<CtxBase *>(p)->evalPaths(u, n, dim, out)) }
 int oracle_seed(void *p, uint64_t seed, uint32_t chain_offset, double *b) { GUARD(static_cast<CtxBase *>(p)->seed(seed, chain_offset, b)) }
+int oracle_seed_pool(void *p, uint64_t seed, uint32_t first_chain, uint32_t pool_chains, double *b) { GUARD(static_cast<CtxBase *>(p)->seed(seed, first_chain, b, pool_chains)) }
 int oracle_run(void *p, uint64_t total, int nthreads) { GUARD(static_cast<CtxBase *>(p)->run(total, nthreads)) }
 int oracle_film_read(void *p, float *out) { GUARD(static_cast<CtxBase *>(p)->filmRead(out)) }
 int oracle_develop(void *p, const float *direct, float *out) { GUARD(static_cast<CtxBase *>(p)->developImage(direct, out)) }
@@ -566,6 +575,37 @@ int oracle_toy_run(int type, int useMixture, int timidAfterLarge, double pLarge,
     return 0;
 }
 double oracle_toy_target(double x, double y) { return ToyEvaluator<double>::target(x, y); }
+
+// Acceptance-map run of the delayed-rejection loop on the toy target (drmlt_proc.cpp:443-450,693-709): returns the
+// W x H x 3 map and every chain's INITIAL state x0 (nChains x 2), so that a test can replay the chains step by step in
+// its own words (tests/test_oracle_process.py: the reference's swap-then-mark order of operations, literally).
+int oracle_toy_amap(int type, double pLarge, double sigma, double scaleSecond, uint64_t seed, uint32_t nChains, uint64_t nMutations,
+                    int w, int h, double *rgb, double *x0) {
+    using F = double;
+    Config<F> c{};
+    c.algo = 0; c.type = type; c.maxDepth = 1; c.rrDepth = 1; c.separateDirect = false; c.acceptanceMap = true;
+    c.timidAfterLarge = false; c.useMixture = false; c.kelemenWeights = false; c.kelemenMutation = true;
+    c.pLarge = pLarge; c.sigma = sigma; c.scaleSecond = scaleSecond; c.maxDim = 2;
+    ToyEvaluator<F> eval{w, h};
+    Film<F> film(w, h, DRMLT_FILTER_BOX, 0.5);
+    Stats st;
+    try {
+        Random boot(seed, 0);
+        std::vector<PathSeed> seeds;
+        generateSeeds<F>(eval, boot, 4096, nChains, seeds);
+        for (uint32_t i = 0; i < nChains; ++i) {
+            DRChain<F, ToyEvaluator<F>> chain(c, eval, seed, i, 0);
+            if (!chain.init(seeds[i])) return DRMLT_E_REPLAY;
+            const std::vector<F> x = chain.state();
+            x0[2 * i] = x[0]; x0[2 * i + 1] = x[1];
+            chain.run(nMutations, film, st);
+        }
+    } catch (const std::exception &) { return -1; }
+    std::vector<double> acc((size_t) w * h * 3, 0.0);
+    film.accumulateInto(acc);
+    for (size_t i = 0; i < acc.size(); ++i) rgb[i] = acc[i];
+    return 0;
+}
 
 // ImageBlock::put through the discretised filter: splat n samples, return interior W x H x 3
 int oracle_film_put(int w, int h, int filter, double param, uint32_t n, const float *xy, const float *rgb, float *out) {

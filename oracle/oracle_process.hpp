@@ -342,12 +342,15 @@ private:
             if (doSecond) splat(film, second, w2); // weight is 0 otherwise
 
             if (acc1 || acc2) {
+                // drmlt_proc.cpp:693-709: `proposed.first.swap(current); splatAcceptanceOnly(proposed.first.get(), 0)` --
+                // after the swap `proposed.first` owns the list that WAS current, so the mark lands on every splat position
+                // of the state being LEFT, not of the one adopted (same for the second stage with `proposed.second`).
                 if (acc1) {
-                    m_current = first;
-                    if (!largeStep) splatAcceptance(film, m_current, 0);
+                    std::swap(first, m_current);
+                    if (!largeStep) splatAcceptance(film, first, 0);
                 } else {
-                    m_current = second;
-                    splatAcceptance(film, m_current, 1);
+                    std::swap(second, m_current);
+                    splatAcceptance(film, second, 1);
                 }
                 m_sampler.accept(acc1);
                 st.accepted++;

@@ -5,6 +5,7 @@ import ctypes as C
 import os
 import re
 import subprocess
+import sys
 import tempfile
 
 import pytest
@@ -26,7 +27,7 @@ def test_library_exports_every_declared_symbol(pkg, native_lib):
     assert set(names) == set(pkg.binding.ABI_SYMBOLS)
     for n in names:
         assert hasattr(native_lib, n), n
-    assert native_lib.drmlt_abi_version() == 2   # 2: + pool seeding, RCCL exchange, drmlt_node_*
+    assert native_lib.drmlt_abi_version() == 3   # 2: + pool seeding, RCCL exchange, drmlt_node_*; 3: + drmlt_comm_info, drmlt_film_tile
 
 
 def test_struct_layouts_match_the_header(abi):
@@ -80,6 +81,8 @@ def test_create_validates_like_the_reference_ctor(pkg, abi, native_lib):
         (dict(type="orbital", technique="mmlt", max_depth=8, algo=1), "pssmlt"),
         (dict(type="orbital", technique="bdpt", max_depth=8, timid_after_large=1), "timidAfterLarge"),
         (dict(type="orbital", technique="mmlt", max_depth=8, timid_after_large=1), "timidAfterLarge"),
+        # device_bdpt.h keeps two flag bits per stored vertex in one 64-bit register: 2 * 16 + 1 slots would need 66
+        (dict(type="orbital", technique="bdpt", max_depth=16), "maxDepth above 15"),
     ]
     for kw, needle in bad:
         with pytest.raises(pkg.DrmltError) as e:
@@ -97,3 +100,19 @@ def test_product_path_fails_loudly_without_a_gpu(pkg, abi, native_lib):
     with pytest.raises(pkg.DrmltError) as e:
         pkg.Context(abi.make_config(type="orbital", max_depth=8), sd)
     assert "no HIP device" in str(e.value) and "no CPU fallback" in str(e.value)
+
+
+def test_missing_rccl_is_an_error_return_not_a_crash(pkg, abi):
+    """the load-failure path called dlerror() twice (the second call returns NULL -> strlen(NULL)). A host
+    without librccl must get DRMLT_E_DEVICE from every entry point that needs a communicator. Own process: the library
+    caches the outcome of its one dlopen attempt."""
+    code = r"""
+import ctypes as C, sys
+L = C.CDLL(sys.argv[1])
+buf = C.create_string_buffer(128)
+print(L.drmlt_comm_unique_id(buf), L.drmlt_comm_unique_id(buf))
+"""
+    env = dict(os.environ, DRMLT_RCCL_LIB="/nonexistent/librccl.so.1")
+    out = subprocess.run([sys.executable, "-c", code, pkg.library_path()], env=env, capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    assert out.stdout.split() == [str(abi.E_DEVICE)] * 2

@@ -66,6 +66,7 @@ def test_config4_tiled_exchange_at_2048_with_eight_ranks_on_one_gpu(pkg, native_
     n, ranks = 8192, 8
     mk = lambda w: pkg.abi.make_config(technique="path", type="orbital", max_depth=8, rr_depth=5, direct_samples=-1, work_units=w,
                                        luminance_samples=100000, sample_count=1)
+    monkeypatch.setenv("DRMLT_TEST_HOOKS", "1")
     monkeypatch.setenv("DRMLT_NODE_DEVICES", ",".join(["0"] * ranks))
     node = pkg.Node(mk(n), sd, device_mask=1)
     monkeypatch.delenv("DRMLT_NODE_DEVICES")

@@ -61,6 +61,7 @@ def test_node_with_two_ranks_on_one_gpu_equals_single_context(pkg, native_lib, m
     threaded run, tiled develop, summed stats == one context with twice the chains."""
     sd = pkg.scenes.cornell_c2(64)
     n, total = 2048, 64 * 64 * 4
+    monkeypatch.setenv("DRMLT_TEST_HOOKS", "1")
     monkeypatch.setenv("DRMLT_NODE_DEVICES", "0,0")
     node = pkg.Node(_cfg(pkg, n), sd, device_mask=1)
     monkeypatch.delenv("DRMLT_NODE_DEVICES")
