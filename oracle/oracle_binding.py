@@ -49,6 +49,7 @@ def lib(native=False):
         L.oracle_eval_paths.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
         L.oracle_seed.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, C.POINTER(C.c_double)]
         L.oracle_seed_pool.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.POINTER(C.c_double)]
+        L.oracle_seed_indices.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_void_p, C.POINTER(C.c_double)]
         L.oracle_run.argtypes = [C.c_void_p, C.c_uint64, C.c_int]
         L.oracle_film_read.argtypes = [C.c_void_p, C.c_void_p]
         L.oracle_develop.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
@@ -129,6 +130,14 @@ class Oracle:
     def seed(self, seed, chain_offset=0):
         b = C.c_double()
         self._chk(self.L.oracle_seed(self.h, seed, chain_offset, C.byref(b)))
+        return b.value
+
+    def seed_with_indices(self, seed, indices, chain_offset=0, pool_chains=0):
+        """Start the chains from explicit bootstrap sample indices (e.g. Context.seed_indices() of a device context)."""
+        idx = np.ascontiguousarray(indices, dtype=np.uint32)
+        assert idx.size == self.cfg.work_units
+        b = C.c_double()
+        self._chk(self.L.oracle_seed_indices(self.h, seed, chain_offset, pool_chains, idx.ctypes.data, C.byref(b)))
         return b.value
 
     def seed_pool(self, seed, first_chain, pool_chains):

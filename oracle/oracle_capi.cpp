@@ -27,7 +27,7 @@ template <typename F> struct ArraySampler : Sampler<F> {
 struct CtxBase {
     virtual ~CtxBase() = default;
     virtual int evalPaths(const float *u, uint32_t n, uint32_t dim, drmlt_splat *out) = 0;
-    virtual int seed(uint64_t seed, uint32_t chainOffset, double *b, uint32_t poolChains = 0) = 0;
+    virtual int seed(uint64_t seed, uint32_t chainOffset, double *b, uint32_t poolChains = 0, const uint32_t *indices = nullptr) = 0;
     virtual int run(uint64_t total, int nthreads) = 0;
     virtual int filmRead(float *out) = 0;
     virtual int developImage(const float *direct, float *out) = 0;
@@ -128,7 +128,10 @@ template <typename F> struct Ctx : CtxBase {
     // poolChains > 0: ONE seed pool for a job split over several participants (the product's drmlt_seed_pool):
     // bootstrap stream 0, sized for poolChains chains, poolChains seeds drawn and sorted; this context takes seeds and
     // chain ids [chainOffset, chainOffset + work_units). Every participant finds the same list and the same b.
-    int seed(uint64_t seedv, uint32_t chainOffset, double *bOut, uint32_t poolChains = 0) override {
+    // indices != nullptr: the chains start from THESE bootstrap samples (work_units sample indices, e.g. the ones a device
+    // context picked: its fp32 luminances shift the CDF under the picks) instead of the oracle's own
+    // picks; b still comes from the oracle's bootstrap. Lets a test run the very same chains on both sides.
+    int seed(uint64_t seedv, uint32_t chainOffset, double *bOut, uint32_t poolChains = 0, const uint32_t *indices = nullptr) override {
         const bool pool = poolChains > 0;
         if (pool && (uint64_t) chainOffset + (uint64_t) cfg.work_units > poolChains) { error = "seed pool does not cover this context's chains"; return DRMLT_E_INVALID; }
         const uint32_t bootStream = pool ? 0u : chainOffset;
@@ -142,6 +145,20 @@ template <typename F> struct Ctx : CtxBase {
             : bdpt ? generateSeeds<F>(beval, boot, lumSamples, nSelect, seeds)
                    : generateSeeds<F>(eval, boot, lumSamples, nSelect, seeds);
         if (pool && b != 0) seeds.assign(seeds.begin() + chainOffset, seeds.begin() + chainOffset + cfg.work_units);
+        if (indices && b != 0) {
+            ReplayableSampler<F> rs(&boot);
+            SplatList<F> list;
+            seeds.clear();
+            for (int i = 0; i < cfg.work_units; ++i) {
+                const uint32_t idx = indices[i];
+                const int depth = mmlt ? (int) (idx % (uint32_t) cfg.max_depth) + 1 : -1; // pathsampler.cpp:884-890
+                rs.setSampleIndex(idx);
+                rs.depth = depth;
+                if (mmlt) meval(rs, list, nullptr); else if (bdpt) beval(rs, list, nullptr); else eval(rs, list, nullptr);
+                if (!(list.luminance > 0)) { error = "seed index with zero luminance in the oracle's arithmetic"; return DRMLT_E_REPLAY; }
+                seeds.push_back(PathSeed{idx, (double) list.luminance, depth});
+            }
+        }
         if (b == 0) { error = "The average image luminance appears to be zero!"; return DRMLT_E_ZERO_LUM; }
         if (cfg.acceptance_map) b = 1.0;                               // drmlt.cpp:550-552
         else if (cfg.average_luminance != -1.0f) b = cfg.average_luminance; // :555-558
@@ -458,6 +475,7 @@ const char *oracle_last_error(void *p) { return static_cast<CtxBase *>(p)->error
 
 int oracle_eval_paths(void *p, const float *u, uint32_t n, uint32_t dim, drmlt_splat *out) { GUARD(static_cast<CtxBase *>(p)->evalPaths(u, n, dim, out)) }
 int oracle_seed(void *p, uint64_t seed, uint32_t chain_offset, double *b) { GUARD(static_cast<CtxBase *>(p)->seed(seed, chain_offset, b)) }
+int oracle_seed_indices(void *p, uint64_t seed, uint32_t chain_offset, uint32_t pool_chains, const uint32_t *indices, double *b) { GUARD(static_cast<CtxBase *>(p)->seed(seed, chain_offset, b, pool_chains, indices)) }
 int oracle_seed_pool(void *p, uint64_t seed, uint32_t first_chain, uint32_t pool_chains, double *b) { GUARD(static_cast<CtxBase *>(p)->seed(seed, first_chain, b, pool_chains)) }
 int oracle_run(void *p, uint64_t total, int nthreads) { GUARD(static_cast<CtxBase *>(p)->run(total, nthreads)) }
 int oracle_film_read(void *p, float *out) { GUARD(static_cast<CtxBase *>(p)->filmRead(out)) }

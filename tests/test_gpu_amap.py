@@ -73,21 +73,23 @@ def test_one_mutation_marks_the_seed_pixels(pkg, ob, tech, kernel, native_lib, m
 
 
 @pytest.mark.parametrize("name,kw,tol", [
-    ("cornell_c2", dict(type="orbital"), 0.08),
-    ("cornell_c2", dict(type="green"), 0.08),
-    ("cornell_c2", dict(type="mira", timid_after_large=1), 0.08),
-    ("caustic_c5", dict(technique="mmlt", type="orbital", max_depth=6, fix_emitter_path=1, luminance_samples=1000), 0.12),
-    ("glass_sphere", dict(technique="bdpt", type="orbital"), 0.15),
+    ("cornell_c2", dict(type="orbital"), 0.06),
+    ("cornell_c2", dict(type="green"), 0.06),
+    ("cornell_c2", dict(type="mira", timid_after_large=1), 0.06),
+    ("caustic_c5", dict(technique="mmlt", type="orbital", max_depth=6, fix_emitter_path=1, luminance_samples=1000), 0.10),
+    ("glass_sphere", dict(technique="bdpt", type="orbital"), 0.12),
 ], ids=["path-orbital", "path-green", "path-mira-timid", "config5-mmlt", "bdpt"])
 def test_map_matches_the_oracle_pixel_by_pixel(pkg, ob, name, kw, tol, native_lib):
-    """Device and oracle run the same addressed chains: the two maps agree pixel by pixel except for the marks of the few
-    chains that left the oracle's trajectory (an acceptance decided differently in fp32: <= 3-5 % of chains after 32
-    mutations, each displacing its later marks). Tolerance = L1 distance / total mass, stated per case."""
+    """Device and oracle run the same addressed chains from the same seeds (the oracle is handed the device's seed picks:
+    its own differ where fp32 luminances shift the CDF): the two maps agree pixel by pixel except for
+    the marks of the few chains that left the oracle's trajectory (an acceptance decided differently in fp32: <= 3-5 % of
+    chains after 32 mutations, each displacing its later marks). Tolerance = L1 distance / total mass, stated per case."""
     res = 64
     sd = getattr(pkg.scenes, name)(res)
     n_chains, n_mut = 4096, 32
     cfg, ctx, orc = make(pkg, ob, sd, work_units=n_chains, **kw)
-    assert ctx.seed(0x5EED) == 1.0 and orc.seed(0x5EED) == 1.0          # drmlt.cpp:550-552
+    assert ctx.seed(0x5EED) == 1.0                                       # drmlt.cpp:550-552
+    assert orc.seed_with_indices(0x5EED, ctx.seed_indices()) == 1.0
     ctx.run(n_chains * n_mut)
     orc.run(n_chains * n_mut, 8)
     fg, fo = ctx.film().astype(np.float64), orc.film().astype(np.float64)

@@ -352,7 +352,9 @@ def test_chain_kernel_generations_run_the_same_chains(pkg, ob, kw, native_lib):
         results.append((ctx.chain_state(34), ctx.stats(), ctx.film()))
     (c0, u0), s0, f0 = results[0]
     for (c, u), s, f in results[1:]:
-        assert np.array_equal(u, u0) and np.array_equal(c["luminance"], c0["luminance"])
+        # states are bit-equal (every proposal function is compiled without contraction); f(u) itself is evaluated by two
+        # different compilations of the path step and may differ in the last bit
+        assert np.array_equal(u, u0) and np.allclose(c["luminance"], c0["luminance"], rtol=2e-6)
         for k in ("first", "large", "bold", "second", "second_large", "second_bold", "overall"):
             assert getattr(s, k + "_base") == getattr(s0, k + "_base") and getattr(s, k + "_acc") == getattr(s0, k + "_acc")
         assert s.rays == s0.rays and s.path_evals == s0.path_evals and s.accepted == s0.accepted

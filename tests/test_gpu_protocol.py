@@ -1,6 +1,7 @@
-"""SURVEY 8(d) parity protocol (tools/parity_protocol.py) at a reduced size: N independent GPU and oracle renders against
-one high-spp path-traced reference. The full-size run (N = 16, 64 x 64, 1024 mutations/pixel, 65 536-spp reference) is kept
-in profiles/r02_parity_protocol.json and quoted by bench.py."""
+"""SURVEY 8(d) parity protocol (tools/parity_protocol.py) at a reduced size: N independent device renders and N independent
+oracle renders (different seeds on the two sides), compared with each other (two-sample, reference-free) and with an
+independent reference. The full-size runs (N = 16, 64 x 64, 1024 mutations/pixel) for configs 2, 3, 5 and bdpt are kept in
+profiles/r03_parity_protocol_*.json and quoted by bench.py."""
 import json
 import os
 import subprocess
@@ -12,18 +13,20 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_protocol_items_1_to_3(tmp_path, native_lib):
+@pytest.mark.parametrize("config,extra", [("c2", ["--ref-spp", "32768"]), ("c5", ["--ref-samples-per-pixel", "1024"])])
+def test_protocol(tmp_path, native_lib, config, extra):
     out = str(tmp_path / "p.json")
-    subprocess.run([sys.executable, os.path.join(ROOT, "tools", "parity_protocol.py"), "--res", "32", "--spp", "512", "--n", "8",
-                    "--ref-spp", "32768", "--chains", "1024", "--threads", "8", "--out", out], check=True, capture_output=True, timeout=900)
+    subprocess.run([sys.executable, os.path.join(ROOT, "tools", "parity_protocol.py"), "--config", config, "--res", "32", "--spp", "512",
+                    "--n", "8", "--chains", "1024", "--threads", "8", "--out", out] + extra, check=True, capture_output=True, timeout=900)
     r = json.load(open(out))
-    # (1) unbiased: the error of the mean of n renders falls like 1 / n on both sides (reference noise subtracted)
+    # (1) same expectation: the two means differ by what their own noise explains (a bias the size of ONE render's noise
+    # would give a ratio ~ 8 here)
+    assert r["two_sample"]["ratio"] < 2.0, r["two_sample"]
+    # (2) equal budget: per-render noise within 10 % (+ 3 standard errors of the comparison itself at N = 8)
+    assert abs(r["equal_budget_relative_difference"]) < 0.10 + 3 * r["equal_budget_standard_error"], r["noise_single_render_about_own_mean"]
+    # (3) against the independent reference: the error of the mean of n renders falls like 1 / n on both sides
     s = r["loglog_slope_vs_n_after_subtracting_reference_noise"]
-    assert -1.2 < s["gpu"] < -0.8 and -1.2 < s["oracle"] < -0.8, s
-    # (2) equal budget: |rMSE_gpu - rMSE_oracle| / rMSE_oracle < 10 %
-    assert r["equal_budget_relative_difference"] < 0.10, r["rmse_single_render"]
-    # the two means are the same image up to their own noise: far closer to each other than either is to the reference
-    assert r["mean_image_gpu_vs_oracle_rmse"] < 0.5 * r["rmse_of_mean_of_n"]["gpu"][-1]
-    # (3) only asserted where the oracle meets it too
+    lo = -1.25 if config == "c2" else -1.4      # (the caustic's reference is itself noisy: its subtraction widens the band)
+    assert lo < s["gpu"] < -0.7 and lo < s["oracle"] < -0.7, s
     b = r["budget_mutations_per_pixel_where_both_meet_1e-3"]
     assert b is None or b <= 8 * 512

@@ -1,15 +1,22 @@
-"""SURVEY 8(d) parity protocol, items (1)-(3), on the GPU box:
+"""SURVEY 8(d) parity protocol on the GPU box, for every measured configuration:
 
-  (1) unbiasedness: N independent GPU renders and N oracle renders (CPU restatement, fp64) of config 2's scene at the same
-      budget, against one high-spp plain path-traced reference of the same integrand; the rMSE of the mean of the first n
-      renders must fall ~ 1/n;
-  (2) equal budget: |rMSE_gpu - rMSE_oracle| / rMSE_oracle < 10 % (mean over the N single renders);
-  (3) the budget at which BOTH meet north_star's rMSE < 1e-3 (mean of n renders of budget B ~ budget n B).
+  python tools/parity_protocol.py --config c2|c3|c5|bdpt [--res 64] [--spp 1024] [--n 16] [--out profiles/r03_parity_protocol_<config>.json]
 
-  python tools/parity_protocol.py [--res 64] [--spp 512] [--n 16] [--ref-spp 65536] [--out profiles/r02_parity_protocol.json]
+N device renders (HIP, fp32, through the C-ABI) and N oracle renders (CPU restatement, fp64) of the same scene / config /
+budget. Unlike round 2's run the two sides use DIFFERENT seeds (device 1000 + i, oracle 501000 + i): they are independent
+estimators, so the comparisons below are statistics about the two implementations, not a restatement of chain-by-chain
+tracking (that is what tests/test_gpu_*.py::test_chains_track_the_oracle cover).
 
-rMSE = mean((I - R)^2 / (R^2 + eps)), eps = 1e-2 mean(R)^2, on luminance. The reference is path traced on the
-device (the oracle's own path tracer agrees with it, tests/test_gpu_parity.py); its residual noise ~ 1 / ref-spp is reported.
+  (1) same expectation, reference-free: rMSE between the mean of the N device renders and the mean of the N oracle renders,
+      against the level two unbiased estimators of ONE image would show, (s_gpu + s_oracle) / N with s = mean rMSE of a
+      single render about its own side's mean (x N / (N - 1)); reported as a ratio (1 = indistinguishable; a bias of the
+      size of one render's noise would give ~ N);
+  (2) equal budget: per-render noise s_gpu vs s_oracle, relative difference (bound 10 %), with its standard error;
+  (3) against an independent reference of the same integrand -- technique=path: device path tracer, two halves (its own
+      residual reported); technique=bdpt / mmlt: the oracle's independent-sample BDPT image (fp64, CPU) -- rMSE of the mean of
+      n renders for n = 1, 2, 4 ..., log-log slope (ideal -1), and the budget at which both sides meet north_star's 1e-3.
+
+rMSE = mean((I - R)^2 / (R^2 + eps)), eps = 1e-2 mean(R)^2, on luminance.
 """
 import argparse, json, os, sys, time
 import numpy as np
@@ -17,6 +24,17 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import __graft_entry__ as g
 
 LUMW = np.array([0.212671, 0.715160, 0.072169])
+
+CONFIGS = {
+    "c2": dict(scene="cornell_c2", cfg=dict(technique="path", type="orbital", max_depth=8, rr_depth=5), ref="pt",
+               what="Cornell box, drmlt technique=path type=orbital (BASELINE configs[1])"),
+    "c3": dict(scene="door_c3", cfg=dict(technique="path", type="green", max_depth=8, rr_depth=5), ref="pt",
+               what="door scene (occluded light, rough-conductor floor), drmlt technique=path type=green (BASELINE configs[2])"),
+    "c5": dict(scene="caustic_c5", cfg=dict(technique="mmlt", type="orbital", max_depth=6, fix_emitter_path=1), ref="bdpt",
+               what="glass caustic, drmlt technique=mmlt type=orbital fixEmitterPath, RADIANCE output (BASELINE configs[4] without acceptanceMap)"),
+    "bdpt": dict(scene="cornell_c2", cfg=dict(technique="bdpt", type="orbital", max_depth=8, rr_depth=5), ref="bdpt",
+                 what="Cornell box, drmlt technique=bdpt type=orbital, directSampling=true"),
+}
 
 
 def rel_mse(img, ref):
@@ -26,60 +44,95 @@ def rel_mse(img, ref):
 
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
     ap.add_argument("--res", type=int, default=64)
-    ap.add_argument("--spp", type=int, default=512)
+    ap.add_argument("--spp", type=int, default=1024)
     ap.add_argument("--n", type=int, default=16)
-    ap.add_argument("--ref-spp", type=int, default=65536)
+    ap.add_argument("--ref-spp", type=int, default=65536, help="device path tracer (technique=path)")
+    ap.add_argument("--ref-samples-per-pixel", type=int, default=8192, help="oracle BDPT samples per pixel (bdpt / mmlt)")
     ap.add_argument("--chains", type=int, default=4096)
     ap.add_argument("--threads", type=int, default=os.cpu_count() or 8)
     ap.add_argument("--out", default="")
     a = ap.parse_args()
+    conf = CONFIGS[a.config]
     pkg, ob = g.load_package(), g.load_oracle()
     ob.build(native=True)   # -O3 -march=native build of the restatement for this host
     abi = pkg.abi
-    sd = pkg.scenes.cornell_c2(a.res)
-    kw = dict(type="orbital", max_depth=8, rr_depth=5, direct_samples=-1, work_units=a.chains, sample_count=a.spp, luminance_samples=100000)
+    sd = pkg.scenes.SCENES[conf["scene"]](res=a.res)
+    kw = dict(direct_samples=-1, work_units=a.chains, sample_count=a.spp, luminance_samples=100000, **conf["cfg"])
     cfg = abi.make_config(**kw)
     total = a.res * a.res * a.spp
     t0 = time.time()
-    ref_ctx = pkg.Context(cfg, sd)
-    half = a.ref_spp // 2
-    ref_a, ref_b = ref_ctx.render_pt(half, seed=101), ref_ctx.render_pt(half, seed=202)   # two halves: the reference's own noise
-    ref = 0.5 * (ref_a + ref_b)
+    if conf["ref"] == "pt":
+        ref_ctx = pkg.Context(cfg, sd)
+        half = a.ref_spp // 2
+        ref_a, ref_b = ref_ctx.render_pt(half, seed=101), ref_ctx.render_pt(half, seed=202)
+        ref_ctx.close()
+        ref_what = "device path tracer, 2 x %d spp" % half
+    else:
+        rkw = dict(kw, technique="bdpt", rr_depth=kw.get("rr_depth", 100))
+        rkw.pop("fix_emitter_path", None)
+        ro = ob.Oracle(abi, abi.make_config(**rkw), sd, precision=64, native=True)
+        nsamp = a.res * a.res * a.ref_samples_per_pixel // 2
+        ref_a, ref_b = ro.bdpt_render(nsamp, seed=101, nthreads=a.threads), ro.bdpt_render(nsamp, seed=202, nthreads=a.threads)
+        ro.close()
+        ref_what = "oracle's independent-sample BDPT image (fp64, CPU), 2 x %d samples per pixel" % (a.ref_samples_per_pixel // 2)
+    ref = 0.5 * (ref_a.astype(np.float64) + ref_b.astype(np.float64))
     ref_noise = rel_mse(ref_a, ref_b) / 4.0            # Var(mean of halves) = Var(difference) / 4
+    print("reference: %s, own rMSE %.3g (%.0f s)" % (ref_what, ref_noise, time.time() - t0), flush=True)
     gpu, orc = [], []
+    t_gpu = t_orc = 0.0
     for i in range(a.n):
+        t = time.time()
         c = pkg.Context(cfg, sd)
-        c.seed(1000 + i); c.run(total); gpu.append(c.develop()); c.close()
+        c.seed(1000 + i); c.run(total); gpu.append(c.develop().astype(np.float64)); c.close()
+        t_gpu += time.time() - t
+        t = time.time()
         o = ob.Oracle(abi, cfg, sd, precision=64, native=True)
-        o.seed(1000 + i); o.run(total, a.threads); orc.append(o.develop()); o.close()
+        o.seed(501000 + i); o.run(total, a.threads); orc.append(o.develop().astype(np.float64)); o.close()
+        t_orc += time.time() - t
         print("render %d/%d  gpu rMSE %.4g  oracle rMSE %.4g  (%.0f s)" % (i + 1, a.n, rel_mse(gpu[-1], ref), rel_mse(orc[-1], ref), time.time() - t0), flush=True)
     gpu, orc = np.array(gpu), np.array(orc)
+    N = a.n
+    mg, mo = gpu.mean(0), orc.mean(0)
+    pooled = 0.5 * (mg + mo)
+    # (2) per-render noise about the side's own mean (unbiased: x N / (N - 1)), measured with the pooled mean as denominator image
+    sg = np.array([rel_mse(x - mg + pooled, pooled) for x in gpu]) * N / (N - 1)
+    so = np.array([rel_mse(x - mo + pooled, pooled) for x in orc]) * N / (N - 1)
+    equal_budget = (sg.mean() - so.mean()) / so.mean()
+    equal_budget_se = float(np.sqrt(sg.var(ddof=1) / N + so.var(ddof=1) / N) / so.mean())
+    # (1) two-sample: rMSE between the two means vs what two unbiased estimators of one image would show
+    between = rel_mse(mg - mo + pooled, pooled)
+    expected = (sg.mean() + so.mean()) / N
+    # (3) against the reference
     single_g = np.array([rel_mse(x, ref) for x in gpu]); single_o = np.array([rel_mse(x, ref) for x in orc])
-    ns = [n for n in (1, 2, 4, 8, 16, 32) if n <= a.n]
-    # mean over disjoint groups of n renders, so that every render is used at every n
+    ns = [n for n in (1, 2, 4, 8, 16, 32) if n <= N]
     def curve(imgs):
-        return [float(np.mean([rel_mse(imgs[k:k + n].mean(0), ref) for k in range(0, a.n - n + 1, n)])) for n in ns]
+        return [float(np.mean([rel_mse(imgs[k:k + n].mean(0), ref) for k in range(0, N - n + 1, n)])) for n in ns]
     cg, co = curve(gpu), curve(orc)
     slope = lambda c: float(np.polyfit(np.log(ns), np.log(np.maximum(np.array(c) - ref_noise, 1e-12)), 1)[0])
-    equal_budget = abs(single_g.mean() - single_o.mean()) / single_o.mean()
     meet = [n * a.spp for n, x, y in zip(ns, cg, co) if x < 1e-3 and y < 1e-3]
+    out_name = a.out or ""
     out = {
         "command": "python tools/parity_protocol.py " + " ".join(sys.argv[1:]),
-        "scene": "cornell_c2 %dx%d, drmlt technique=path type=orbital, %d chains, %d mutations/pixel per render" % (a.res, a.res, a.chains, a.spp),
-        "n_renders": a.n, "reference": "device path tracer, %d spp (two independent halves); residual rMSE of the reference itself %.3g" % (a.ref_spp, ref_noise),
-        "rmse_single_render": {"gpu_mean": float(single_g.mean()), "gpu_std": float(single_g.std()), "oracle_mean": float(single_o.mean()), "oracle_std": float(single_o.std())},
-        "rmse_of_mean_of_n": {"n": ns, "gpu": cg, "oracle": co},
+        "scene": "%s %dx%d: %s, %d chains, %d mutations/pixel per render" % (conf["scene"], a.res, a.res, conf["what"], a.chains, a.spp),
+        "n_renders": N, "seeds": "device 1000 + i, oracle 501000 + i (independent estimators)",
+        "reference": "%s; residual rMSE of the reference itself %.3g" % (ref_what, ref_noise),
+        "two_sample": {"rmse_between_means": between, "expected_if_same_expectation": expected, "ratio": between / expected,
+                       "note": "ratio ~ 1: the two means differ by no more than their own noise; a bias as large as one render's noise would give ~ %d" % N},
+        "noise_single_render_about_own_mean": {"gpu_mean": float(sg.mean()), "gpu_std": float(sg.std(ddof=1)), "oracle_mean": float(so.mean()), "oracle_std": float(so.std(ddof=1))},
+        "equal_budget_relative_difference": float(equal_budget), "equal_budget_standard_error": equal_budget_se, "equal_budget_bound": 0.10,
+        "rmse_single_render_vs_reference": {"gpu_mean": float(single_g.mean()), "gpu_std": float(single_g.std()), "oracle_mean": float(single_o.mean()), "oracle_std": float(single_o.std())},
+        "rmse_of_mean_of_n_vs_reference": {"n": ns, "gpu": cg, "oracle": co},
         "loglog_slope_vs_n_after_subtracting_reference_noise": {"gpu": slope(cg), "oracle": slope(co), "ideal": -1.0},
-        "equal_budget_relative_difference": float(equal_budget),
-        "mean_image_gpu_vs_oracle_rmse": rel_mse(gpu.mean(0), orc.mean(0)),
         "budget_mutations_per_pixel_where_both_meet_1e-3": (min(meet) if meet else None),
-        "summary": {"equal_budget_rel_diff": float(equal_budget), "bound": 0.10, "slope_gpu": slope(cg), "slope_oracle": slope(co),
+        "summary": {"config": a.config, "two_sample_ratio": between / expected, "equal_budget_rel_diff": float(equal_budget), "equal_budget_se": equal_budget_se,
+                    "bound": 0.10, "slope_gpu": slope(cg), "slope_oracle": slope(co),
                     "rmse_lt_1e-3_at_mutations_per_pixel": (min(meet) if meet else None),
                     "rmse_gpu_at_that_budget": (cg[ns.index(min(meet) // a.spp)] if meet else None),
                     "rmse_oracle_at_that_budget": (co[ns.index(min(meet) // a.spp)] if meet else None),
-                    "source": "profiles/r02_parity_protocol.json (tools/parity_protocol.py, N = %d renders each)" % a.n},
-        "seconds": time.time() - t0,
+                    "source": "%s (tools/parity_protocol.py --config %s, N = %d independent renders per side at %dx%d)" % (os.path.basename(out_name) or "stdout", a.config, N, a.res, a.res)},
+        "seconds": {"total": time.time() - t0, "gpu_renders": t_gpu, "oracle_renders": t_orc},
     }
     print(json.dumps(out["summary"]))
     if a.out:
