@@ -64,6 +64,9 @@ public:
         m_cfg.kelemen_style_weights = props.getBoolean("kelemenStyleWeights", true);
         m_cfg.kelemen_style_mutation = 1;
         m_twoStage = props.getBoolean("twoStage", false);
+        // "Used internally to let the nested rendering process of a two-stage MLT approach know that it is running the first
+        // stage" (drmlt.cpp:282-284): such an instance renders no first stage of its own and no direct image (:406,420,479)
+        m_firstStage = props.getBoolean("firstStage", false);
         m_firstStageSizeReduction = props.getInteger("firstStageSizeReduction", 16);
         m_cfg.timeout_s = props.getInteger("timeout", 0);
         m_cfg.no_light_image = props.getBoolean("lightImage", true) ? 0 : 1;
@@ -79,6 +82,7 @@ public:
         stream->read(&m_cfg, sizeof m_cfg);
         m_deviceMask = (uint32_t) stream->readInt();
         m_twoStage = stream->readBool();
+        m_firstStage = stream->readBool();
         m_firstStageSizeReduction = stream->readInt();
         m_hasSeed = stream->readBool();
         m_seed = (uint64_t) stream->readInt();
@@ -89,6 +93,7 @@ public:
         stream->write(&m_cfg, sizeof m_cfg);
         stream->writeInt((int) m_deviceMask);
         stream->writeBool(m_twoStage);
+        stream->writeBool(m_firstStage);
         stream->writeInt(m_firstStageSizeReduction);
         stream->writeBool(m_hasSeed);
         stream->writeInt((int) m_seed);
@@ -151,7 +156,8 @@ public:
         // two-stage MLT (drmlt.cpp:406-418): the nested first stage is a second context on a reduced film; its
         // developed image becomes the luminance image of the full render (util.cpp:96-199)
         std::vector<float> importance;
-        if (m_twoStage) {
+        const bool nested = m_twoStage && m_firstStage; // drmlt.cpp:420
+        if (m_twoStage && !m_firstStage) {
             Log(EInfo, "Executing first MLT stage");
             drmlt_scene small = sc;
             small.camera.width = std::max(1, crop.x / m_firstStageSizeReduction);
@@ -186,7 +192,7 @@ public:
 
         // separate direct pass stays on the host integrator (util.cpp:30-92), exactly as in the reference
         ref<Bitmap> directImage;
-        if (m_cfg.direct_samples > 0) {
+        if (m_cfg.direct_samples > 0 && !nested) { // drmlt.cpp:479
             directImage = BidirectionalUtils::renderDirectComponent(scene, sceneResID, sensorResID, queue, job,
                                                                     m_cfg.direct_samples);
             if (directImage == NULL) { drmlt_node_destroy(node); return false; }
@@ -382,7 +388,7 @@ private:
 
     drmlt_config m_cfg;
     uint32_t m_deviceMask;
-    bool m_twoStage = false;
+    bool m_twoStage = false, m_firstStage = false;
     int m_firstStageSizeReduction = 16;
     bool m_hasSeed = false;
     uint64_t m_seed = 0;

@@ -230,7 +230,11 @@ public:
     Bitmap(EPixelFormat pf, EComponentFormat cf, const Vector2i &size) : m_pf(pf), m_cf(cf), m_size(size), m_data((size_t) size.x * size.y * 3, 0.f) {}
     float *getFloat32Data() { return m_data.data(); }             // bitmap.h:1216
     const float *getFloat32Data() const { return m_data.data(); }
-    ref<Bitmap> convert(EPixelFormat, EComponentFormat) const { Bitmap *b = new Bitmap(m_pf, m_cf, m_size); b->m_data = m_data; return b; } // bitmap.h:685
+    // bitmap.h:685-687 (not a const member in the reference either)
+    ref<Bitmap> convert(EPixelFormat, EComponentFormat, Float gamma = 1.0f, Float multiplier = 1.0f, int intent = 0) {
+        (void) gamma; (void) multiplier; (void) intent;
+        Bitmap *b = new Bitmap(m_pf, m_cf, m_size); b->m_data = m_data; return b;
+    }
     const Vector2i &getSize() const { return m_size; }
 private:
     EPixelFormat m_pf; EComponentFormat m_cf; Vector2i m_size;

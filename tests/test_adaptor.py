@@ -121,7 +121,7 @@ def test_parameters_statistics_progress_and_direct_pass(pkg, harness_mock, tmp_p
     assert cfg.direct_samples == 16 and cfg.no_direct_sampling == 0       # reference defaults: directSamples=16, directSampling=true
     assert cfg.work_units == -1 and cfg.average_luminance == -1.0 and mask == 5 and cfg.struct_size == C.sizeof(abi.Config)
     assert open(prefix + ".seed").read().strip() == "99"
-    assert os.path.getsize(prefix + ".ser") == C.sizeof(abi.Config) + 4 + 1 + 4 + 1 + 4   # Integrator::serialize round trip payload
+    assert os.path.getsize(prefix + ".ser") == C.sizeof(abi.Config) + 4 + 1 + 1 + 4 + 1 + 4   # Integrator::serialize round trip payload (mask, twoStage, firstStage, reduction, hasSeed, seed)
     text = [t for _, t in log]
     # the seven StatsCounters of drmlt_proc.cpp:34-49
     for name, pct in (("Accepted 1st-stage mutations", 10), ("Accepted large mutations in the 1st stage", 20),

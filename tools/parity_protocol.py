@@ -13,8 +13,11 @@ tracking (that is what tests/test_gpu_*.py::test_chains_track_the_oracle cover).
       size of one render's noise would give ~ N);
   (2) equal budget: per-render noise s_gpu vs s_oracle, relative difference (bound 10 %), with its standard error;
   (3) against an independent reference of the same integrand -- technique=path: device path tracer, two halves (its own
-      residual reported); technique=bdpt / mmlt: the oracle's independent-sample BDPT image (fp64, CPU) -- rMSE of the mean of
-      n renders for n = 1, 2, 4 ..., log-log slope (ideal -1), and the budget at which both sides meet north_star's 1e-3.
+      residual reported); technique=bdpt: the oracle's independent-sample BDPT image (fp64, CPU); technique=mmlt: the sum over
+      depths 1..maxDepth of the oracle's independent-sample multiplexed estimator (mmlt drops directly visible emitters,
+      pathsampler.cpp:84-320, so a BDPT image is NOT its expectation) -- rMSE of the mean of n renders for n = 1, 2, 4 ...,
+      log-log slope (ideal -1), and the budget at which both sides meet north_star's 1e-3. The same curve is also computed
+      with the OTHER side's N-render mean as the reference (its noise s / N subtracted): no external estimator involved.
 
 rMSE = mean((I - R)^2 / (R^2 + eps)), eps = 1e-2 mean(R)^2, on luminance.
 """
@@ -30,7 +33,7 @@ CONFIGS = {
                what="Cornell box, drmlt technique=path type=orbital (BASELINE configs[1])"),
     "c3": dict(scene="door_c3", cfg=dict(technique="path", type="green", max_depth=8, rr_depth=5), ref="pt",
                what="door scene (occluded light, rough-conductor floor), drmlt technique=path type=green (BASELINE configs[2])"),
-    "c5": dict(scene="caustic_c5", cfg=dict(technique="mmlt", type="orbital", max_depth=6, fix_emitter_path=1), ref="bdpt",
+    "c5": dict(scene="caustic_c5", cfg=dict(technique="mmlt", type="orbital", max_depth=6, fix_emitter_path=1), ref="mmlt",
                what="glass caustic, drmlt technique=mmlt type=orbital fixEmitterPath, RADIANCE output (BASELINE configs[4] without acceptanceMap)"),
     "bdpt": dict(scene="cornell_c2", cfg=dict(technique="bdpt", type="orbital", max_depth=8, rr_depth=5), ref="bdpt",
                  what="Cornell box, drmlt technique=bdpt type=orbital, directSampling=true"),
@@ -69,14 +72,20 @@ def main():
         ref_a, ref_b = ref_ctx.render_pt(half, seed=101), ref_ctx.render_pt(half, seed=202)
         ref_ctx.close()
         ref_what = "device path tracer, 2 x %d spp" % half
-    else:
-        rkw = dict(kw, technique="bdpt", rr_depth=kw.get("rr_depth", 100))
-        rkw.pop("fix_emitter_path", None)
-        ro = ob.Oracle(abi, abi.make_config(**rkw), sd, precision=64, native=True)
+    elif conf["ref"] == "bdpt":
+        ro = ob.Oracle(abi, cfg, sd, precision=64, native=True)
         nsamp = a.res * a.res * a.ref_samples_per_pixel // 2
         ref_a, ref_b = ro.bdpt_render(nsamp, seed=101, nthreads=a.threads), ro.bdpt_render(nsamp, seed=202, nthreads=a.threads)
         ro.close()
         ref_what = "oracle's independent-sample BDPT image (fp64, CPU), 2 x %d samples per pixel" % (a.ref_samples_per_pixel // 2)
+    else:
+        ro = ob.Oracle(abi, cfg, sd, precision=64, native=True)
+        nsamp = a.res * a.res * a.ref_samples_per_pixel // 2
+        md = conf["cfg"]["max_depth"]
+        ref_a = sum(ro.mmlt_render(d, nsamp, seed=101 + d, nthreads=a.threads)[0].astype(np.float64) for d in range(1, md + 1))
+        ref_b = sum(ro.mmlt_render(d, nsamp, seed=202 + d, nthreads=a.threads)[0].astype(np.float64) for d in range(1, md + 1))
+        ro.close()
+        ref_what = "oracle's independent-sample multiplexed estimator summed over depths 1..%d (fp64, CPU), 2 x %d samples per pixel and depth" % (md, a.ref_samples_per_pixel // 2)
     ref = 0.5 * (ref_a.astype(np.float64) + ref_b.astype(np.float64))
     ref_noise = rel_mse(ref_a, ref_b) / 4.0            # Var(mean of halves) = Var(difference) / 4
     print("reference: %s, own rMSE %.3g (%.0f s)" % (ref_what, ref_noise, time.time() - t0), flush=True)
@@ -112,6 +121,11 @@ def main():
     cg, co = curve(gpu), curve(orc)
     slope = lambda c: float(np.polyfit(np.log(ns), np.log(np.maximum(np.array(c) - ref_noise, 1e-12)), 1)[0])
     meet = [n * a.spp for n, x, y in zip(ns, cg, co) if x < 1e-3 and y < 1e-3]
+    # the same curves against the other side's N-render mean (noise of that mean: s / N, subtracted before the fit)
+    def curve_x(imgs, other_mean):
+        return [float(np.mean([rel_mse(imgs[k:k + n].mean(0), other_mean) for k in range(0, N - n + 1, n)])) for n in ns]
+    xg, xo = curve_x(gpu, mo), curve_x(orc, mg)
+    slope_x = lambda c, noise: float(np.polyfit(np.log(ns), np.log(np.maximum(np.array(c) - noise, 1e-12)), 1)[0])
     out_name = a.out or ""
     out = {
         "command": "python tools/parity_protocol.py " + " ".join(sys.argv[1:]),
@@ -125,9 +139,15 @@ def main():
         "rmse_single_render_vs_reference": {"gpu_mean": float(single_g.mean()), "gpu_std": float(single_g.std()), "oracle_mean": float(single_o.mean()), "oracle_std": float(single_o.std())},
         "rmse_of_mean_of_n_vs_reference": {"n": ns, "gpu": cg, "oracle": co},
         "loglog_slope_vs_n_after_subtracting_reference_noise": {"gpu": slope(cg), "oracle": slope(co), "ideal": -1.0},
+        "rmse_of_mean_of_n_vs_other_sides_mean": {"n": ns, "gpu_vs_oracle_mean": xg, "oracle_vs_gpu_mean": xo,
+                                                  "slope_gpu": slope_x(xg, so.mean() / N), "slope_oracle": slope_x(xo, sg.mean() / N)},
+        "noise_median_single_render": {"gpu": float(np.median(sg)), "oracle": float(np.median(so)),
+                                       "relative_difference_of_medians": float((np.median(sg) - np.median(so)) / np.median(so))},
         "budget_mutations_per_pixel_where_both_meet_1e-3": (min(meet) if meet else None),
         "summary": {"config": a.config, "two_sample_ratio": between / expected, "equal_budget_rel_diff": float(equal_budget), "equal_budget_se": equal_budget_se,
+                    "equal_budget_rel_diff_of_medians": float((np.median(sg) - np.median(so)) / np.median(so)),
                     "bound": 0.10, "slope_gpu": slope(cg), "slope_oracle": slope(co),
+                    "slope_gpu_vs_oracle_mean": slope_x(xg, so.mean() / N), "slope_oracle_vs_gpu_mean": slope_x(xo, sg.mean() / N),
                     "rmse_lt_1e-3_at_mutations_per_pixel": (min(meet) if meet else None),
                     "rmse_gpu_at_that_budget": (cg[ns.index(min(meet) // a.spp)] if meet else None),
                     "rmse_oracle_at_that_budget": (co[ns.index(min(meet) // a.spp)] if meet else None),
