@@ -60,7 +60,8 @@ DEV float kelemen_logpdf(float du) {
     return -__logf(2.f * d * 2.772588722239781f); // ln(s2/s1) = ln 16
 }
 
-struct Sampler {
+// STRIDE: floats per row of the chain-state rows in LDS (x[k] of the chain in column `lane` = lds_x[k * STRIDE + lane])
+template <uint32_t STRIDE = 64u> struct SamplerT {
     // addressing
     uint32_t key0, key1, chain, major; // major: mutation index (chains) or sample index (boot / pt)
     int mode, type;
@@ -93,7 +94,7 @@ struct Sampler {
         if (blk != b2_idx) { b2 = philox4x32_10(key0, key1, blk, major, chain, TAG_S2); b2_idx = blk; }
         return pick4(b2, idx & 3u);
     }
-    DEV float x(uint32_t k) const { return lds_x[k * 64u + lane]; }
+    DEV float x(uint32_t k) const { return lds_x[k * STRIDE + lane]; }
 
     // first-stage proposal, unwrapped (fillSpace with isFirst = true)
     DEV float y_raw(uint32_t k) {
@@ -164,6 +165,7 @@ struct Sampler {
         }
     }
 };
+typedef SamplerT<64u> Sampler;
 
 // ------------------------------------------------------------------ PSS sampler of k_mutate_v2
 // Same proposals as `Sampler`, but the Philox draws of a mutation are produced up front, by all
@@ -560,44 +562,45 @@ DEV void trav_reset_counters(Trav &T) { T.n_nodes = T.n_prims = T.it_inner = T.i
 DEV unsigned umin2(unsigned a, unsigned b) { return a < b ? a : b; }
 DEV unsigned umax2(unsigned a, unsigned b) { return a < b ? b : a; }
 
-// Advance the traversals of the lanes with `mine` set until all of them are done or, if yield_lanes > 0, at least that
-// many lanes of the wave have finished during this call.
-// StackT: int, or short when every node index and leaf reference of the scene fits 15 bits (drmlt_create decides): half
-// the LDS, which is what lets k_mutate_v4 keep 8 waves per CU on BVH scenes (measured: 1.13e8 -> 2.0e8 mutations/s on the
-// 2000-triangle soup, all of it occupancy).
-// OVF: compile the spill / refill paths in (k_mutate_v4 has a build without them for trees that fit the column: they cost
-// 4 % there even when never taken).
-// CAP: entries of the LDS column (k_mutate_v4 gives its 32-bit stacks 12 instead of 24 -- with the overflow paths the column
-// only has to hold the hot top of the stack, and 3.5 KB instead of 6.5 KB keep eight waves on a CU).
-template <class StackT, class PT, bool OVF = true, int CAP = BVH_STACK, int FEAT = 15> DEV void trav_run(const PT &P, Trav &T, bool mine, int yield_lanes) {
-    constexpr int SPILL = CAP / 2; // entries moved at a time
-    __shared__ StackT bvh_stack[(CAP + 3) * 64]; // + 3: the branch-free pushes write up to three entries above the top (lanes that hold no node: all three, from row CAP)
-    StackT *const stk = bvh_stack + (threadIdx.x & 63u); // every kernel that traces runs one wave per workgroup
-    // The LDS column holds CAP entries (+ 2 spare); a tree deeper than CAP / 3 levels can need more. Slow paths: before a
-    // node's pushes could run past the column its SPILL OLDEST entries move to this lane's column of an overflow area in
-    // memory and the rest slides down; a pop that finds the column empty brings the newest SPILL back.
-    const size_t ovf_col = (size_t) blockIdx.x * 64u + (threadIdx.x & 63u);
-    auto spill = [&]() {
+// One wave's traversal machinery: the LDS stack column of this lane, the buffer resources of the node / primitive arrays, and
+// `step` = ONE iteration for the whole wave (nodes or leaves, by vote). Two loops drive it: trav_run (every lane keeps the
+// ray it was given until a slice ends) and k_mutate_v5's pool loop (a lane that finishes a ray takes the next one from
+// the wave's ray queue inside the loop).
+template <class StackT, class PT, bool OVF = true, int CAP = BVH_STACK, int FEAT = 15> struct TravLoop {
+    static constexpr int SPILL = CAP / 2; // entries moved at a time
+    static constexpr unsigned TRAV_NO_FETCH = 0xfffff000u;
+    const PT &P;
+    StackT *const stk;
+    const size_t ovf_col;
+    const bool has_ovf;
+    const __amdgpu_buffer_rsrc_t r_bvh, r_prm;
+    // `column`: this lane's column of a (CAP + 3) x 64 array in LDS. The column holds CAP entries (+ 3 spare: the branch-free
+    // pushes write up to three entries above the top; lanes that hold no node: all three, from row CAP). A tree deeper than
+    // CAP / 3 levels can need more. Slow paths: before a node's pushes could run past the column its SPILL OLDEST entries move
+    // to this lane's column of an overflow area in memory and the rest slides down; a pop that finds the column empty brings
+    // the newest SPILL back. Node and primitive records are raw buffers (byte offsets; drmlt_create refuses arrays of 2 GiB
+    // and more).
+    DEV TravLoop(const PT &P_, StackT *column)
+        : P(P_), stk(column), ovf_col((size_t) blockIdx.x * 64u + (threadIdx.x & 63u)), has_ovf(OVF && P_.bvh_overflow != nullptr),
+          r_bvh(__builtin_amdgcn_make_buffer_rsrc((void *) (uintptr_t) P_.bvh, 0, 0x80000000u, 0x00020000)),
+          r_prm(__builtin_amdgcn_make_buffer_rsrc((void *) (uintptr_t) P_.prims, 0, 0x80000000u, 0x00020000)) {}
+    DEV void spill(Trav &T) const {
         for (int i = 0; i < SPILL; ++i) P.bvh_overflow[(size_t) (T.ovf + i) * P.bvh_ovf_lanes + ovf_col] = (int) stk[i * 64];
         for (int i = SPILL; i < T.sp; ++i) stk[(i - SPILL) * 64] = stk[i * 64];
         T.sp -= SPILL; T.ovf += SPILL;
-    };
-    auto refill = [&]() {
+    }
+    DEV void refill(Trav &T) const {
         T.ovf -= SPILL;
         for (int i = 0; i < SPILL; ++i) stk[i * 64] = (StackT) P.bvh_overflow[(size_t) (T.ovf + i) * P.bvh_ovf_lanes + ovf_col];
         T.sp = SPILL;
-    };
-    const bool has_ovf = OVF && P.bvh_overflow != nullptr; // wave-uniform
-    // node and primitive records as raw buffers (byte offsets; drmlt_create refuses arrays of 2 GiB and more)
-    const __amdgpu_buffer_rsrc_t r_bvh = __builtin_amdgcn_make_buffer_rsrc((void *) (uintptr_t) P.bvh, 0, 0x80000000u, 0x00020000);
-    const __amdgpu_buffer_rsrc_t r_prm = __builtin_amdgcn_make_buffer_rsrc((void *) (uintptr_t) P.prims, 0, 0x80000000u, 0x00020000);
-    constexpr unsigned TRAV_NO_FETCH = 0xfffff000u;
-    int finished = 0;
-    for (;;) {
+    }
+    // Advance the lanes with `mine` set by one iteration. Returns, per lane, whether its traversal FINISHED in this iteration;
+    // `any` (wave-uniform): some lane still had a traversal to advance (false: nothing was done).
+    DEV bool step(Trav &T, bool mine, bool &any) const {
         const bool run = mine && T.active;
         const unsigned long long m_inner = __ballot(run && T.cur >= 0), m_leaf = __ballot(run && T.cur < 0);
-        if (!m_inner && !m_leaf) break;
-        if (yield_lanes > 0 && finished >= yield_lanes) break;
+        any = (m_inner | m_leaf) != 0ull;
+        if (!any) return false;
         bool done_now = false;
         // Both blocks below are STRAIGHT-LINE code for the whole wave: a lane that does not hold the kind being advanced
         // computes on whatever its registers hold and keeps nothing of it (its pushes land in the spare rows above the
@@ -607,7 +610,7 @@ template <class StackT, class PT, bool OVF = true, int CAP = BVH_STACK, int FEAT
         if (__popcll(m_inner) * P.trace_vote >= __popcll(m_leaf) * 16) { // a leaf test costs about 0.4 node tests: see drmlt_capi.cpp
             T.it_inner++;
             const bool ok = run && T.cur >= 0;
-            if (has_ovf) { if (ok && T.sp > CAP - 3) spill(); }
+            if (has_ovf) { if (ok && T.sp > CAP - 3) spill(T); }
             // The node's rows (16 bytes each: lox, hix, loy, hiy, loz, hiz, child) are fetched with the lo / hi rows of an
             // axis SWAPPED where the ray runs against it: the first of each pair then holds the four NEAR planes, the second
             // the four FAR ones, and the slab test needs no per-axis min / max (24 of ~110 vector instructions per node).
@@ -671,7 +674,7 @@ template <class StackT, class PT, bool OVF = true, int CAP = BVH_STACK, int FEAT
             bool fin = !has0 && sp == 0;
             T.cur = ok && !fin ? (has0 ? child_of(k0) : top) : T.cur;
             T.sp = ok ? (has0 ? sp : below) : T.sp;
-            if (has_ovf) { if (ok && fin && T.ovf > 0) { refill(); T.cur = stk[--T.sp * 64]; fin = false; } }
+            if (has_ovf) { if (ok && fin && T.ovf > 0) { refill(T); T.cur = stk[--T.sp * 64]; fin = false; } }
             done_now = ok && fin;
             T.active = T.active && !done_now;
         } else {
@@ -699,10 +702,32 @@ template <class StackT, class PT, bool OVF = true, int CAP = BVH_STACK, int FEAT
             bool fin = found || sp == 0;
             T.cur = ok && !fin ? top : T.cur;
             T.sp = ok ? below : T.sp;
-            if (has_ovf) { if (ok && !found && sp == 0 && T.ovf > 0) { refill(); T.cur = stk[--T.sp * 64]; fin = false; } }
+            if (has_ovf) { if (ok && !found && sp == 0 && T.ovf > 0) { refill(T); T.cur = stk[--T.sp * 64]; fin = false; } }
             done_now = ok && fin;
             T.active = T.active && !done_now;
         }
+        return done_now;
+    }
+};
+
+// Advance the traversals of the lanes with `mine` set until all of them are done or, if yield_lanes > 0, at least that
+// many lanes of the wave have finished during this call.
+// StackT: int, or short when every node index and leaf reference of the scene fits 15 bits (drmlt_create decides): half
+// the LDS, which is what lets k_mutate_v4 keep 8 waves per CU on BVH scenes (measured: 1.13e8 -> 2.0e8 mutations/s on the
+// 2000-triangle soup, all of it occupancy).
+// OVF: compile the spill / refill paths in (k_mutate_v4 has a build without them for trees that fit the column: they cost
+// 4 % there even when never taken).
+// CAP: entries of the LDS column (k_mutate_v4 gives its 32-bit stacks 12 instead of 24 -- with the overflow paths the column
+// only has to hold the hot top of the stack, and 3.5 KB instead of 6.5 KB keep eight waves on a CU).
+template <class StackT, class PT, bool OVF = true, int CAP = BVH_STACK, int FEAT = 15> DEV void trav_run(const PT &P, Trav &T, bool mine, int yield_lanes) {
+    __shared__ StackT bvh_stack[(CAP + 3) * 64];
+    const TravLoop<StackT, PT, OVF, CAP, FEAT> L(P, bvh_stack + (threadIdx.x & 63u)); // every kernel that traces runs one wave per workgroup
+    int finished = 0;
+    for (;;) {
+        if (yield_lanes > 0 && finished >= yield_lanes) break;
+        bool any;
+        const bool done_now = L.step(T, mine, any);
+        if (!any) break;
         finished += __popcll(__ballot(done_now));
     }
 }

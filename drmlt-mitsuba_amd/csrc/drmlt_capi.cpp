@@ -520,13 +520,14 @@ drmlt_ctx *drmlt_create(const drmlt_config *cfg, const drmlt_scene *scene, int d
     P.debug = 0;
     if (const char *d = getenv("DRMLT_DEBUG")) P.debug = atoi(d);
     P.kernel_variant = 4;
-    if (const char *k = getenv("DRMLT_KERNEL")) { int kv = atoi(k); P.kernel_variant = kv == 3 ? 3 : 4; }
+    if (const char *k = getenv("DRMLT_KERNEL")) { int kv = atoi(k); P.kernel_variant = kv == 3 ? 3 : (kv == 5 ? 5 : 4); }
     P.features = 0;
     for (const DBsdf &b : bsdfs) P.features |= b.type == DRMLT_BSDF_ROUGHCONDUCTOR ? 1 : (b.type == DRMLT_BSDF_DIELECTRIC ? 2 : 0);
     for (const DPrim &g : ctx->prims) if (g.type == PRIM_SPHERE) P.features |= 4;
     if (P.use_bvh) P.features |= 8;
     if (getenv("DRMLT_FEAT_ALL")) P.features = 15;
-    P.mh_batch = P.kernel_variant == 4 ? (P.use_bvh ? (P.bvh_stack16 ? 6 : 4) : (P.features == 0 ? 12 : 8)) : 32; // v4: chains run free, the bookkeeping branch fires as soon as a few are parked
+    if (P.kernel_variant == 5 && !P.use_bvh) P.kernel_variant = 4; // the ray-pool kernel is the BVH scenes' (flat scenes loop over their records: rays need no regrouping there)
+    P.mh_batch = P.kernel_variant == 5 ? 16 : (P.kernel_variant == 4 ? (P.use_bvh ? (P.bvh_stack16 ? 6 : 4) : (P.features == 0 ? 12 : 8)) : 32); // v4 / v5: chains run free, the bookkeeping branch fires as soon as a few are parked
     if (const char *k = getenv("DRMLT_MH_BATCH")) P.mh_batch = std::max(1, std::min(64, atoi(k)));
     P.bvh_overflow = nullptr; P.bvh_ovf_lanes = 0;
     P.exec_order = nullptr;
@@ -773,6 +774,9 @@ int drmlt_set_luminance(drmlt_ctx *ctx, double b) {
     return DRMLT_OK;
 }
 
+// waves of a chain-kernel launch: k_mutate_v4 carries 32 chains per wave (lane pairs), k_mutate_v5 64
+static uint32_t chain_waves(const drmlt_ctx *ctx) { return ctx->P.kernel_variant == 5 ? (ctx->n_chains + 63u) / 64u : (ctx->n_chains + 31u) / 32u; }
+
 int drmlt_run(drmlt_ctx *ctx, uint64_t total_mutations, volatile int *stop, drmlt_progress_cb cb, void *user) {
     if (!ctx) return DRMLT_E_INVALID;
     if (!ctx->seeded) return ctx->fail(DRMLT_E_STATE, "drmlt_run called before drmlt_seed");
@@ -789,7 +793,7 @@ int drmlt_run(drmlt_ctx *ctx, uint64_t total_mutations, volatile int *stop, drml
     // chains that are there keep going -- towards the total of THIS call, at most 8192 mutations beyond the target (16-bit event
     // counters per chain and launch). The last launch has target = limit = total: every chain ends at exactly its count.
     // (A single launch has target = limit and is the plain fixed-count launch; the per-chain counts are kept either way.)
-    const bool ahead = ctx->cfg.technique == DRMLT_TECH_PATH && ctx->cfg.algo != DRMLT_ALGO_PSSMLT && ctx->P.kernel_variant == 4 &&
+    const bool ahead = ctx->cfg.technique == DRMLT_TECH_PATH && ctx->cfg.algo != DRMLT_ALGO_PSSMLT && ctx->P.kernel_variant >= 4 &&
                        !getenv("DRMLT_NO_RUN_AHEAD");
     const uint64_t call_base = ctx->mutation_base, call_end = call_base + per_chain;
     while (done < per_chain) {
@@ -812,7 +816,7 @@ int drmlt_run(drmlt_ctx *ctx, uint64_t total_mutations, volatile int *stop, drml
             const uint64_t target = call_base + done + n;
             Q.chain_done = ctx->d_done.as<uint32_t>();
             Q.run_limit = (uint32_t) std::min<uint64_t>(call_end, target + (getenv("DRMLT_AHEAD_CAP") ? (uint64_t) atoi(getenv("DRMLT_AHEAD_CAP")) : std::min<uint64_t>(8 * slice, 8192))); // at most eight launches ahead (the per-chain event counters of a launch are 16 bits wide); measured on config 3: 1024 6.7e8, 4096 7.1e8, 8192 7.14e8
-            launch_set_u32(Q.waves_left, (ctx->n_chains + 31u) / 32u, ctx->stream);
+            launch_set_u32(Q.waves_left, chain_waves(ctx), ctx->stream);
             launch_mutate(Q, (uint32_t) target, 0u, ctx->stream);
         } else launch_mutate(ctx->P, n, ctx->mutation_base, ctx->stream);
         HIP_TRY(ctx, hipGetLastError());
@@ -842,7 +846,7 @@ int drmlt_run(drmlt_ctx *ctx, uint64_t total_mutations, volatile int *stop, drml
             DParams Q = ctx->P;
             Q.chain_done = ctx->d_done.as<uint32_t>();
             Q.run_limit = top;
-            launch_set_u32(Q.waves_left, (ctx->n_chains + 31u) / 32u, ctx->stream);
+            launch_set_u32(Q.waves_left, chain_waves(ctx), ctx->stream);
             launch_mutate(Q, top, 0u, ctx->stream);
             HIP_TRY(ctx, hipGetLastError());
             HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));

@@ -10,6 +10,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include <cstdio>
+#include <type_traits>
 #include "device_path.h"
 
 #include "kernel_common.h"
@@ -895,6 +896,284 @@ __global__ void __launch_bounds__(CHAIN_BLOCK) k_mutate_v4(DParams P, uint32_t n
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// k_mutate_v5: the chain loop for BVH scenes with MORE RAYS THAN LANES.
+//
+// In k_mutate_v4 a ray belongs to a lane: chain lane i traverses its camera / bounce ray, helper lane 32 + i the shadow ray
+// of the same vertex. On a scene that is traversed (not looped over) the wave then advances ~25 of its 64 lanes per node
+// iteration: helpers mostly have no ray (no NEE at a vertex, the path parked or in its bookkeeping), chains wait for their
+// partner, and a slice drains towards its longest ray. Here rays and lanes are decoupled:
+//   * 64 chains per wave, chain c = lane c for everything that is per chain (path state, acceptance logic);
+//   * every ray a path step issues -- the bounce ray and, beside it, the shadow ray of the same vertex -- goes into a RAY POOL
+//     in LDS (slot c: chain c's closest-hit ray, slot 64 + c: its shadow ray; origin, direction, interval; the result is
+//     written over the record) and its slot number into a FIFO of pending rays, appended with ballot + prefix count
+//     (wave-level compaction of the lanes that have something to add);
+//   * the traversal loop runs over whatever rays the pool holds: a lane whose traversal finishes writes the result to the
+//     slot, and the idle lanes take the next pending slots off the queue (ballot + prefix count again) INSIDE the loop; a
+//     phase ends when the pool is dry or `trace_yield` closest-hit rays have finished -- their chains then step (any lane
+//     whose chain has its results) and refill the pool.
+// With 64 chains a wave holds ~75-80 rays, so the queue keeps the lanes fed until a phase is nearly over.
+// LDS: the proposal rows of v4 (y, z: 2 x 9 KB for 64 chains) do not fit beside that; proposals are evaluated on demand
+// from the chain state and the addressed Philox stream (SamplerT: the arithmetic of the other kernels, component by
+// component -- the same chains bit for bit), which costs a few Philox blocks per path step at the step's lane occupancy
+// and is small next to ~2000 instructions per traversed ray. Per wave: x rows 8.8 KB + splat queue 2.5 KB + pool 4 KB +
+// traversal stack 3.4 KB = 19 KB: eight waves per CU with 131 072 chains, two per SIMD.
+#define V5_STRIDE 65u
+#define V5_QCAP 128u
+#define V5_SLOTS 128u
+enum { RS_IDLE = 0, RS_BUSY = 1, RS_DONE = 2 };
+
+struct V5Lds {
+    uint32_t q_off;      // splat queue: 5 rows of V5_QCAP floats
+    uint32_t pool_off;   // ray pool: 8 rows of V5_SLOTS floats (ox oy oz dx dy dz tmin tmax; result over rows 0..3)
+    uint32_t ring_off;   // pending slots, FIFO: V5_SLOTS bytes
+    uint32_t status_off; // RS_* per slot: V5_SLOTS bytes
+};
+DEV V5Lds v5_layout(uint32_t D) {
+    V5Lds L;
+    L.q_off = D * V5_STRIDE;
+    L.pool_off = (L.q_off + 5u * V5_QCAP + 3u) & ~3u;
+    L.ring_off = L.pool_off + 8u * V5_SLOTS;
+    L.status_off = L.ring_off + V5_SLOTS / 4u;
+    return L;
+}
+static size_t v5_lds_bytes(uint32_t D) { return ((size_t) ((D * V5_STRIDE + 5u * V5_QCAP + 3u) & ~3u) + 8u * V5_SLOTS + 2u * (V5_SLOTS / 4u)) * sizeof(float); }
+
+template <int FEAT, bool STACK16, bool OVF>
+__global__ void __launch_bounds__(CHAIN_BLOCK, 2) k_mutate_v5(DParams P, uint32_t n_mut, uint32_t mut_base) {
+    const uint32_t lane = threadIdx.x;
+    const uint32_t c = blockIdx.x * 64u + lane;
+    const bool live = c < P.n_chains;
+    const uint32_t cc = live ? c : P.n_chains - 1;
+    const uint32_t S = V5_STRIDE, D = (uint32_t) P.eff_dim;
+    const V5Lds L = v5_layout(D);
+    const V4Lds Lq{0u, 0u, L.q_off, V5_QCAP};
+    unsigned char *const ring = reinterpret_cast<unsigned char *>(&lds_x[L.ring_off]);
+    unsigned char *const status = reinterpret_cast<unsigned char *>(&lds_x[L.status_off]);
+    float *const pool = &lds_x[L.pool_off];
+    for (uint32_t k = 0; k < D; ++k) lds_x[k * S + lane] = P.x[(size_t) k * P.n_chains + cc];
+    status[lane] = RS_IDLE; status[64u + lane] = RS_IDLE;
+
+    ChainState cs;
+    cs.cur.lum = P.cur_lum[cc]; cs.cur.px = P.cur_px[cc]; cs.cur.py = P.cur_py[cc];
+    cs.cur.r = P.cur_r[cc]; cs.cur.g = P.cur_g[cc]; cs.cur.b = P.cur_b[cc];
+    cs.y = cs.cur; cs.z = cs.cur;
+    cs.a1 = 0.f; cs.coin_acc1 = cs.coin_acc2 = cs.coin_mix = 0.f;
+    cs.it = 0u; cs.nd1 = cs.nd2 = 0u; cs.stage = -1; cs.large = false; cs.do_second = false;
+    float cum = 0.f; // weight of the current state since it was adopted (one splat per residence, as k_mutate_v4)
+    uint32_t qn = 0u;
+    Counters ct = {0u, 0u, 0u, 0u, 0u};
+
+    SamplerT<V5_STRIDE> smp;
+    smp.key0 = P.key0; smp.key1 = P.key1; smp.chain = P.chain_offset + cc; smp.major = 0u;
+    smp.mode = SM_STAGE1; smp.type = P.type; smp.large = false; smp.sigma2 = P.sigma2; smp.lane = lane; smp.arr = nullptr;
+    smp.reset_caches();
+
+    PathState ps;
+    path_init(P, ps);
+    ps.o = mk3(0.f, 0.f, 0.f); ps.d = mk3(0.f, 0.f, 1.f); ps.tmin = 0.f; ps.tmax = 0.f;
+    // run-ahead between the launches of a call: as k_mutate_v4 (chain_done / waves_left / run_limit)
+    const uint32_t base = (P.chain_done && live) ? P.chain_done[cc] : mut_base;
+    const uint32_t target = P.chain_done ? n_mut : mut_base + n_mut;
+    const uint32_t limit = P.chain_done ? P.run_limit : target;
+    bool reported = false;
+    ps.phase = (live && base < limit) ? PH_DONE : PH_IDLE;
+    const int batch = P.mh_batch > 64 ? 64 : P.mh_batch;
+    const GlobalTables GT{P.shade, P.bsdfs, P.emitters};
+
+    // traversal: this lane's column of the stack, the ray it is working on (`slot`), the FIFO of pending slots
+    typedef typename std::conditional<STACK16, short, int>::type StackT;
+    constexpr int CAP = STACK16 ? BVH_STACK : V4_STACK32_CAP;
+    __shared__ StackT v5_stack[(CAP + 3) * 64];
+    const TravLoop<StackT, DParams, OVF || !STACK16, CAP, FEAT> TL(P, v5_stack + lane);
+    Trav T;
+    T.active = false; T.cur = 0; T.sp = 0; T.ovf = 0; T.rx = T.ry = T.rz = 0u; T.any_hit = false; T.h = Hit{-1, 0.f, 0.f, 0.f}; T.tmin = 0.f;
+    T.o = T.d = T.inv = T.oi = mk3(0.f, 0.f, 0.f);
+    trav_reset_counters(T);
+    uint32_t slot = 0u;
+    uint32_t q_head = 0u, q_count = 0u; // wave-uniform
+    unsigned long long n_phase = 0ull, n_refill = 0ull, n_lanes_at_start = 0ull;
+
+    for (;;) {
+        const bool parked = ps.phase == PH_DONE;
+        const unsigned long long pmask = __ballot(parked);
+        const unsigned long long rmask = __ballot(ps.phase != PH_DONE && ps.phase != PH_IDLE);
+        if (!pmask && !rmask) break;
+        const bool rays_in_flight = q_count != 0u || __ballot(T.active) != 0ull;
+        // ---------------------------------------------------------------- bookkeeping: decide, commit, start
+        if (pmask && (__popcll(pmask) >= batch || !rays_in_flight)) {
+            if (qn + 192u > V5_QCAP + 64u) v4_flush(P, Lq, qn, lane); // room for this branch's splats (three rounds of at most 64, flushed in between)
+            int commit = 0;
+            bool want0 = false, want1 = false, want2 = false;
+            float e0x = 0.f, e0y = 0.f, e0r = 0.f, e0g = 0.f, e0b = 0.f;
+            float e1x = 0.f, e1y = 0.f, e1r = 0.f, e1g = 0.f, e1b = 0.f;
+            float e2x = 0.f, e2y = 0.f, e2r = 0.f, e2g = 0.f, e2b = 0.f;
+            if (parked) {
+                const MhOutcome o = mh_decide(P, cs, smp, ps, ct);
+                if (o.decided) {
+                    cum += o.w.w0;
+                    const bool a1st = o.commit == SM_STAGE1, a2nd = o.commit == SM_STAGE2;
+                    want1 = !a1st && o.w.w1 > 0.f;
+                    e1x = cs.y.px; e1y = cs.y.py; e1r = cs.y.r * o.w.w1; e1g = cs.y.g * o.w.w1; e1b = cs.y.b * o.w.w1;
+                    want2 = !a2nd && o.w.w2 > 0.f;
+                    e2x = cs.z.px; e2y = cs.z.py; e2r = cs.z.r * o.w.w2; e2g = cs.z.g * o.w.w2; e2b = cs.z.b * o.w.w2;
+                    if (o.commit) {
+                        want0 = cum > 0.f;
+                        e0x = cs.cur.px; e0y = cs.cur.py; e0r = cs.cur.r * cum; e0g = cs.cur.g * cum; e0b = cs.cur.b * cum;
+                        cum = a1st ? o.w.w1 : o.w.w2;
+                        cs.cur = select_splat(a1st, cs.y, cs.z);
+                        if (o.amap) { // acceptance map: the mark goes to the pixel of the state that was LEFT (device_mh.h)
+                            const f3 mc = mh_amap_colour(o.amap);
+                            want1 = true; e1x = e0x; e1y = e0y; e1r = mc.x; e1g = mc.y; e1b = mc.z;
+                        }
+                    }
+                    commit = o.commit;
+                }
+            }
+            // the queue holds V5_QCAP entries: at most 64 per round
+            v4_enqueue(Lq, qn, want0, e0x, e0y, e0r, e0g, e0b);
+            if (qn + 64u > V5_QCAP) v4_flush(P, Lq, qn, lane);
+            v4_enqueue(Lq, qn, want1, e1x, e1y, e1r, e1g, e1b);
+            if (qn + 64u > V5_QCAP) v4_flush(P, Lq, qn, lane);
+            v4_enqueue(Lq, qn, want2, e2x, e2y, e2r, e2g, e2b);
+            // DRMLTSampler::accept: uCurrent = wrap(chosen proposal), every kept dimension (the pair cache holds the OLD x of
+            // a pair until both of its components are written: even k computes the pair, odd k reads it)
+            if (commit) {
+                if (commit == SM_STAGE1) { for (uint32_t k = 0; k < D; ++k) lds_x[k * S + lane] = wrap01(smp.y_raw(k)); }
+                else { for (uint32_t k = 0; k < D; ++k) lds_x[k * S + lane] = wrap01(smp.z_raw(k)); }
+            }
+            // what next: the next mutation while short of the target; beyond it (run-ahead) while anybody in the grid is short
+            const uint32_t done_now = base + cs.it;
+            const bool under = __ballot(live && done_now < target) != 0ull;
+            bool more = under;
+            if (P.chain_done) {
+                if (!under && !reported) { reported = true; if (lane == 0) atomicSub(P.waves_left, 1u); }
+                if (!under) more = __builtin_amdgcn_readfirstlane((int) __hip_atomic_load(P.waves_left, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != 0;
+            }
+            if (parked) {
+                bool go = true;
+                if (cs.stage < 0) { // between mutations
+                    go = done_now < target || (done_now < limit && more);
+                    if (go) {
+                        const uint32_t m = done_now;
+                        const u4 coins = philox4x32_10(P.key0, P.key1, 0u, m, smp.chain, TAG_COIN);
+                        cs.large = u32_to_unit(coins.x) < P.p_large;
+                        cs.coin_acc1 = u32_to_unit(coins.y); cs.coin_acc2 = u32_to_unit(coins.z); cs.coin_mix = u32_to_unit(coins.w);
+                        smp.major = m; smp.large = cs.large;
+                        cs.stage = 0; cs.do_second = false; cs.nd1 = cs.nd2 = 0u;
+                    }
+                }
+                if (!go) ps.phase = PH_IDLE;
+                else {
+                    smp.mode = cs.stage == 0 ? SM_STAGE1 : (cs.stage == 1 ? SM_STAGE2 : SM_REVERSE);
+                    smp.reset_caches();
+                    path_init(P, ps); // PH_BEGIN: the step phase below draws the film position and issues the camera ray
+                }
+            }
+        }
+
+        // ---------------------------------------------------------------- step: chains whose ray results are in
+        {
+            const int st_c = status[lane], st_s = status[64u + lane];
+            const bool ready = ps.phase == PH_BEGIN || (ps.phase == PH_CLOSEST && st_c == RS_DONE && st_s != RS_BUSY) ||
+                               (ps.phase == PH_FLUSH && st_s != RS_BUSY);
+            bool push_c = false, push_s = false;
+            if (ready) {
+                Hit h{-1, 0.f, 0.f, 0.f};
+                if (ps.phase == PH_CLOSEST) {
+                    h.prim = __float_as_int(pool[lane]); h.t = pool[V5_SLOTS + lane]; h.u = pool[2u * V5_SLOTS + lane]; h.v = pool[3u * V5_SLOTS + lane];
+                }
+                const bool shadow_clear = st_s == RS_DONE ? pool[64u + lane] == 0.f : true;
+                status[lane] = RS_IDLE; status[64u + lane] = RS_IDLE;
+                ShadowRay sr;
+                sr.o = ps.o; sr.d = ps.d; sr.tmin = 0.f; sr.tmax = 0.f; sr.valid = false;
+                path_step<true, FEAT, SamplerT<V5_STRIDE>, GlobalTables, true>(P, GT, ps, smp, h, shadow_clear, sr);
+                push_c = ps.phase == PH_CLOSEST;
+                push_s = sr.valid;
+                if (push_c) {
+                    float *r = pool + lane;
+                    r[0] = ps.o.x; r[V5_SLOTS] = ps.o.y; r[2u * V5_SLOTS] = ps.o.z; r[3u * V5_SLOTS] = ps.d.x; r[4u * V5_SLOTS] = ps.d.y; r[5u * V5_SLOTS] = ps.d.z;
+                    r[6u * V5_SLOTS] = ps.tmin; r[7u * V5_SLOTS] = ps.tmax;
+                    status[lane] = RS_BUSY;
+                }
+                if (push_s) {
+                    float *r = pool + 64u + lane;
+                    r[0] = sr.o.x; r[V5_SLOTS] = sr.o.y; r[2u * V5_SLOTS] = sr.o.z; r[3u * V5_SLOTS] = sr.d.x; r[4u * V5_SLOTS] = sr.d.y; r[5u * V5_SLOTS] = sr.d.z;
+                    r[6u * V5_SLOTS] = sr.tmin; r[7u * V5_SLOTS] = sr.tmax;
+                    status[64u + lane] = RS_BUSY;
+                }
+            }
+            // ray compaction: the lanes that issued a ray append its slot to the FIFO (ballot + prefix count)
+            const unsigned long long mc = __ballot(push_c);
+            if (push_c) ring[(q_head + q_count + __builtin_amdgcn_mbcnt_hi((uint32_t) (mc >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) mc, 0u))) & (V5_SLOTS - 1u)] = (unsigned char) lane;
+            q_count += (uint32_t) __popcll(mc);
+            const unsigned long long ms = __ballot(push_s);
+            if (push_s) ring[(q_head + q_count + __builtin_amdgcn_mbcnt_hi((uint32_t) (ms >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) ms, 0u))) & (V5_SLOTS - 1u)] = (unsigned char) (64u + lane);
+            q_count += (uint32_t) __popcll(ms);
+        }
+
+        // ---------------------------------------------------------------- trace: the pool's rays, any lane any ray
+        {
+            int finished_closest = 0;
+            bool first = true;
+            n_phase++;
+            for (;;) {
+                // idle lanes take pending slots off the queue (at the start of a phase, and whenever a few lanes have run dry)
+                const unsigned long long idle = __ballot(!T.active);
+                if (q_count != 0u && idle != 0ull && (first || __popcll(idle) >= 4 || idle == ~0ull)) {
+                    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t) (idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) idle, 0u));
+                    const bool take = !T.active && rank < q_count;
+                    if (take) {
+                        slot = ring[(q_head + rank) & (V5_SLOTS - 1u)];
+                        const float *r = pool + slot;
+                        trav_begin(T, mk3(r[0], r[V5_SLOTS], r[2u * V5_SLOTS]), mk3(r[3u * V5_SLOTS], r[4u * V5_SLOTS], r[5u * V5_SLOTS]),
+                                   r[6u * V5_SLOTS], r[7u * V5_SLOTS], slot >= 64u);
+                    }
+                    const uint32_t taken = min((uint32_t) __popcll(idle), q_count);
+                    q_head = (q_head + taken) & (V5_SLOTS - 1u);
+                    q_count -= taken;
+                    n_refill++;
+                }
+                if (first) n_lanes_at_start += (unsigned long long) __popcll(__ballot(T.active));
+                first = false;
+                if (finished_closest >= P.trace_yield) break;
+                bool any;
+                const bool done_now = TL.step(T, true, any);
+                if (!any) break; // (the queue is empty too: an idle wave with pending slots refills above)
+                if (done_now) { // result over the ray's record; the owner chain picks it up in the step phase
+                    if (slot < 64u) {
+                        float *r = pool + slot;
+                        r[0] = __int_as_float(T.h.prim); r[V5_SLOTS] = T.h.t; r[2u * V5_SLOTS] = T.h.u; r[3u * V5_SLOTS] = T.h.v;
+                    } else {
+                        pool[slot] = T.h.prim >= 0 ? 1.f : 0.f;
+                    }
+                    status[slot] = RS_DONE;
+                }
+                finished_closest += __popcll(__ballot(done_now && slot < 64u));
+            }
+        }
+    }
+    // "Perform the last splat": the current states with what they have accumulated since they were adopted
+    if (qn + 64u > V5_QCAP) v4_flush(P, Lq, qn, lane);
+    v4_enqueue(Lq, qn, live && cum > 0.f, cs.cur.px, cs.cur.py, cs.cur.r * cum, cs.cur.g * cum, cs.cur.b * cum);
+    v4_flush(P, Lq, qn, lane);
+    if (live) {
+        for (uint32_t k = 0; k < D; ++k) P.x[(size_t) k * P.n_chains + c] = lds_x[k * S + lane];
+        P.cur_lum[c] = cs.cur.lum; P.cur_px[c] = cs.cur.px; P.cur_py[c] = cs.cur.py;
+        P.cur_r[c] = cs.cur.r; P.cur_g[c] = cs.cur.g; P.cur_b[c] = cs.cur.b;
+        if (P.chain_done) P.chain_done[c] = base + cs.it;
+    }
+    if (P.chain_done && !reported && lane == 0) atomicSub(P.waves_left, 1u); // (a wave none of whose chains had anything to do)
+    flush_counters(P, ct, lane);
+    const unsigned long long decided = wave_sum(live ? cs.it : 0u);
+    const unsigned long long nn = wave_sum(T.n_nodes), np = wave_sum(T.n_prims);
+    if (lane == 0) {
+        atomicAdd(P.stats + 9, decided);
+        atomicAdd(P.stats + 10, nn); atomicAdd(P.stats + 11, np); atomicAdd(P.stats + 12, (unsigned long long) T.it_inner); atomicAdd(P.stats + 13, (unsigned long long) T.it_leaf);
+        if (P.debug & 1024) { atomicAdd(P.stats + 20, n_phase); atomicAdd(P.stats + 21, n_lanes_at_start); atomicAdd(P.stats + 22, n_refill); }
+    }
+}
+
 __global__ void __launch_bounds__(64) k_eval_paths(DParams P, const float *u, uint32_t n, uint32_t dim, float *out8) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -985,7 +1264,16 @@ void launch_mutate_pssmlt(const DParams &P, uint32_t n_mut, uint32_t mut_base, h
 void launch_mutate(const DParams &P, uint32_t n_mut, uint32_t mut_base, hipStream_t st) {
     const size_t D = (size_t) P.eff_dim, D4 = (D + 3) & ~(size_t) 3;
     const dim3 block(CHAIN_BLOCK);
-    if (P.kernel_variant == 4) { // free-running chains, flattened bookkeeping, queued splats (rows of 33 floats)
+    if (P.kernel_variant == 5) { // BVH scenes: ray pool, 64 chains per wave
+        const size_t lds = v5_lds_bytes((uint32_t) D);
+        if (getenv("DRMLT_VERBOSE")) fprintf(stderr, "[drmlt] k_mutate_v5: %zu B of LDS per wave (+ the traversal stack)\n", lds);
+        const dim3 g5((P.n_chains + 63) / 64);
+        const bool diffuse = P.features == 8;
+        if (!P.bvh_stack16) { if (diffuse) hipLaunchKernelGGL((k_mutate_v5<8, false, true>), g5, block, lds, st, P, n_mut, mut_base); else hipLaunchKernelGGL((k_mutate_v5<15, false, true>), g5, block, lds, st, P, n_mut, mut_base); }
+        else if (P.bvh_overflow) { if (diffuse) hipLaunchKernelGGL((k_mutate_v5<8, true, true>), g5, block, lds, st, P, n_mut, mut_base); else hipLaunchKernelGGL((k_mutate_v5<15, true, true>), g5, block, lds, st, P, n_mut, mut_base); }
+        else if (diffuse) hipLaunchKernelGGL((k_mutate_v5<8, true, false>), g5, block, lds, st, P, n_mut, mut_base);
+        else hipLaunchKernelGGL((k_mutate_v5<15, true, false>), g5, block, lds, st, P, n_mut, mut_base);
+    } else if (P.kernel_variant == 4) { // free-running chains, flattened bookkeeping, queued splats (rows of 33 floats)
         const size_t qcap = (P.features & 8) || !P.tables_in_lds ? V4_QCAP_BVH : V4_QCAP; // as the kernel variants below
         size_t lds = ((D + 2 * D4 + 4) * V4_STRIDE + 32 + 5 * qcap + 3) / 4 * 4 * sizeof(float);
         if (P.tables_in_lds) lds += (size_t) P.n_shade * 64 + (size_t) P.n_bsdfs * 48 + (size_t) P.n_emitters * 32;

@@ -1,0 +1,85 @@
+"""k_mutate_v5, the ray-pool chain kernel of BVH scenes (64 chains per wave, rays queued in LDS, any lane traverses any
+ray; north_star's "wavefront ballot / prefix-sum ray compaction"): it must run the chains of k_mutate_v4 / k_mutate_v3 bit
+for bit -- same addressed draws, same proposal arithmetic, same acceptance code (device_mh.h) -- whatever the order in
+which the wave happens to traverse its rays."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+LUMW = np.array([0.212671, 0.715160, 0.072169])
+
+
+def lum(img):
+    return img @ LUMW
+
+
+def ctx_with_env(pkg, cfg, sd, **env):
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update({k: str(v) for k, v in env.items()})
+    try:
+        return pkg.Context(cfg, sd)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                del os.environ[k]
+            else:
+                os.environ[k] = v
+
+
+CASES = [
+    ("triangle_soup", dict(n_tris=2000), dict(type="orbital"), {}),                                  # 16-bit stacks, diffuse-only build
+    ("triangle_soup", dict(n_tris=2000), dict(type="green"), {}),
+    ("triangle_soup", dict(n_tris=2000), dict(type="mira", timid_after_large=1), {}),
+    ("triangle_soup", dict(n_tris=2000), dict(type="orbital", use_mixture=1), {}),
+    ("triangle_soup", dict(n_tris=40000), dict(type="orbital"), {}),                                 # 32-bit stacks, overflow area in use
+    ("caustic_c5", {}, dict(type="orbital"), dict(DRMLT_BVH_THRESHOLD=0)),                           # spheres + dielectric in the leaves
+    ("door_c3", {}, dict(type="green"), dict(DRMLT_BVH_THRESHOLD=0)),                                # rough conductor
+]
+
+
+@pytest.mark.parametrize("scene,skw,kw,env", CASES, ids=["soup-orbital", "soup-green", "soup-mira-timid", "soup-mixture", "soup40k", "caustic-bvh", "door-bvh"])
+def test_ray_pool_kernel_runs_the_same_chains(pkg, native_lib, scene, skw, kw, env):
+    sd = pkg.scenes.SCENES[scene](res=32, **skw)
+    n_chains, n_mut = 1000, 60                       # 1000: the last wave of either kernel is ragged
+    cfg = pkg.abi.make_config(max_depth=8, direct_samples=-1, luminance_samples=20000, work_units=n_chains, sample_count=1, **kw)
+    res = []
+    for kern in (4, 5):
+        ctx = ctx_with_env(pkg, cfg, sd, DRMLT_KERNEL=kern, **env)
+        ctx.seed(0x5005)
+        ctx.run(n_chains * n_mut)
+        res.append((ctx.chain_state(34), ctx.stats(), ctx.film()))
+        ctx.close()
+    ((c4, u4), s4, f4), ((c5, u5), s5, f5) = res
+    assert s5.mutations == s4.mutations == n_chains * n_mut
+    assert np.array_equal(u5, u4)                                                    # states: bit-equal
+    assert np.allclose(c5["luminance"], c4["luminance"], rtol=2e-6)                  # f(u): two compilations of the path step
+    for k in ("first", "large", "bold", "second", "second_large", "second_bold", "overall"):
+        assert getattr(s5, k + "_base") == getattr(s4, k + "_base") and getattr(s5, k + "_acc") == getattr(s4, k + "_acc"), k
+    assert s5.accepted == s4.accepted and s5.rays == s4.rays and s5.path_evals == s4.path_evals
+    assert s5.bvh_node_visits == s4.bvh_node_visits and s5.bvh_prim_tests == s4.bvh_prim_tests   # the same rays, traversed the same way
+    assert lum(f5).sum() == pytest.approx(lum(f4).sum(), rel=1e-5)
+    assert np.abs(lum(f5) - lum(f4)).sum() / lum(f4).sum() < 1e-4
+
+
+def test_ray_pool_kernel_with_run_ahead_and_acceptance_map(pkg, native_lib):
+    sd = pkg.scenes.triangle_soup(2000, 32)
+    n_chains, per_chain = 1536, 300
+    cfg = pkg.abi.make_config(type="orbital", max_depth=8, direct_samples=-1, luminance_samples=20000, work_units=n_chains, sample_count=1,
+                              acceptance_map=1)
+    res = []
+    for env in (dict(DRMLT_KERNEL=4, DRMLT_SLICE=64), dict(DRMLT_KERNEL=5, DRMLT_SLICE=64), dict(DRMLT_KERNEL=5, DRMLT_SLICE=64, DRMLT_NO_RUN_AHEAD=1)):
+        ctx = ctx_with_env(pkg, cfg, sd, **env)
+        ctx.seed(9)
+        os.environ.update({k: str(v) for k, v in env.items()})
+        try:
+            ctx.run(n_chains * per_chain)
+        finally:
+            for k in env:
+                del os.environ[k]
+        res.append((ctx.chain_state(34)[1], ctx.stats(), ctx.film()))
+        ctx.close()
+    for u, s, f in res[1:]:
+        assert np.array_equal(u, res[0][0]) and s.accepted == res[0][1].accepted and s.mutations == n_chains * per_chain
+        np.testing.assert_array_equal(f, res[0][2])                                   # marks are whole numbers of box weights: exact
