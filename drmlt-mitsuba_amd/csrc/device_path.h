@@ -127,7 +127,7 @@ template <uint32_t STRIDE = 64u> struct SamplerT {
                 float d = kelemen_sample(u_s1(k0), KELEMEN_S2 * ORBITAL_SCALE);
                 float a = u_s1(k0 + 1u);
                 pair_y0 = fmaf(d, cos_rev(a), x0);
-                pair_y1 = fmaf(d, sin_rev(a), x1);
+                pair_y1 = fmaf(d, cos_rev(a - 0.25f), x1); // sin(2 pi a) as the row samplers evaluate it (v_sin and v_cos differ in the last bit)
             }
             pair_has_z = false;
         }

@@ -902,7 +902,11 @@ int drmlt_stats_get(drmlt_ctx *ctx, drmlt_stats *o) {
     if ((ctx->P.debug & 128) && ctx->cfg.technique == DRMLT_TECH_BDPT) // diagnostic stamps of eval_bdpt / k_mutate_bdpt
         fprintf(stderr, "[drmlt stamps] bdpt cycles per wave, summed: walks %llu pair loop %llu whole chain loop %llu | evaluations %llu | stages (all evaluations) %llu, weights + splats %llu, counters + commit %llu\n",
                 v[16], v[17], v[18], v[19], v[20], v[21], v[22]);
-    else if (ctx->P.debug & 128) // diagnostic stamps of k_mutate_v2 / v3
+    else if ((ctx->P.debug & 128) && ctx->P.kernel_variant == 5) // diagnostic stamps of k_mutate_v5
+        fprintf(stderr, "[drmlt v5] cycles per wave, summed: bookkeeping %llu step %llu trace %llu | outer iterations %llu, bookkeeping branches %llu (%.1f chains each), "
+                        "stepping chains per iteration %.1f, trace phases %llu starting with %.1f lanes, refills %llu\n",
+                v[16], v[18], v[17], v[19], v[23], v[23] ? (double) v[24] / v[23] : 0.0, v[19] ? (double) v[25] / v[19] : 0.0, v[20], v[20] ? (double) v[21] / v[20] : 0.0, v[22]);
+    else if (ctx->P.debug & 128) // diagnostic stamps of k_mutate_v3 / v4
         fprintf(stderr, "[drmlt stamps] cycles: mh %llu trace %llu step %llu | iterations %llu mh-branches %llu tracing-lanes %llu\n",
                 v[16], v[17], v[18], v[19], v[20], v[21]),
         fprintf(stderr, "[drmlt stamps] mh sections: decide+splat %llu commit %llu start %llu fill %llu\n", v[22], v[23], v[24], v[25]),
@@ -910,7 +914,7 @@ int drmlt_stats_get(drmlt_ctx *ctx, drmlt_stats *o) {
     if (getenv("DRMLT_VERBOSE") && v[12])
         fprintf(stderr, "[drmlt bvh] wave iterations: inner %llu (%.1f lanes each), leaf %llu (%.1f lanes each)\n", v[12], (double) v[10] / (double) v[12], v[13],
                 v[13] ? (double) v[11] / (double) v[13] : 0.0);
-    if ((ctx->P.debug & 1024) && v[20])
+    if ((ctx->P.debug & 1024) && v[20] && ctx->P.kernel_variant != 5)
         fprintf(stderr, "[drmlt bvh] lanes at slice start, of 64: tracing %.1f, chain waiting for its partner %.1f, chain parked for bookkeeping %.1f, helper idle %.1f, flush %.1f (%llu slices)\n",
                 (double) v[21] / v[20], (double) v[22] / v[20], (double) v[23] / v[20], (double) v[24] / v[20], (double) v[25] / v[20], v[20]);
     memset(o, 0, sizeof *o);

@@ -939,7 +939,7 @@ DEV V5Lds v5_layout(uint32_t D) {
 }
 static size_t v5_lds_bytes(uint32_t D) { return ((size_t) ((D * V5_STRIDE + 5u * V5_QCAP + 3u) & ~3u) + 8u * V5_SLOTS + 2u * (V5_SLOTS / 4u)) * sizeof(float); }
 
-template <int FEAT, bool STACK16, bool OVF>
+template <int FEAT, bool STACK16, bool OVF, bool STAMPS = false>
 __global__ void __launch_bounds__(CHAIN_BLOCK, 2) k_mutate_v5(DParams P, uint32_t n_mut, uint32_t mut_base) {
     const uint32_t lane = threadIdx.x;
     const uint32_t c = blockIdx.x * 64u + lane;
@@ -993,6 +993,8 @@ __global__ void __launch_bounds__(CHAIN_BLOCK, 2) k_mutate_v5(DParams P, uint32_
     uint32_t slot = 0u;
     uint32_t q_head = 0u, q_count = 0u; // wave-uniform
     unsigned long long n_phase = 0ull, n_refill = 0ull, n_lanes_at_start = 0ull;
+    unsigned long long t_mh = 0ull, t_step = 0ull, t_trace = 0ull, n_outer = 0ull, n_mh = 0ull, n_stepping = 0ull, n_parked = 0ull;
+#define STAMP5() (STAMPS ? __builtin_amdgcn_s_memtime() : 0ull)
 
     for (;;) {
         const bool parked = ps.phase == PH_DONE;
@@ -1000,8 +1002,11 @@ __global__ void __launch_bounds__(CHAIN_BLOCK, 2) k_mutate_v5(DParams P, uint32_
         const unsigned long long rmask = __ballot(ps.phase != PH_DONE && ps.phase != PH_IDLE);
         if (!pmask && !rmask) break;
         const bool rays_in_flight = q_count != 0u || __ballot(T.active) != 0ull;
+        const unsigned long long s0 = STAMP5();
+        n_outer++;
         // ---------------------------------------------------------------- bookkeeping: decide, commit, start
         if (pmask && (__popcll(pmask) >= batch || !rays_in_flight)) {
+            if (STAMPS) { n_mh++; n_parked += (unsigned long long) __popcll(pmask); }
             if (qn + 192u > V5_QCAP + 64u) v4_flush(P, Lq, qn, lane); // room for this branch's splats (three rounds of at most 64, flushed in between)
             int commit = 0;
             bool want0 = false, want1 = false, want2 = false;
@@ -1072,12 +1077,14 @@ __global__ void __launch_bounds__(CHAIN_BLOCK, 2) k_mutate_v5(DParams P, uint32_
             }
         }
 
+        const unsigned long long s1 = STAMP5();
         // ---------------------------------------------------------------- step: chains whose ray results are in
         {
             const int st_c = status[lane], st_s = status[64u + lane];
             const bool ready = ps.phase == PH_BEGIN || (ps.phase == PH_CLOSEST && st_c == RS_DONE && st_s != RS_BUSY) ||
                                (ps.phase == PH_FLUSH && st_s != RS_BUSY);
             bool push_c = false, push_s = false;
+            if (STAMPS) n_stepping += (unsigned long long) __popcll(__ballot(ready));
             if (ready) {
                 Hit h{-1, 0.f, 0.f, 0.f};
                 if (ps.phase == PH_CLOSEST) {
@@ -1112,6 +1119,7 @@ __global__ void __launch_bounds__(CHAIN_BLOCK, 2) k_mutate_v5(DParams P, uint32_
             q_count += (uint32_t) __popcll(ms);
         }
 
+        const unsigned long long s2 = STAMP5();
         // ---------------------------------------------------------------- trace: the pool's rays, any lane any ray
         {
             int finished_closest = 0;
@@ -1152,6 +1160,13 @@ __global__ void __launch_bounds__(CHAIN_BLOCK, 2) k_mutate_v5(DParams P, uint32_
                 finished_closest += __popcll(__ballot(done_now && slot < 64u));
             }
         }
+        const unsigned long long s3 = STAMP5();
+        t_mh += s1 - s0; t_step += s2 - s1; t_trace += s3 - s2;
+    }
+#undef STAMP5
+    if (STAMPS && lane == 0) {
+        atomicAdd(P.stats + 16, t_mh); atomicAdd(P.stats + 17, t_trace); atomicAdd(P.stats + 18, t_step); atomicAdd(P.stats + 19, n_outer);
+        atomicAdd(P.stats + 23, n_mh); atomicAdd(P.stats + 24, n_parked); atomicAdd(P.stats + 25, n_stepping);
     }
     // "Perform the last splat": the current states with what they have accumulated since they were adopted
     if (qn + 64u > V5_QCAP) v4_flush(P, Lq, qn, lane);
@@ -1170,7 +1185,7 @@ __global__ void __launch_bounds__(CHAIN_BLOCK, 2) k_mutate_v5(DParams P, uint32_
     if (lane == 0) {
         atomicAdd(P.stats + 9, decided);
         atomicAdd(P.stats + 10, nn); atomicAdd(P.stats + 11, np); atomicAdd(P.stats + 12, (unsigned long long) T.it_inner); atomicAdd(P.stats + 13, (unsigned long long) T.it_leaf);
-        if (P.debug & 1024) { atomicAdd(P.stats + 20, n_phase); atomicAdd(P.stats + 21, n_lanes_at_start); atomicAdd(P.stats + 22, n_refill); }
+        if (P.debug & (1024 | 128)) { atomicAdd(P.stats + 20, n_phase); atomicAdd(P.stats + 21, n_lanes_at_start); atomicAdd(P.stats + 22, n_refill); }
     }
 }
 
@@ -1271,6 +1286,7 @@ void launch_mutate(const DParams &P, uint32_t n_mut, uint32_t mut_base, hipStrea
         const bool diffuse = P.features == 8;
         if (!P.bvh_stack16) { if (diffuse) hipLaunchKernelGGL((k_mutate_v5<8, false, true>), g5, block, lds, st, P, n_mut, mut_base); else hipLaunchKernelGGL((k_mutate_v5<15, false, true>), g5, block, lds, st, P, n_mut, mut_base); }
         else if (P.bvh_overflow) { if (diffuse) hipLaunchKernelGGL((k_mutate_v5<8, true, true>), g5, block, lds, st, P, n_mut, mut_base); else hipLaunchKernelGGL((k_mutate_v5<15, true, true>), g5, block, lds, st, P, n_mut, mut_base); }
+        else if (diffuse && (P.debug & 128)) hipLaunchKernelGGL((k_mutate_v5<8, true, false, true>), g5, block, lds, st, P, n_mut, mut_base); // diagnostic stamps
         else if (diffuse) hipLaunchKernelGGL((k_mutate_v5<8, true, false>), g5, block, lds, st, P, n_mut, mut_base);
         else hipLaunchKernelGGL((k_mutate_v5<15, true, false>), g5, block, lds, st, P, n_mut, mut_base);
     } else if (P.kernel_variant == 4) { // free-running chains, flattened bookkeeping, queued splats (rows of 33 floats)
