@@ -57,21 +57,22 @@ CONFIGS = {
     "bdpt": dict(scene=("cornell_c2", {}), res=512, chains=131072, cfg=dict(technique="bdpt", type="orbital", max_depth=8, rr_depth=5),
                  spp=256, kernel="k_mutate_bdpt", pmc="r02_bdpt_pmc.json",
                  what="Cornell box %(res)dx%(res)d, drmlt technique=bdpt type=orbital, %(chains)d chains/GPU, sampleCount %(spp)d"),
-    "soup": dict(scene=("triangle_soup", dict(n_tris=2000)), res=512,
-                 cfg=dict(technique="path", type="orbital", max_depth=8, rr_depth=5), spp=256, kernel="k_mutate_v4",
+    # BVH scenes under type = orbital run k_mutate_v5 (ray pool, 64 chains per wave): 131 072 chains put two waves on every SIMD
+    "soup": dict(scene=("triangle_soup", dict(n_tris=2000)), res=512, chains=131072,
+                 cfg=dict(technique="path", type="orbital", max_depth=8, rr_depth=5), spp=256, kernel="k_mutate_v5",
                  pmc="r02_soup_pmc.json", ref_spp=2048,
                  what="closed room with 2000 random triangles (BVH in HBM) %(res)dx%(res)d, drmlt technique=path type=orbital, "
                       "%(chains)d chains/GPU, sampleCount %(spp)d"),
-    "soup50k": dict(scene=("triangle_soup", dict(n_tris=50000)), res=512,
-                    cfg=dict(technique="path", type="orbital", max_depth=8, rr_depth=5), spp=256, kernel="k_mutate_v4",
+    "soup50k": dict(scene=("triangle_soup", dict(n_tris=50000)), res=512, chains=131072,
+                    cfg=dict(technique="path", type="orbital", max_depth=8, rr_depth=5), spp=256, kernel="k_mutate_v5",
                     pmc="r02_soup50k_pmc.json", ref_spp=512,
                     what="closed room with 50000 random triangles (BVH, primitive and shading records: 9.6 MB in HBM / L2; "
                          "32-bit traversal stacks) %(res)dx%(res)d, drmlt technique=path type=orbital, %(chains)d chains/GPU, "
                          "sampleCount %(spp)d"),
     # a scene whose node / primitive / shading records (188 MB) exceed the L2 caches: the regime SURVEY 8(d) names as the one
     # where memory, not instruction issue, would bound the path. 64 mutations/pixel per step (the scene is slow to traverse).
-    "soup1m": dict(scene=("triangle_soup", dict(n_tris=1000000)), res=512,
-                   cfg=dict(technique="path", type="orbital", max_depth=8, rr_depth=5), spp=64, kernel="k_mutate_v4",
+    "soup1m": dict(scene=("triangle_soup", dict(n_tris=1000000)), res=512, chains=131072,
+                   cfg=dict(technique="path", type="orbital", max_depth=8, rr_depth=5), spp=64, kernel="k_mutate_v5",
                    pmc="r02_soup1m_pmc.json", no_cpu_baseline="the CPU restatement has no acceleration structure: brute force over "
                    "1e6 triangles per ray is not a baseline (soup50k already runs 3e3 mutations/s on 16 threads)", no_quality=True,
                    what="closed room with 1000000 random triangles (BVH, primitive and shading records: 188 MB, beyond L2, inside "

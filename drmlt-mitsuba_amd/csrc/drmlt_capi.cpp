@@ -434,7 +434,9 @@ drmlt_ctx *drmlt_create(const drmlt_config *cfg, const drmlt_scene *scene, int d
             const uint64_t per_unit = (mmlt || bdpt) ? 100000 : 200000;
             work_units = (int) std::max<uint64_t>(1, (budget + per_unit - 1) / per_unit);
         } else {
-            const uint64_t fill = mmlt ? 262144 : (bdpt ? 131072 : 65536); // mmlt: two rounds of waves, run in depth order
+            // (k_mutate_v5, the ray-pool kernel of BVH scenes under type = orbital, carries 64 chains per wave: 131 072 fill the device)
+            const bool pool_kernel = !mmlt && !bdpt && cfg->algo != DRMLT_ALGO_PSSMLT && P.use_bvh && cfg->type == DRMLT_TYPE_ORBITAL && !getenv("DRMLT_KERNEL");
+            const uint64_t fill = mmlt ? 262144 : ((bdpt || pool_kernel) ? 131072 : 65536); // mmlt: two rounds of waves, run in depth order
             work_units = (int) std::min<uint64_t>(fill, std::max<uint64_t>(64, budget / 64 / 64 * 64));
         }
     }
@@ -519,21 +521,27 @@ drmlt_ctx *drmlt_create(const drmlt_config *cfg, const drmlt_scene *scene, int d
     P.error_flag = ctx->d_err.as<int32_t>();
     P.debug = 0;
     if (const char *d = getenv("DRMLT_DEBUG")) P.debug = atoi(d);
-    P.kernel_variant = 4;
+    // chain kernel of technique=path: 4 = k_mutate_v4 (lane pairs, 32 chains per wave), 5 = k_mutate_v5 (ray pool, 64 chains per wave:
+    // the default where it applies, see below), 3 = k_mutate_v3 (the bit-equality cross-check)
+    P.kernel_variant = 5;
     if (const char *k = getenv("DRMLT_KERNEL")) { int kv = atoi(k); P.kernel_variant = kv == 3 ? 3 : (kv == 5 ? 5 : 4); }
     P.features = 0;
     for (const DBsdf &b : bsdfs) P.features |= b.type == DRMLT_BSDF_ROUGHCONDUCTOR ? 1 : (b.type == DRMLT_BSDF_DIELECTRIC ? 2 : 0);
     for (const DPrim &g : ctx->prims) if (g.type == PRIM_SPHERE) P.features |= 4;
     if (P.use_bvh) P.features |= 8;
     if (getenv("DRMLT_FEAT_ALL")) P.features = 15;
-    if (P.kernel_variant == 5 && !P.use_bvh) P.kernel_variant = 4; // the ray-pool kernel is the BVH scenes' (flat scenes loop over their records: rays need no regrouping there)
+    // the ray-pool kernel is the BVH scenes' (flat scenes loop over their records: rays need no regrouping there), and it keeps ONE
+    // proposal row group in LDS: type = orbital only (Green's reverse move and Mira's ratio need x, y and z together)
+    if (P.kernel_variant == 5 && (!P.use_bvh || cfg->type != DRMLT_TYPE_ORBITAL)) P.kernel_variant = 4;
     P.mh_batch = P.kernel_variant == 5 ? 16 : (P.kernel_variant == 4 ? (P.use_bvh ? (P.bvh_stack16 ? 6 : 4) : (P.features == 0 ? 12 : 8)) : 32); // v4 / v5: chains run free, the bookkeeping branch fires as soon as a few are parked
     if (const char *k = getenv("DRMLT_MH_BATCH")) P.mh_batch = std::max(1, std::min(64, atoi(k)));
     P.bvh_overflow = nullptr; P.bvh_ovf_lanes = 0;
     P.exec_order = nullptr;
     // measured (5-launch calls) on the 2000-triangle soup: 16 3.69e8, 20 3.80e8, 24 3.84e8, 28 3.84e8 mutations/s; on 50 000 triangles (32-bit
     // stacks, longer traversals): 20 1.90e8, 24 1.86e8, 28 1.79e8; bookkeeping batch there 4 1.89e8, 6 1.86e8, 8 1.82e8
-    P.trace_yield = P.bvh_stack16 ? 24 : 20;
+    // k_mutate_v5 (131 072 chains, 3-step calls) on the soup: yield x bookkeeping batch -- 12: 4.84 / 5.13 / 5.12e8 (batch 8 / 16 / 28),
+    // 16: 5.08 / 5.37 / 5.20, 20: 5.25 / 5.44 / 5.10, 24: 5.31 / 5.40 / 4.81
+    P.trace_yield = P.kernel_variant == 5 ? 20 : (P.bvh_stack16 ? 24 : 20);
     if (const char *k = getenv("DRMLT_TRACE_YIELD")) P.trace_yield = std::max(0, std::min(64, atoi(k)));
     P.trace_vote = 10; // measured on the 2000-triangle soup: 16 (plain majority) 2.70e8, 10 2.78e8, 5 2.73e8 mutations/s
     if (const char *k = getenv("DRMLT_TRACE_VOTE")) P.trace_vote = std::max(1, std::min(1024, atoi(k)));

@@ -897,10 +897,10 @@ __global__ void __launch_bounds__(CHAIN_BLOCK) k_mutate_v4(DParams P, uint32_t n
 }
 
 // ------------------------------------------------------------------------------------------
-// k_mutate_v5: the chain loop for BVH scenes with MORE RAYS THAN LANES.
+// k_mutate_v5: the chain loop for BVH scenes with MORE RAYS THAN LANES (type = orbital; the iid kernels stay on v4).
 //
 // In k_mutate_v4 a ray belongs to a lane: chain lane i traverses its camera / bounce ray, helper lane 32 + i the shadow ray
-// of the same vertex. On a scene that is traversed (not looped over) the wave then advances ~25 of its 64 lanes per node
+// of the same vertex. On a scene that is traversed (not looped over) the wave then advances ~22 of its 64 lanes per node
 // iteration: helpers mostly have no ray (no NEE at a vertex, the path parked or in its bookkeeping), chains wait for their
 // partner, and a slice drains towards its longest ray. Here rays and lanes are decoupled:
 //   * 64 chains per wave, chain c = lane c for everything that is per chain (path state, acceptance logic);
@@ -913,79 +913,155 @@ __global__ void __launch_bounds__(CHAIN_BLOCK) k_mutate_v4(DParams P, uint32_t n
 //     phase ends when the pool is dry or `trace_yield` closest-hit rays have finished -- their chains then step (any lane
 //     whose chain has its results) and refill the pool.
 // With 64 chains a wave holds ~75-80 rays, so the queue keeps the lanes fed until a phase is nearly over.
-// LDS: the proposal rows of v4 (y, z: 2 x 9 KB for 64 chains) do not fit beside that; proposals are evaluated on demand
-// from the chain state and the addressed Philox stream (SamplerT: the arithmetic of the other kernels, component by
-// component -- the same chains bit for bit), which costs a few Philox blocks per path step at the step's lane occupancy
-// and is small next to ~2000 instructions per traversed ray. Per wave: x rows 8.8 KB + splat queue 2.5 KB + pool 4 KB +
-// traversal stack 3.4 KB = 19 KB: eight waves per CU with 131 072 chains, two per SIMD.
-#define V5_STRIDE 65u
-#define V5_QCAP 128u
+//
+// LDS (20 KB per wave = eight waves per CU = two per SIMD with 131 072 chains): v4's three row groups (x, y, z: 3 x 9 KB for
+// 64 chains) cannot sit beside the pool. The CURRENT STATE x therefore stays at home in device memory ([dim][chain], the
+// layout it has between launches anyway): it is read when a mutation's proposal is made (flattened over the wave, chain-minor:
+// partly coalesced 256 B rows) and written when a proposal is adopted -- SURVEY 8(d)'s B_state, now real traffic (~250 B per
+// mutation, L2 / MALL resident). LDS holds ONE row group: the proposal under evaluation -- y, overwritten in place by z when a
+// chain enters its second stage (the orbital rule needs only the luminances of y afterwards; Green's reverse move and Mira's
+// ratio need x, y and z together, which is why those types keep k_mutate_v4). Bookkeeping is v4's: decide per lane, commit /
+// proposals / coins flattened over the 64 lanes. Same addressed draws, same arithmetic per component: the same chains.
+#define V5_QCAP 96u
 #define V5_SLOTS 128u
 enum { RS_IDLE = 0, RS_BUSY = 1, RS_DONE = 2 };
 
 struct V5Lds {
-    uint32_t q_off;      // splat queue: 5 rows of V5_QCAP floats
-    uint32_t pool_off;   // ray pool: 8 rows of V5_SLOTS floats (ox oy oz dx dy dz tmin tmax; result over rows 0..3)
-    uint32_t ring_off;   // pending slots, FIFO: V5_SLOTS bytes
-    uint32_t status_off; // RS_* per slot: V5_SLOTS bytes
+    uint32_t coin_off, list_off; // 4 rows of coins (one mutation ahead), the compacted chain list of the bookkeeping branch
+    uint32_t q_off;              // splat queue: 5 rows of V5_QCAP floats
+    uint32_t pool_off;           // ray pool: 8 rows of V5_SLOTS floats (ox oy oz dx dy dz tmin tmax; result over rows 0..3)
+    uint32_t ring_off;           // pending slots, FIFO: V5_SLOTS bytes
+    uint32_t status_off;         // RS_* per slot: V5_SLOTS bytes
 };
 DEV V5Lds v5_layout(uint32_t D) {
     V5Lds L;
-    L.q_off = D * V5_STRIDE;
-    L.pool_off = (L.q_off + 5u * V5_QCAP + 3u) & ~3u;
+    L.coin_off = D * 64u;
+    L.list_off = L.coin_off + 4u * 64u;
+    L.q_off = L.list_off + 64u;
+    L.pool_off = L.q_off + 5u * V5_QCAP;
     L.ring_off = L.pool_off + 8u * V5_SLOTS;
     L.status_off = L.ring_off + V5_SLOTS / 4u;
     return L;
 }
-static size_t v5_lds_bytes(uint32_t D) { return ((size_t) ((D * V5_STRIDE + 5u * V5_QCAP + 3u) & ~3u) + 8u * V5_SLOTS + 2u * (V5_SLOTS / 4u)) * sizeof(float); }
+static size_t v5_lds_bytes(uint32_t D) { return ((size_t) D * 64u + 4u * 64u + 64u + 5u * V5_QCAP + 8u * V5_SLOTS + 2u * (V5_SLOTS / 4u)) * sizeof(float); }
+
+// the proposal rows as the path step sees them: whatever stage is being evaluated sits in the one row group
+struct PoolRowSampler {
+    uint32_t lane;
+    DEV void reset_caches() {}
+    DEV float row(uint32_t k) const { return lds_x[k * 64u + lane]; }
+    DEV float next(uint32_t k) const { return wrap01(row(k)); }
+    DEV float x(uint32_t k) const { return row(k); }      // (Mira's ratio: never evaluated here, the launcher routes type = orbital only)
+    DEV float y_raw(uint32_t k) const { return row(k); }
+    DEV float z_raw(uint32_t k) const { return row(k); }
+};
+
+// first-stage proposal of the chain in column `col` (state column `xcol` of P.x), dimensions 4b .. 4b+3, from Philox block b
+DEV void v5_fill_first(const DParams &P, uint32_t D, uint32_t col, size_t xcol, uint32_t b, uint32_t major, uint32_t chain, bool large) {
+    FP_STRICT;
+    const u4 r = philox4x32_10(P.key0, P.key1, b, major, chain, TAG_S1);
+    const float u0 = u32_to_unit(r.x), u1 = u32_to_unit(r.y), u2 = u32_to_unit(r.z), u3 = u32_to_unit(r.w);
+    const bool hi = 4u * b + 2u < D; // D is even: a block holds two pairs or, at the end of the vector, one
+    const float *xs = P.x + (size_t) (4u * b) * P.n_chains + xcol;
+    const float x0 = load_global_f32(xs), x1 = load_global_f32(xs + P.n_chains);
+    const float x2 = load_global_f32(xs + (hi ? 2u : 0u) * (size_t) P.n_chains), x3 = load_global_f32(xs + (hi ? 3u : 1u) * (size_t) P.n_chains);
+    // pairwise orbital: radius from the Kelemen kernel (x 1.9), uniform angle (drmlt_sampler.cpp:354-361)
+    const float d0 = kelemen_sample(u0, KELEMEN_S2 * ORBITAL_SCALE), d1 = kelemen_sample(u2, KELEMEN_S2 * ORBITAL_SCALE);
+    const float y0 = fmaf(d0, cos_rev(u1), x0), y1 = fmaf(d0, cos_rev(u1 - 0.25f), x1);
+    const float y2 = fmaf(d1, cos_rev(u3), x2), y3 = fmaf(d1, cos_rev(u3 - 0.25f), x3);
+    float *ys = &lds_x[4u * b * 64u + col];
+    ys[0] = large ? u0 : y0; ys[64] = large ? u1 : y1;
+    if (hi) { ys[128] = large ? u2 : y2; ys[192] = large ? u3 : y3; }
+}
+// second-stage proposal from Philox block b of the TAG_S2 stream, written OVER the first-stage rows: a large step
+// (timidAfterLarge) -> dims 4b .. 4b+3 (uniforms); otherwise the orbital angles of pairs 4b .. 4b+3 = dims 8b .. 8b+7
+DEV void v5_fill_second(const DParams &P, uint32_t D, uint32_t col, size_t xcol, uint32_t b, uint32_t major, uint32_t chain, bool large) {
+    FP_STRICT;
+    const u4 r = philox4x32_10(P.key0, P.key1, b, major, chain, TAG_S2);
+    const float u[4] = {u32_to_unit(r.x), u32_to_unit(r.y), u32_to_unit(r.z), u32_to_unit(r.w)};
+    if (large) {
+#pragma unroll
+        for (uint32_t i = 0; i < 4u; ++i)
+            if (4u * b + i < D) lds_x[(4u * b + i) * 64u + col] = u[i];
+        return;
+    }
+#pragma unroll
+    for (uint32_t i = 0; i < 4u; ++i) {
+        const uint32_t k0 = 2u * (4u * b + i);
+        if (k0 + 1u < D) {
+            const float x0 = load_global_f32(P.x + (size_t) k0 * P.n_chains + xcol), x1 = load_global_f32(P.x + (size_t) (k0 + 1u) * P.n_chains + xcol);
+            const float y0 = lds_x[k0 * 64u + col], y1 = lds_x[(k0 + 1u) * 64u + col];
+            // theta ~ wrapped Cauchy by inverse CDF (transition.h:157-173); z = y + R(theta)(x - y) (drmlt_sampler.cpp:374-391)
+            float xi = u[i], sign = 1.f;
+            if (xi < 0.5f) { xi *= 2.f; } else { sign = -1.f; xi = 2.f * (xi - 0.5f); }
+            const float V = cos_rev(xi);
+            const float A = fminf(1.f, fmaxf(-1.f, (V + WC_DISPERSION) / (1.f + WC_DISPERSION * V)));
+            const float ct = A, st = sign * sqrtf(fmaxf(0.f, 1.f - A * A));
+            const float dx0 = x0 - y0, dx1 = x1 - y1;
+            lds_x[k0 * 64u + col] = y0 + (ct * dx0 - st * dx1);
+            lds_x[(k0 + 1u) * 64u + col] = y1 + (st * dx0 + ct * dx1);
+        }
+    }
+}
 
 template <int FEAT, bool STACK16, bool OVF, bool STAMPS = false>
 __global__ void __launch_bounds__(CHAIN_BLOCK, 2) k_mutate_v5(DParams P, uint32_t n_mut, uint32_t mut_base) {
+    // per-section copies of the parameter block, read through a kernarg pointer the compiler cannot see through (see k_mutate_v4):
+    // the fields a section uses are scalar loads at its head and dead at its end, instead of ~200 spilled scalar registers
+    typedef const DParams __attribute__((address_space(4))) *KArg;
+    const KArg kp = (KArg) __builtin_amdgcn_kernarg_segment_ptr();
+#define SECTION_PARAMS(name)                                               \
+    KArg name##_q = kp;                                                    \
+    asm volatile("" : "+s"(name##_q));                                     \
+    DParams name;                                                          \
+    load_params(name, name##_q)
+    SECTION_PARAMS(P0);
     const uint32_t lane = threadIdx.x;
-    const uint32_t c = blockIdx.x * 64u + lane;
-    const bool live = c < P.n_chains;
-    const uint32_t cc = live ? c : P.n_chains - 1;
-    const uint32_t S = V5_STRIDE, D = (uint32_t) P.eff_dim;
+    const uint32_t wave_base = blockIdx.x * 64u;
+    const uint32_t c = wave_base + lane;
+    const bool live = c < P0.n_chains;
+    const uint32_t cc = live ? c : P0.n_chains - 1;
+    const uint32_t D = (uint32_t) P0.eff_dim, nb1 = (D + 3u) / 4u;
     const V5Lds L = v5_layout(D);
     const V4Lds Lq{0u, 0u, L.q_off, V5_QCAP};
     unsigned char *const ring = reinterpret_cast<unsigned char *>(&lds_x[L.ring_off]);
     unsigned char *const status = reinterpret_cast<unsigned char *>(&lds_x[L.status_off]);
+    int *const lds_list = reinterpret_cast<int *>(&lds_x[L.list_off]);
     float *const pool = &lds_x[L.pool_off];
-    for (uint32_t k = 0; k < D; ++k) lds_x[k * S + lane] = P.x[(size_t) k * P.n_chains + cc];
     status[lane] = RS_IDLE; status[64u + lane] = RS_IDLE;
 
     ChainState cs;
-    cs.cur.lum = P.cur_lum[cc]; cs.cur.px = P.cur_px[cc]; cs.cur.py = P.cur_py[cc];
-    cs.cur.r = P.cur_r[cc]; cs.cur.g = P.cur_g[cc]; cs.cur.b = P.cur_b[cc];
+    cs.cur.lum = P0.cur_lum[cc]; cs.cur.px = P0.cur_px[cc]; cs.cur.py = P0.cur_py[cc];
+    cs.cur.r = P0.cur_r[cc]; cs.cur.g = P0.cur_g[cc]; cs.cur.b = P0.cur_b[cc];
     cs.y = cs.cur; cs.z = cs.cur;
     cs.a1 = 0.f; cs.coin_acc1 = cs.coin_acc2 = cs.coin_mix = 0.f;
     cs.it = 0u; cs.nd1 = cs.nd2 = 0u; cs.stage = -1; cs.large = false; cs.do_second = false;
     float cum = 0.f; // weight of the current state since it was adopted (one splat per residence, as k_mutate_v4)
     uint32_t qn = 0u;
     Counters ct = {0u, 0u, 0u, 0u, 0u};
-
-    SamplerT<V5_STRIDE> smp;
-    smp.key0 = P.key0; smp.key1 = P.key1; smp.chain = P.chain_offset + cc; smp.major = 0u;
-    smp.mode = SM_STAGE1; smp.type = P.type; smp.large = false; smp.sigma2 = P.sigma2; smp.lane = lane; smp.arr = nullptr;
-    smp.reset_caches();
+    PoolRowSampler smp{lane};
 
     PathState ps;
-    path_init(P, ps);
+    path_init(P0, ps);
     ps.o = mk3(0.f, 0.f, 0.f); ps.d = mk3(0.f, 0.f, 1.f); ps.tmin = 0.f; ps.tmax = 0.f;
     // run-ahead between the launches of a call: as k_mutate_v4 (chain_done / waves_left / run_limit)
-    const uint32_t base = (P.chain_done && live) ? P.chain_done[cc] : mut_base;
-    const uint32_t target = P.chain_done ? n_mut : mut_base + n_mut;
-    const uint32_t limit = P.chain_done ? P.run_limit : target;
+    const uint32_t base = (P0.chain_done && live) ? P0.chain_done[cc] : mut_base;
+    const uint32_t target = P0.chain_done ? n_mut : mut_base + n_mut;
+    const uint32_t limit = P0.chain_done ? P0.run_limit : target;
     bool reported = false;
     ps.phase = (live && base < limit) ? PH_DONE : PH_IDLE;
-    const int batch = P.mh_batch > 64 ? 64 : P.mh_batch;
-    const GlobalTables GT{P.shade, P.bsdfs, P.emitters};
+    const int batch = P0.mh_batch > 64 ? 64 : P0.mh_batch;
+    { // coins of every chain's first mutation of this launch (afterwards they are drawn one mutation ahead, beside the proposal)
+        const u4 coins = philox4x32_10(P0.key0, P0.key1, 0u, base, P0.chain_offset + cc, TAG_COIN);
+        float *dst = &lds_x[L.coin_off + lane];
+        dst[0] = u32_to_unit(coins.x); dst[64] = u32_to_unit(coins.y); dst[128] = u32_to_unit(coins.z); dst[192] = u32_to_unit(coins.w);
+    }
 
     // traversal: this lane's column of the stack, the ray it is working on (`slot`), the FIFO of pending slots
     typedef typename std::conditional<STACK16, short, int>::type StackT;
     constexpr int CAP = STACK16 ? BVH_STACK : V4_STACK32_CAP;
     __shared__ StackT v5_stack[(CAP + 3) * 64];
-    const TravLoop<StackT, DParams, OVF || !STACK16, CAP, FEAT> TL(P, v5_stack + lane);
+    StackT *const my_stack = v5_stack + lane;
     Trav T;
     T.active = false; T.cur = 0; T.sp = 0; T.ovf = 0; T.rx = T.ry = T.rz = 0u; T.any_hit = false; T.h = Hit{-1, 0.f, 0.f, 0.f}; T.tmin = 0.f;
     T.o = T.d = T.inv = T.oi = mk3(0.f, 0.f, 0.f);
@@ -995,6 +1071,7 @@ __global__ void __launch_bounds__(CHAIN_BLOCK, 2) k_mutate_v5(DParams P, uint32_
     unsigned long long n_phase = 0ull, n_refill = 0ull, n_lanes_at_start = 0ull;
     unsigned long long t_mh = 0ull, t_step = 0ull, t_trace = 0ull, n_outer = 0ull, n_mh = 0ull, n_stepping = 0ull, n_parked = 0ull;
 #define STAMP5() (STAMPS ? __builtin_amdgcn_s_memtime() : 0ull)
+    auto prefix = [](unsigned long long m) { return __builtin_amdgcn_mbcnt_hi((uint32_t) (m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) m, 0u)); };
 
     for (;;) {
         const bool parked = ps.phase == PH_DONE;
@@ -1003,18 +1080,19 @@ __global__ void __launch_bounds__(CHAIN_BLOCK, 2) k_mutate_v5(DParams P, uint32_
         if (!pmask && !rmask) break;
         const bool rays_in_flight = q_count != 0u || __ballot(T.active) != 0ull;
         const unsigned long long s0 = STAMP5();
-        n_outer++;
-        // ---------------------------------------------------------------- bookkeeping: decide, commit, start
+        if (STAMPS) n_outer++;
+        // ---------------------------------------------------------------- bookkeeping: decide, commit, proposals, start
         if (pmask && (__popcll(pmask) >= batch || !rays_in_flight)) {
+            SECTION_PARAMS(Pm);
             if (STAMPS) { n_mh++; n_parked += (unsigned long long) __popcll(pmask); }
-            if (qn + 192u > V5_QCAP + 64u) v4_flush(P, Lq, qn, lane); // room for this branch's splats (three rounds of at most 64, flushed in between)
-            int commit = 0;
+            if (qn + 64u > V5_QCAP) v4_flush(Pm, Lq, qn, lane);
+            int commit = 0, kind = 0; // kind: 0 nothing / finished, 1 next mutation, 2 second stage (4: between mutations, resolved below)
             bool want0 = false, want1 = false, want2 = false;
             float e0x = 0.f, e0y = 0.f, e0r = 0.f, e0g = 0.f, e0b = 0.f;
             float e1x = 0.f, e1y = 0.f, e1r = 0.f, e1g = 0.f, e1b = 0.f;
             float e2x = 0.f, e2y = 0.f, e2r = 0.f, e2g = 0.f, e2b = 0.f;
             if (parked) {
-                const MhOutcome o = mh_decide(P, cs, smp, ps, ct);
+                const MhOutcome o = mh_decide(Pm, cs, smp, ps, ct);
                 if (o.decided) {
                     cum += o.w.w0;
                     const bool a1st = o.commit == SM_STAGE1, a2nd = o.commit == SM_STAGE2;
@@ -1034,57 +1112,128 @@ __global__ void __launch_bounds__(CHAIN_BLOCK, 2) k_mutate_v5(DParams P, uint32_
                     }
                     commit = o.commit;
                 }
+                kind = cs.stage < 0 ? 4 : 2; // (stage 2, Green's reverse move, does not occur: type = orbital)
             }
-            // the queue holds V5_QCAP entries: at most 64 per round
+            {
+                // between mutations: go on while short of the target; beyond it (run-ahead) while anybody in the grid is short
+                const uint32_t done_now = base + cs.it;
+                const bool under = __ballot(live && done_now < target) != 0ull;
+                bool more = under;
+                if (Pm.chain_done) {
+                    if (!under && !reported) { reported = true; if (lane == 0) atomicSub(Pm.waves_left, 1u); }
+                    if (!under) more = __builtin_amdgcn_readfirstlane((int) __hip_atomic_load(Pm.waves_left, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != 0;
+                }
+                if (kind == 4) kind = (done_now < target || (done_now < limit && more)) ? 1 : 0;
+            }
+            // the queue holds V5_QCAP entries, a round adds at most 64
             v4_enqueue(Lq, qn, want0, e0x, e0y, e0r, e0g, e0b);
-            if (qn + 64u > V5_QCAP) v4_flush(P, Lq, qn, lane);
+            if (qn + 64u > V5_QCAP) v4_flush(Pm, Lq, qn, lane);
             v4_enqueue(Lq, qn, want1, e1x, e1y, e1r, e1g, e1b);
-            if (qn + 64u > V5_QCAP) v4_flush(P, Lq, qn, lane);
+            if (qn + 64u > V5_QCAP) v4_flush(Pm, Lq, qn, lane);
             v4_enqueue(Lq, qn, want2, e2x, e2y, e2r, e2g, e2b);
-            // DRMLTSampler::accept: uCurrent = wrap(chosen proposal), every kept dimension (the pair cache holds the OLD x of
-            // a pair until both of its components are written: even k computes the pair, odd k reads it)
-            if (commit) {
-                if (commit == SM_STAGE1) { for (uint32_t k = 0; k < D; ++k) lds_x[k * S + lane] = wrap01(smp.y_raw(k)); }
-                else { for (uint32_t k = 0; k < D; ++k) lds_x[k * S + lane] = wrap01(smp.z_raw(k)); }
-            }
-            // what next: the next mutation while short of the target; beyond it (run-ahead) while anybody in the grid is short
-            const uint32_t done_now = base + cs.it;
-            const bool under = __ballot(live && done_now < target) != 0ull;
-            bool more = under;
-            if (P.chain_done) {
-                if (!under && !reported) { reported = true; if (lane == 0) atomicSub(P.waves_left, 1u); }
-                if (!under) more = __builtin_amdgcn_readfirstlane((int) __hip_atomic_load(P.waves_left, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != 0;
-            }
-            if (parked) {
-                bool go = true;
-                if (cs.stage < 0) { // between mutations
-                    go = done_now < target || (done_now < limit && more);
-                    if (go) {
-                        const uint32_t m = done_now;
-                        const u4 coins = philox4x32_10(P.key0, P.key1, 0u, m, smp.chain, TAG_COIN);
-                        cs.large = u32_to_unit(coins.x) < P.p_large;
-                        cs.coin_acc1 = u32_to_unit(coins.y); cs.coin_acc2 = u32_to_unit(coins.z); cs.coin_mix = u32_to_unit(coins.w);
-                        smp.major = m; smp.large = cs.large;
-                        cs.stage = 0; cs.do_second = false; cs.nd1 = cs.nd2 = 0u;
+
+            // ---- commit (DRMLTSampler::accept: uCurrent = wrap(adopted proposal)) to the state's home in device memory,
+            // flattened: items (accepted chain j, row quad q), chain-minor
+            const unsigned long long cmask = __ballot(commit != 0);
+            if (cmask) {
+                if (commit) lds_list[prefix(cmask)] = (int) lane;
+                const uint32_t n = (uint32_t) __popcll(cmask), total = n * nb1;
+                const float rcp_n = 1.f / (float) n;
+                for (uint32_t ib = 0u; ib < total; ib += 64u) {
+                    const uint32_t i = ib + lane;
+                    const bool valid = i < total;
+                    const uint32_t ii = valid ? i : 0u;
+                    const uint32_t q = (uint32_t) (((float) ii + 0.5f) * rcp_n), j = ii - q * n;
+                    const uint32_t cj = (uint32_t) lds_list[j];
+                    if (valid) {
+                        const float *src = &lds_x[4u * q * 64u + cj];
+                        float *dst = Pm.x + (size_t) (4u * q) * Pm.n_chains + wave_base + cj;
+#pragma unroll
+                        for (uint32_t r = 0; r < 4u; ++r)
+                            if (4u * q + r < D) dst[(size_t) r * Pm.n_chains] = wrap01(src[r * 64u]);
                     }
                 }
-                if (!go) ps.phase = PH_IDLE;
+            }
+            // this wave's own stores to the state rows must have landed before the proposals below read them back (same CU: the
+            // wait is all a workgroup-scope fence amounts to)
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+            // ---- start (parked chain lanes): the coins of the mutation that begins were drawn with the previous one
+            if (parked && kind == 1) {
+                const float *cn = &lds_x[L.coin_off + lane];
+                cs.large = cn[0] < Pm.p_large;
+                cs.coin_acc1 = cn[64]; cs.coin_acc2 = cn[128]; cs.coin_mix = cn[192];
+                cs.stage = 0;
+                cs.do_second = false;
+                cs.nd1 = cs.nd2 = 0u;
+            }
+            // ---- proposals, flattened: items (chain j, Philox block b) -> dimensions 4b .. 4b+3 of y from the state in device
+            // memory (the commits above are this wave's own stores: visible to its later loads); block nb1 = the four coins of
+            // the NEXT mutation
+            const uint32_t chain_base = Pm.chain_offset + wave_base;
+            const uint32_t maj_mine = base + cs.it; // the mutation in flight
+            const unsigned info = cs.large ? 1u : 0u;
+            const unsigned long long f1mask = __ballot(kind == 1);
+            if (f1mask) {
+                if (kind == 1) lds_list[prefix(f1mask)] = (int) lane;
+                const uint32_t n = (uint32_t) __popcll(f1mask), total = n * (nb1 + 1u);
+                const float rcp_n = 1.f / (float) n;
+                for (uint32_t ib = 0u; ib < total; ib += 64u) {
+                    const uint32_t i = ib + lane;
+                    const bool valid = i < total;
+                    const uint32_t ii = valid ? i : 0u;
+                    const uint32_t b = (uint32_t) (((float) ii + 0.5f) * rcp_n), j = ii - b * n;
+                    const uint32_t cj = (uint32_t) lds_list[j];
+                    const uint32_t mj = (uint32_t) __shfl((int) maj_mine, (int) cj, 64);
+                    const unsigned inf = (unsigned) __shfl((int) info, (int) cj, 64);
+                    if (valid) {
+                        if (b < nb1) v5_fill_first(Pm, D, cj, (size_t) wave_base + cj, b, mj, chain_base + cj, inf != 0u);
+                        else {
+                            const u4 coins = philox4x32_10(Pm.key0, Pm.key1, 0u, mj + 1u, chain_base + cj, TAG_COIN);
+                            float *dst = &lds_x[L.coin_off + cj];
+                            dst[0] = u32_to_unit(coins.x); dst[64] = u32_to_unit(coins.y); dst[128] = u32_to_unit(coins.z); dst[192] = u32_to_unit(coins.w);
+                        }
+                    }
+                }
+            }
+            const unsigned long long f2mask = __ballot(kind == 2);
+            if (f2mask) { // second-stage proposals (rejected bold steps), in place over the first-stage rows
+                if (kind == 2) lds_list[prefix(f2mask)] = (int) lane;
+                const uint32_t nb2 = Pm.timid_after_large ? nb1 : (D / 2u + 3u) / 4u; // uniforms for a large step: one per dim; else one angle per pair
+                const uint32_t n = (uint32_t) __popcll(f2mask), total = n * nb2;
+                const float rcp_n = 1.f / (float) n;
+                for (uint32_t ib = 0u; ib < total; ib += 64u) {
+                    const uint32_t i = ib + lane;
+                    const bool valid = i < total;
+                    const uint32_t ii = valid ? i : 0u;
+                    const uint32_t b = (uint32_t) (((float) ii + 0.5f) * rcp_n), j = ii - b * n;
+                    const uint32_t cj = (uint32_t) lds_list[j];
+                    const uint32_t mj = (uint32_t) __shfl((int) maj_mine, (int) cj, 64);
+                    const unsigned inf = (unsigned) __shfl((int) info, (int) cj, 64);
+                    if (valid && (inf != 0u || b < (D / 2u + 3u) / 4u)) v5_fill_second(Pm, D, cj, (size_t) wave_base + cj, b, mj, chain_base + cj, inf != 0u);
+                }
+            }
+            // ---- begin the evaluation: film position and camera ray from the first two components; the ray goes into the pool
+            if (parked) {
+                if (kind == 0) ps.phase = PH_IDLE;
                 else {
-                    smp.mode = cs.stage == 0 ? SM_STAGE1 : (cs.stage == 1 ? SM_STAGE2 : SM_REVERSE);
-                    smp.reset_caches();
-                    path_init(P, ps); // PH_BEGIN: the step phase below draws the film position and issues the camera ray
+                    path_init(Pm, ps);
+                    const float v0 = smp.next(0u), v1 = smp.next(1u);
+                    path_begin(Pm, ps, v0, v1);
                 }
             }
         }
-
         const unsigned long long s1 = STAMP5();
+
         // ---------------------------------------------------------------- step: chains whose ray results are in
         {
+            SECTION_PARAMS(Ps);
             const int st_c = status[lane], st_s = status[64u + lane];
-            const bool ready = ps.phase == PH_BEGIN || (ps.phase == PH_CLOSEST && st_c == RS_DONE && st_s != RS_BUSY) ||
-                               (ps.phase == PH_FLUSH && st_s != RS_BUSY);
-            bool push_c = false, push_s = false;
+            const bool fresh = ps.phase == PH_CLOSEST && st_c == RS_IDLE; // a camera ray of the bookkeeping branch above: not yet in the pool
+            const bool ready = (ps.phase == PH_CLOSEST && st_c == RS_DONE && st_s != RS_BUSY) || (ps.phase == PH_FLUSH && st_s != RS_BUSY);
+            bool push_c = fresh, push_s = false;
             if (STAMPS) n_stepping += (unsigned long long) __popcll(__ballot(ready));
+            ShadowRay sr;
+            sr.o = ps.o; sr.d = ps.d; sr.tmin = 0.f; sr.tmax = 0.f; sr.valid = false;
             if (ready) {
                 Hit h{-1, 0.f, 0.f, 0.f};
                 if (ps.phase == PH_CLOSEST) {
@@ -1092,44 +1241,45 @@ __global__ void __launch_bounds__(CHAIN_BLOCK, 2) k_mutate_v5(DParams P, uint32_
                 }
                 const bool shadow_clear = st_s == RS_DONE ? pool[64u + lane] == 0.f : true;
                 status[lane] = RS_IDLE; status[64u + lane] = RS_IDLE;
-                ShadowRay sr;
-                sr.o = ps.o; sr.d = ps.d; sr.tmin = 0.f; sr.tmax = 0.f; sr.valid = false;
-                path_step<true, FEAT, SamplerT<V5_STRIDE>, GlobalTables, true>(P, GT, ps, smp, h, shadow_clear, sr);
+                path_step<true, FEAT, PoolRowSampler, GlobalTables, false>(Ps, GlobalTables{Ps.shade, Ps.bsdfs, Ps.emitters}, ps, smp, h, shadow_clear, sr);
                 push_c = ps.phase == PH_CLOSEST;
                 push_s = sr.valid;
-                if (push_c) {
-                    float *r = pool + lane;
-                    r[0] = ps.o.x; r[V5_SLOTS] = ps.o.y; r[2u * V5_SLOTS] = ps.o.z; r[3u * V5_SLOTS] = ps.d.x; r[4u * V5_SLOTS] = ps.d.y; r[5u * V5_SLOTS] = ps.d.z;
-                    r[6u * V5_SLOTS] = ps.tmin; r[7u * V5_SLOTS] = ps.tmax;
-                    status[lane] = RS_BUSY;
-                }
-                if (push_s) {
-                    float *r = pool + 64u + lane;
-                    r[0] = sr.o.x; r[V5_SLOTS] = sr.o.y; r[2u * V5_SLOTS] = sr.o.z; r[3u * V5_SLOTS] = sr.d.x; r[4u * V5_SLOTS] = sr.d.y; r[5u * V5_SLOTS] = sr.d.z;
-                    r[6u * V5_SLOTS] = sr.tmin; r[7u * V5_SLOTS] = sr.tmax;
-                    status[64u + lane] = RS_BUSY;
-                }
+            }
+            if (push_c) {
+                float *r = pool + lane;
+                r[0] = ps.o.x; r[V5_SLOTS] = ps.o.y; r[2u * V5_SLOTS] = ps.o.z; r[3u * V5_SLOTS] = ps.d.x; r[4u * V5_SLOTS] = ps.d.y; r[5u * V5_SLOTS] = ps.d.z;
+                r[6u * V5_SLOTS] = ps.tmin; r[7u * V5_SLOTS] = ps.tmax;
+                status[lane] = RS_BUSY;
+            }
+            if (push_s) {
+                float *r = pool + 64u + lane;
+                r[0] = sr.o.x; r[V5_SLOTS] = sr.o.y; r[2u * V5_SLOTS] = sr.o.z; r[3u * V5_SLOTS] = sr.d.x; r[4u * V5_SLOTS] = sr.d.y; r[5u * V5_SLOTS] = sr.d.z;
+                r[6u * V5_SLOTS] = sr.tmin; r[7u * V5_SLOTS] = sr.tmax;
+                status[64u + lane] = RS_BUSY;
             }
             // ray compaction: the lanes that issued a ray append its slot to the FIFO (ballot + prefix count)
             const unsigned long long mc = __ballot(push_c);
-            if (push_c) ring[(q_head + q_count + __builtin_amdgcn_mbcnt_hi((uint32_t) (mc >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) mc, 0u))) & (V5_SLOTS - 1u)] = (unsigned char) lane;
+            if (push_c) ring[(q_head + q_count + prefix(mc)) & (V5_SLOTS - 1u)] = (unsigned char) lane;
             q_count += (uint32_t) __popcll(mc);
             const unsigned long long ms = __ballot(push_s);
-            if (push_s) ring[(q_head + q_count + __builtin_amdgcn_mbcnt_hi((uint32_t) (ms >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) ms, 0u))) & (V5_SLOTS - 1u)] = (unsigned char) (64u + lane);
+            if (push_s) ring[(q_head + q_count + prefix(ms)) & (V5_SLOTS - 1u)] = (unsigned char) (64u + lane);
             q_count += (uint32_t) __popcll(ms);
         }
-
         const unsigned long long s2 = STAMP5();
+
         // ---------------------------------------------------------------- trace: the pool's rays, any lane any ray
         {
+            SECTION_PARAMS(Pt);
+            const TravLoop<StackT, DParams, OVF || !STACK16, CAP, FEAT> TL(Pt, my_stack);
+            const int yield_lanes = Pt.trace_yield;
             int finished_closest = 0;
             bool first = true;
-            n_phase++;
+            if (STAMPS) n_phase++;
             for (;;) {
                 // idle lanes take pending slots off the queue (at the start of a phase, and whenever a few lanes have run dry)
                 const unsigned long long idle = __ballot(!T.active);
                 if (q_count != 0u && idle != 0ull && (first || __popcll(idle) >= 4 || idle == ~0ull)) {
-                    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t) (idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) idle, 0u));
+                    const uint32_t rank = prefix(idle);
                     const bool take = !T.active && rank < q_count;
                     if (take) {
                         slot = ring[(q_head + rank) & (V5_SLOTS - 1u)];
@@ -1140,11 +1290,11 @@ __global__ void __launch_bounds__(CHAIN_BLOCK, 2) k_mutate_v5(DParams P, uint32_
                     const uint32_t taken = min((uint32_t) __popcll(idle), q_count);
                     q_head = (q_head + taken) & (V5_SLOTS - 1u);
                     q_count -= taken;
-                    n_refill++;
+                    if (STAMPS) n_refill++;
                 }
-                if (first) n_lanes_at_start += (unsigned long long) __popcll(__ballot(T.active));
+                if (STAMPS && first) n_lanes_at_start += (unsigned long long) __popcll(__ballot(T.active));
                 first = false;
-                if (finished_closest >= P.trace_yield) break;
+                if (finished_closest >= yield_lanes) break;
                 bool any;
                 const bool done_now = TL.step(T, true, any);
                 if (!any) break; // (the queue is empty too: an idle wave with pending slots refills above)
@@ -1164,28 +1314,29 @@ __global__ void __launch_bounds__(CHAIN_BLOCK, 2) k_mutate_v5(DParams P, uint32_
         t_mh += s1 - s0; t_step += s2 - s1; t_trace += s3 - s2;
     }
 #undef STAMP5
+    SECTION_PARAMS(Pe);
+#undef SECTION_PARAMS
     if (STAMPS && lane == 0) {
-        atomicAdd(P.stats + 16, t_mh); atomicAdd(P.stats + 17, t_trace); atomicAdd(P.stats + 18, t_step); atomicAdd(P.stats + 19, n_outer);
-        atomicAdd(P.stats + 23, n_mh); atomicAdd(P.stats + 24, n_parked); atomicAdd(P.stats + 25, n_stepping);
+        atomicAdd(Pe.stats + 16, t_mh); atomicAdd(Pe.stats + 17, t_trace); atomicAdd(Pe.stats + 18, t_step); atomicAdd(Pe.stats + 19, n_outer);
+        atomicAdd(Pe.stats + 23, n_mh); atomicAdd(Pe.stats + 24, n_parked); atomicAdd(Pe.stats + 25, n_stepping);
     }
     // "Perform the last splat": the current states with what they have accumulated since they were adopted
-    if (qn + 64u > V5_QCAP) v4_flush(P, Lq, qn, lane);
+    if (qn + 64u > V5_QCAP) v4_flush(Pe, Lq, qn, lane);
     v4_enqueue(Lq, qn, live && cum > 0.f, cs.cur.px, cs.cur.py, cs.cur.r * cum, cs.cur.g * cum, cs.cur.b * cum);
-    v4_flush(P, Lq, qn, lane);
-    if (live) {
-        for (uint32_t k = 0; k < D; ++k) P.x[(size_t) k * P.n_chains + c] = lds_x[k * S + lane];
-        P.cur_lum[c] = cs.cur.lum; P.cur_px[c] = cs.cur.px; P.cur_py[c] = cs.cur.py;
-        P.cur_r[c] = cs.cur.r; P.cur_g[c] = cs.cur.g; P.cur_b[c] = cs.cur.b;
-        if (P.chain_done) P.chain_done[c] = base + cs.it;
+    v4_flush(Pe, Lq, qn, lane);
+    if (live) { // (the PSS state is at home in device memory already)
+        Pe.cur_lum[c] = cs.cur.lum; Pe.cur_px[c] = cs.cur.px; Pe.cur_py[c] = cs.cur.py;
+        Pe.cur_r[c] = cs.cur.r; Pe.cur_g[c] = cs.cur.g; Pe.cur_b[c] = cs.cur.b;
+        if (Pe.chain_done) Pe.chain_done[c] = base + cs.it;
     }
-    if (P.chain_done && !reported && lane == 0) atomicSub(P.waves_left, 1u); // (a wave none of whose chains had anything to do)
-    flush_counters(P, ct, lane);
+    if (Pe.chain_done && !reported && lane == 0) atomicSub(Pe.waves_left, 1u); // (a wave none of whose chains had anything to do)
+    flush_counters(Pe, ct, lane);
     const unsigned long long decided = wave_sum(live ? cs.it : 0u);
     const unsigned long long nn = wave_sum(T.n_nodes), np = wave_sum(T.n_prims);
     if (lane == 0) {
-        atomicAdd(P.stats + 9, decided);
-        atomicAdd(P.stats + 10, nn); atomicAdd(P.stats + 11, np); atomicAdd(P.stats + 12, (unsigned long long) T.it_inner); atomicAdd(P.stats + 13, (unsigned long long) T.it_leaf);
-        if (P.debug & (1024 | 128)) { atomicAdd(P.stats + 20, n_phase); atomicAdd(P.stats + 21, n_lanes_at_start); atomicAdd(P.stats + 22, n_refill); }
+        atomicAdd(Pe.stats + 9, decided);
+        atomicAdd(Pe.stats + 10, nn); atomicAdd(Pe.stats + 11, np); atomicAdd(Pe.stats + 12, (unsigned long long) T.it_inner); atomicAdd(Pe.stats + 13, (unsigned long long) T.it_leaf);
+        if (STAMPS) { atomicAdd(Pe.stats + 20, n_phase); atomicAdd(Pe.stats + 21, n_lanes_at_start); atomicAdd(Pe.stats + 22, n_refill); }
     }
 }
 

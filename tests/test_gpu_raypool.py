@@ -1,7 +1,8 @@
 """k_mutate_v5, the ray-pool chain kernel of BVH scenes (64 chains per wave, rays queued in LDS, any lane traverses any
 ray; north_star's "wavefront ballot / prefix-sum ray compaction"): it must run the chains of k_mutate_v4 / k_mutate_v3 bit
 for bit -- same addressed draws, same proposal arithmetic, same acceptance code (device_mh.h) -- whatever the order in
-which the wave happens to traverse its rays."""
+which the wave happens to traverse its rays. (type = orbital: the kernel keeps one proposal row group in LDS; Green / Mira
+scenes stay on k_mutate_v4, which the last test checks.)"""
 import os
 
 import numpy as np
@@ -30,20 +31,22 @@ def ctx_with_env(pkg, cfg, sd, **env):
 
 CASES = [
     ("triangle_soup", dict(n_tris=2000), dict(type="orbital"), {}),                                  # 16-bit stacks, diffuse-only build
-    ("triangle_soup", dict(n_tris=2000), dict(type="green"), {}),
-    ("triangle_soup", dict(n_tris=2000), dict(type="mira", timid_after_large=1), {}),
+    ("triangle_soup", dict(n_tris=2000), dict(type="orbital", timid_after_large=1), {}),             # second stages after large steps: uniform rows
     ("triangle_soup", dict(n_tris=2000), dict(type="orbital", use_mixture=1), {}),
+    ("triangle_soup", dict(n_tris=2000), dict(type="orbital", p_large=0.02, max_depth=5, rr_depth=2), {}),   # another state size (D = 18)
     ("triangle_soup", dict(n_tris=40000), dict(type="orbital"), {}),                                 # 32-bit stacks, overflow area in use
     ("caustic_c5", {}, dict(type="orbital"), dict(DRMLT_BVH_THRESHOLD=0)),                           # spheres + dielectric in the leaves
-    ("door_c3", {}, dict(type="green"), dict(DRMLT_BVH_THRESHOLD=0)),                                # rough conductor
+    ("door_c3", {}, dict(type="orbital"), dict(DRMLT_BVH_THRESHOLD=0)),                              # rough conductor
 ]
 
 
-@pytest.mark.parametrize("scene,skw,kw,env", CASES, ids=["soup-orbital", "soup-green", "soup-mira-timid", "soup-mixture", "soup40k", "caustic-bvh", "door-bvh"])
+@pytest.mark.parametrize("scene,skw,kw,env", CASES, ids=["soup-orbital", "soup-timid", "soup-mixture", "soup-short", "soup40k", "caustic-bvh", "door-bvh"])
 def test_ray_pool_kernel_runs_the_same_chains(pkg, native_lib, scene, skw, kw, env):
     sd = pkg.scenes.SCENES[scene](res=32, **skw)
     n_chains, n_mut = 1000, 60                       # 1000: the last wave of either kernel is ragged
-    cfg = pkg.abi.make_config(max_depth=8, direct_samples=-1, luminance_samples=20000, work_units=n_chains, sample_count=1, **kw)
+    base = dict(max_depth=8, direct_samples=-1, luminance_samples=20000, work_units=n_chains, sample_count=1)
+    base.update(kw)
+    cfg = pkg.abi.make_config(**base)
     res = []
     for kern in (4, 5):
         ctx = ctx_with_env(pkg, cfg, sd, DRMLT_KERNEL=kern, **env)
@@ -83,3 +86,17 @@ def test_ray_pool_kernel_with_run_ahead_and_acceptance_map(pkg, native_lib):
     for u, s, f in res[1:]:
         assert np.array_equal(u, res[0][0]) and s.accepted == res[0][1].accepted and s.mutations == n_chains * per_chain
         np.testing.assert_array_equal(f, res[0][2])                                   # marks are whole numbers of box weights: exact
+
+
+def test_iid_kernel_types_stay_on_v4(pkg, native_lib, capfd):
+    sd = pkg.scenes.triangle_soup(2000, 32)
+    cfg = pkg.abi.make_config(type="green", max_depth=8, direct_samples=-1, luminance_samples=20000, work_units=512, sample_count=1)
+    ctx = ctx_with_env(pkg, cfg, sd, DRMLT_KERNEL=5, DRMLT_VERBOSE=1)
+    ctx.seed(1)
+    os.environ["DRMLT_VERBOSE"] = "1"
+    try:
+        ctx.run(512 * 4)
+    finally:
+        del os.environ["DRMLT_VERBOSE"]
+    err = capfd.readouterr().err
+    assert "k_mutate_v4" in err and "k_mutate_v5" not in err
