@@ -147,6 +147,8 @@ struct DParams {
     int32_t *bvh_overflow;       // [entry][lane of the grid]: where a traversal stack that outgrows its LDS column puts its oldest entries, or NULL
     uint32_t bvh_ovf_lanes;      // column count of that area (>= lanes of the launch)
     int32_t trace_vote;          // traversal: the wave tests nodes when 16 * (lanes at a leaf) <= trace_vote * (lanes at a node), leaves otherwise
+    int32_t pool_refill;         // k_mutate_v5: idle lanes take pending rays off the queue inside a trace phase once this many lanes have run dry
+    int32_t pad_end;
 };
 
 // result of one PSS evaluation, SoA-friendly

@@ -543,6 +543,8 @@ drmlt_ctx *drmlt_create(const drmlt_config *cfg, const drmlt_scene *scene, int d
     // 16: 5.08 / 5.37 / 5.20, 20: 5.25 / 5.44 / 5.10, 24: 5.31 / 5.40 / 4.81
     P.trace_yield = P.kernel_variant == 5 ? 20 : (P.bvh_stack16 ? 24 : 20);
     if (const char *k = getenv("DRMLT_TRACE_YIELD")) P.trace_yield = std::max(0, std::min(64, atoi(k)));
+    P.pool_refill = 8; // soup, 131 072 chains: 1 5.38e8, 2 5.41e8, 4 5.43e8, 8 5.45e8, 16 5.37e8 mutations/s
+    if (const char *k = getenv("DRMLT_POOL_REFILL")) P.pool_refill = std::max(1, std::min(64, atoi(k)));
     P.trace_vote = 10; // measured on the 2000-triangle soup: 16 (plain majority) 2.70e8, 10 2.78e8, 5 2.73e8 mutations/s
     if (const char *k = getenv("DRMLT_TRACE_VOTE")) P.trace_vote = std::max(1, std::min(1024, atoi(k)));
     if (hipDeviceSynchronize() != hipSuccess) return bail(ctx, "device synchronisation failed after setup");

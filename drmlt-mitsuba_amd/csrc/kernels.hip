@@ -1271,14 +1271,14 @@ __global__ void __launch_bounds__(CHAIN_BLOCK, 2) k_mutate_v5(DParams P, uint32_
         {
             SECTION_PARAMS(Pt);
             const TravLoop<StackT, DParams, OVF || !STACK16, CAP, FEAT> TL(Pt, my_stack);
-            const int yield_lanes = Pt.trace_yield;
+            const int yield_lanes = Pt.trace_yield, refill_at = Pt.pool_refill;
             int finished_closest = 0;
             bool first = true;
             if (STAMPS) n_phase++;
             for (;;) {
                 // idle lanes take pending slots off the queue (at the start of a phase, and whenever a few lanes have run dry)
                 const unsigned long long idle = __ballot(!T.active);
-                if (q_count != 0u && idle != 0ull && (first || __popcll(idle) >= 4 || idle == ~0ull)) {
+                if (q_count != 0u && idle != 0ull && (first || __popcll(idle) >= refill_at || idle == ~0ull)) {
                     const uint32_t rank = prefix(idle);
                     const bool take = !T.active && rank < q_count;
                     if (take) {
