@@ -532,8 +532,12 @@ drmlt_ctx *drmlt_create(const drmlt_config *cfg, const drmlt_scene *scene, int d
     if (getenv("DRMLT_FEAT_ALL")) P.features = 15;
     // the ray-pool kernel is the BVH scenes' (flat scenes loop over their records: rays need no regrouping there), and it keeps ONE
     // proposal row group in LDS: type = orbital only (Green's reverse move and Mira's ratio need x, y and z together)
-    if (P.kernel_variant == 5 && (!P.use_bvh || cfg->type != DRMLT_TYPE_ORBITAL)) P.kernel_variant = 4;
-    P.mh_batch = P.kernel_variant == 5 ? 16 : (P.kernel_variant == 4 ? (P.use_bvh ? (P.bvh_stack16 ? 6 : 4) : (P.features == 0 ? 12 : 8)) : 32); // v4 / v5: chains run free, the bookkeeping branch fires as soon as a few are parked
+    // On flat scenes it runs when asked for (DRMLT_KERNEL=5 / chains beyond 65 536): it needs 131 072 chains to put two waves on a
+    // SIMD, and BASELINE's config 2 fixes 65 536.
+    const bool v5_forced = getenv("DRMLT_KERNEL") && atoi(getenv("DRMLT_KERNEL")) == 5;
+    if (P.kernel_variant == 5 && (cfg->type != DRMLT_TYPE_ORBITAL || (!P.use_bvh && !v5_forced))) P.kernel_variant = 4;
+    // (v5 on the Cornell scene, 131 072 chains: batch 16 1.98e9, 24 2.08e9, 32 2.13e9, 48 1.84e9; on the soup: 8 5.05e8, 16 5.24e8, 32 5.06e8)
+    P.mh_batch = P.kernel_variant == 5 ? (P.use_bvh ? 16 : 32) : (P.kernel_variant == 4 ? (P.use_bvh ? (P.bvh_stack16 ? 6 : 4) : (P.features == 0 ? 12 : 8)) : 32); // v4 / v5: chains run free, the bookkeeping branch fires as soon as a few are parked
     if (const char *k = getenv("DRMLT_MH_BATCH")) P.mh_batch = std::max(1, std::min(64, atoi(k)));
     P.bvh_overflow = nullptr; P.bvh_ovf_lanes = 0;
     P.exec_order = nullptr;

@@ -943,7 +943,7 @@ DEV V5Lds v5_layout(uint32_t D) {
     L.status_off = L.ring_off + V5_SLOTS / 4u;
     return L;
 }
-static size_t v5_lds_bytes(uint32_t D) { return ((size_t) D * 64u + 4u * 64u + 64u + 5u * V5_QCAP + 8u * V5_SLOTS + 2u * (V5_SLOTS / 4u)) * sizeof(float); }
+static size_t v5_lds_bytes(uint32_t D) { return ((size_t) D * 64u + 4u * 64u + 64u + 5u * V5_QCAP + 8u * V5_SLOTS + 2u * (V5_SLOTS / 4u)) * sizeof(float); } // (+ the scene tables, when they are staged)
 
 // the proposal rows as the path step sees them: whatever stage is being evaluated sits in the one row group
 struct PoolRowSampler {
@@ -1004,8 +1004,13 @@ DEV void v5_fill_second(const DParams &P, uint32_t D, uint32_t col, size_t xcol,
     }
 }
 
-template <int FEAT, bool STACK16, bool OVF, bool STAMPS = false>
+// FEAT & 8 (BVH scenes): the traversal loop described above. Flat scenes (FEAT without bit 3; LDS_TABLES: their shading /
+// BSDF / emitter tables staged in LDS) run the same kernel with the wave-uniform brute-force loop as their "trace phase":
+// up to 64 rays off the queue per pass, every one of them done when the pass ends -- so nearly all 64 chains step together
+// (k_mutate_v4 steps at most its 32 chain lanes; the helper lanes idle through the path step).
+template <int FEAT, bool STACK16, bool OVF, bool STAMPS = false, bool LDS_TABLES = false>
 __global__ void __launch_bounds__(CHAIN_BLOCK, 2) k_mutate_v5(DParams P, uint32_t n_mut, uint32_t mut_base) {
+    constexpr bool FLAT = (FEAT & 8) == 0;
     // per-section copies of the parameter block, read through a kernarg pointer the compiler cannot see through (see k_mutate_v4):
     // the fields a section uses are scalar loads at its head and dead at its end, instead of ~200 spilled scalar registers
     typedef const DParams __attribute__((address_space(4))) *KArg;
@@ -1029,6 +1034,11 @@ __global__ void __launch_bounds__(CHAIN_BLOCK, 2) k_mutate_v5(DParams P, uint32_
     int *const lds_list = reinterpret_cast<int *>(&lds_x[L.list_off]);
     float *const pool = &lds_x[L.pool_off];
     status[lane] = RS_IDLE; status[64u + lane] = RS_IDLE;
+    LdsTables LT;
+    LT.shade_off = L.status_off + V5_SLOTS / 4u;
+    LT.bsdf_off = LT.shade_off + (uint32_t) P0.n_shade * 16u;
+    LT.emit_off = LT.bsdf_off + (uint32_t) P0.n_bsdfs * 12u;
+    if (LDS_TABLES) stage_tables(P0, LT, lane);
 
     ChainState cs;
     cs.cur.lum = P0.cur_lum[cc]; cs.cur.px = P0.cur_px[cc]; cs.cur.py = P0.cur_py[cc];
@@ -1060,8 +1070,8 @@ __global__ void __launch_bounds__(CHAIN_BLOCK, 2) k_mutate_v5(DParams P, uint32_
     // traversal: this lane's column of the stack, the ray it is working on (`slot`), the FIFO of pending slots
     typedef typename std::conditional<STACK16, short, int>::type StackT;
     constexpr int CAP = STACK16 ? BVH_STACK : V4_STACK32_CAP;
-    __shared__ StackT v5_stack[(CAP + 3) * 64];
-    StackT *const my_stack = v5_stack + lane;
+    __shared__ StackT v5_stack[FLAT ? 1 : (CAP + 3) * 64];
+    StackT *const my_stack = v5_stack + (FLAT ? 0u : lane);
     Trav T;
     T.active = false; T.cur = 0; T.sp = 0; T.ovf = 0; T.rx = T.ry = T.rz = 0u; T.any_hit = false; T.h = Hit{-1, 0.f, 0.f, 0.f}; T.tmin = 0.f;
     T.o = T.d = T.inv = T.oi = mk3(0.f, 0.f, 0.f);
@@ -1073,245 +1083,293 @@ __global__ void __launch_bounds__(CHAIN_BLOCK, 2) k_mutate_v5(DParams P, uint32_
 #define STAMP5() (STAMPS ? __builtin_amdgcn_s_memtime() : 0ull)
     auto prefix = [](unsigned long long m) { return __builtin_amdgcn_mbcnt_hi((uint32_t) (m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) m, 0u)); };
 
+    // a ray goes into the pool slot of its chain (slot c: closest hit, 64 + c: shadow) and the slot number into the FIFO: ray
+    // compaction by ballot + prefix count over the lanes that issued one
+    auto push_rays = [&](bool push_c, bool push_s, const ShadowRay &sr) {
+        if (push_c) {
+            float *r = pool + lane;
+            r[0] = ps.o.x; r[V5_SLOTS] = ps.o.y; r[2u * V5_SLOTS] = ps.o.z; r[3u * V5_SLOTS] = ps.d.x; r[4u * V5_SLOTS] = ps.d.y; r[5u * V5_SLOTS] = ps.d.z;
+            r[6u * V5_SLOTS] = ps.tmin; r[7u * V5_SLOTS] = ps.tmax;
+            status[lane] = RS_BUSY;
+        }
+        if (push_s) {
+            float *r = pool + 64u + lane;
+            r[0] = sr.o.x; r[V5_SLOTS] = sr.o.y; r[2u * V5_SLOTS] = sr.o.z; r[3u * V5_SLOTS] = sr.d.x; r[4u * V5_SLOTS] = sr.d.y; r[5u * V5_SLOTS] = sr.d.z;
+            r[6u * V5_SLOTS] = sr.tmin; r[7u * V5_SLOTS] = sr.tmax;
+            status[64u + lane] = RS_BUSY;
+        }
+        // ray compaction: the lanes that issued a ray append its slot to the FIFO (ballot + prefix count)
+        const unsigned long long mc = __ballot(push_c);
+        if (push_c) ring[(q_head + q_count + prefix(mc)) & (V5_SLOTS - 1u)] = (unsigned char) lane;
+        q_count += (uint32_t) __popcll(mc);
+        const unsigned long long ms = __ballot(push_s);
+        if (push_s) ring[(q_head + q_count + prefix(ms)) & (V5_SLOTS - 1u)] = (unsigned char) (64u + lane);
+        q_count += (uint32_t) __popcll(ms);
+    };
+
     for (;;) {
-        const bool parked = ps.phase == PH_DONE;
-        const unsigned long long pmask = __ballot(parked);
-        const unsigned long long rmask = __ballot(ps.phase != PH_DONE && ps.phase != PH_IDLE);
-        if (!pmask && !rmask) break;
-        const bool rays_in_flight = q_count != 0u || __ballot(T.active) != 0ull;
-        const unsigned long long s0 = STAMP5();
+        {
+            const unsigned long long pm = __ballot(ps.phase == PH_DONE), rm = __ballot(ps.phase != PH_DONE && ps.phase != PH_IDLE);
+            if (!pm && !rm) break;
+        }
         if (STAMPS) n_outer++;
-        // ---------------------------------------------------------------- bookkeeping: decide, commit, proposals, start
-        if (pmask && (__popcll(pmask) >= batch || !rays_in_flight)) {
-            SECTION_PARAMS(Pm);
-            if (STAMPS) { n_mh++; n_parked += (unsigned long long) __popcll(pmask); }
-            if (qn + 64u > V5_QCAP) v4_flush(Pm, Lq, qn, lane);
-            int commit = 0, kind = 0; // kind: 0 nothing / finished, 1 next mutation, 2 second stage (4: between mutations, resolved below)
-            bool want0 = false, want1 = false, want2 = false;
-            float e0x = 0.f, e0y = 0.f, e0r = 0.f, e0g = 0.f, e0b = 0.f;
-            float e1x = 0.f, e1y = 0.f, e1r = 0.f, e1g = 0.f, e1b = 0.f;
-            float e2x = 0.f, e2y = 0.f, e2r = 0.f, e2g = 0.f, e2b = 0.f;
-            if (parked) {
-                const MhOutcome o = mh_decide(Pm, cs, smp, ps, ct);
-                if (o.decided) {
-                    cum += o.w.w0;
-                    const bool a1st = o.commit == SM_STAGE1, a2nd = o.commit == SM_STAGE2;
-                    want1 = !a1st && o.w.w1 > 0.f;
-                    e1x = cs.y.px; e1y = cs.y.py; e1r = cs.y.r * o.w.w1; e1g = cs.y.g * o.w.w1; e1b = cs.y.b * o.w.w1;
-                    want2 = !a2nd && o.w.w2 > 0.f;
-                    e2x = cs.z.px; e2y = cs.z.py; e2r = cs.z.r * o.w.w2; e2g = cs.z.g * o.w.w2; e2b = cs.z.b * o.w.w2;
-                    if (o.commit) {
-                        want0 = cum > 0.f;
-                        e0x = cs.cur.px; e0y = cs.cur.py; e0r = cs.cur.r * cum; e0g = cs.cur.g * cum; e0b = cs.cur.b * cum;
-                        cum = a1st ? o.w.w1 : o.w.w2;
-                        cs.cur = select_splat(a1st, cs.y, cs.z);
-                        if (o.amap) { // acceptance map: the mark goes to the pixel of the state that was LEFT (device_mh.h)
-                            const f3 mc = mh_amap_colour(o.amap);
-                            want1 = true; e1x = e0x; e1y = e0y; e1r = mc.x; e1g = mc.y; e1b = mc.z;
-                        }
-                    }
-                    commit = o.commit;
-                }
-                kind = cs.stage < 0 ? 4 : 2; // (stage 2, Green's reverse move, does not occur: type = orbital)
-            }
+        auto do_step = [&]() {
+            const unsigned long long t0 = STAMP5();
+            // ---------------------------------------------------------------- step: chains whose ray results are in
             {
-                // between mutations: go on while short of the target; beyond it (run-ahead) while anybody in the grid is short
-                const uint32_t done_now = base + cs.it;
-                const bool under = __ballot(live && done_now < target) != 0ull;
-                bool more = under;
-                if (Pm.chain_done) {
-                    if (!under && !reported) { reported = true; if (lane == 0) atomicSub(Pm.waves_left, 1u); }
-                    if (!under) more = __builtin_amdgcn_readfirstlane((int) __hip_atomic_load(Pm.waves_left, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != 0;
-                }
-                if (kind == 4) kind = (done_now < target || (done_now < limit && more)) ? 1 : 0;
-            }
-            // the queue holds V5_QCAP entries, a round adds at most 64
-            v4_enqueue(Lq, qn, want0, e0x, e0y, e0r, e0g, e0b);
-            if (qn + 64u > V5_QCAP) v4_flush(Pm, Lq, qn, lane);
-            v4_enqueue(Lq, qn, want1, e1x, e1y, e1r, e1g, e1b);
-            if (qn + 64u > V5_QCAP) v4_flush(Pm, Lq, qn, lane);
-            v4_enqueue(Lq, qn, want2, e2x, e2y, e2r, e2g, e2b);
-
-            // ---- commit (DRMLTSampler::accept: uCurrent = wrap(adopted proposal)) to the state's home in device memory,
-            // flattened: items (accepted chain j, row quad q), chain-minor
-            const unsigned long long cmask = __ballot(commit != 0);
-            if (cmask) {
-                if (commit) lds_list[prefix(cmask)] = (int) lane;
-                const uint32_t n = (uint32_t) __popcll(cmask), total = n * nb1;
-                const float rcp_n = 1.f / (float) n;
-                for (uint32_t ib = 0u; ib < total; ib += 64u) {
-                    const uint32_t i = ib + lane;
-                    const bool valid = i < total;
-                    const uint32_t ii = valid ? i : 0u;
-                    const uint32_t q = (uint32_t) (((float) ii + 0.5f) * rcp_n), j = ii - q * n;
-                    const uint32_t cj = (uint32_t) lds_list[j];
-                    if (valid) {
-                        const float *src = &lds_x[4u * q * 64u + cj];
-                        float *dst = Pm.x + (size_t) (4u * q) * Pm.n_chains + wave_base + cj;
-#pragma unroll
-                        for (uint32_t r = 0; r < 4u; ++r)
-                            if (4u * q + r < D) dst[(size_t) r * Pm.n_chains] = wrap01(src[r * 64u]);
+                SECTION_PARAMS(Ps);
+                const int st_c = status[lane], st_s = status[64u + lane];
+                const bool ready = (ps.phase == PH_CLOSEST && st_c == RS_DONE && st_s != RS_BUSY) || (ps.phase == PH_FLUSH && st_s != RS_BUSY);
+                bool push_c = false, push_s = false;
+                if (STAMPS) n_stepping += (unsigned long long) __popcll(__ballot(ready));
+                ShadowRay sr;
+                sr.o = ps.o; sr.d = ps.d; sr.tmin = 0.f; sr.tmax = 0.f; sr.valid = false;
+                if (ready) {
+                    Hit h{-1, 0.f, 0.f, 0.f};
+                    if (ps.phase == PH_CLOSEST) {
+                        h.prim = __float_as_int(pool[lane]); h.t = pool[V5_SLOTS + lane]; h.u = pool[2u * V5_SLOTS + lane]; h.v = pool[3u * V5_SLOTS + lane];
                     }
+                    const bool shadow_clear = st_s == RS_DONE ? pool[64u + lane] == 0.f : true;
+                    status[lane] = RS_IDLE; status[64u + lane] = RS_IDLE;
+                    if (LDS_TABLES) path_step<true, FEAT, PoolRowSampler, LdsTables, false>(Ps, LT, ps, smp, h, shadow_clear, sr);
+                    else path_step<true, FEAT, PoolRowSampler, GlobalTables, false>(Ps, GlobalTables{Ps.shade, Ps.bsdfs, Ps.emitters}, ps, smp, h, shadow_clear, sr);
+                    push_c = ps.phase == PH_CLOSEST;
+                    push_s = sr.valid;
                 }
+                push_rays(push_c, push_s, sr);
             }
-            // this wave's own stores to the state rows must have landed before the proposals below read them back (same CU: the
-            // wait is all a workgroup-scope fence amounts to)
-            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-            // ---- start (parked chain lanes): the coins of the mutation that begins were drawn with the previous one
-            if (parked && kind == 1) {
-                const float *cn = &lds_x[L.coin_off + lane];
-                cs.large = cn[0] < Pm.p_large;
-                cs.coin_acc1 = cn[64]; cs.coin_acc2 = cn[128]; cs.coin_mix = cn[192];
-                cs.stage = 0;
-                cs.do_second = false;
-                cs.nd1 = cs.nd2 = 0u;
-            }
-            // ---- proposals, flattened: items (chain j, Philox block b) -> dimensions 4b .. 4b+3 of y from the state in device
-            // memory (the commits above are this wave's own stores: visible to its later loads); block nb1 = the four coins of
-            // the NEXT mutation
-            const uint32_t chain_base = Pm.chain_offset + wave_base;
-            const uint32_t maj_mine = base + cs.it; // the mutation in flight
-            const unsigned info = cs.large ? 1u : 0u;
-            const unsigned long long f1mask = __ballot(kind == 1);
-            if (f1mask) {
-                if (kind == 1) lds_list[prefix(f1mask)] = (int) lane;
-                const uint32_t n = (uint32_t) __popcll(f1mask), total = n * (nb1 + 1u);
-                const float rcp_n = 1.f / (float) n;
-                for (uint32_t ib = 0u; ib < total; ib += 64u) {
-                    const uint32_t i = ib + lane;
-                    const bool valid = i < total;
-                    const uint32_t ii = valid ? i : 0u;
-                    const uint32_t b = (uint32_t) (((float) ii + 0.5f) * rcp_n), j = ii - b * n;
-                    const uint32_t cj = (uint32_t) lds_list[j];
-                    const uint32_t mj = (uint32_t) __shfl((int) maj_mine, (int) cj, 64);
-                    const unsigned inf = (unsigned) __shfl((int) info, (int) cj, 64);
-                    if (valid) {
-                        if (b < nb1) v5_fill_first(Pm, D, cj, (size_t) wave_base + cj, b, mj, chain_base + cj, inf != 0u);
-                        else {
-                            const u4 coins = philox4x32_10(Pm.key0, Pm.key1, 0u, mj + 1u, chain_base + cj, TAG_COIN);
-                            float *dst = &lds_x[L.coin_off + cj];
-                            dst[0] = u32_to_unit(coins.x); dst[64] = u32_to_unit(coins.y); dst[128] = u32_to_unit(coins.z); dst[192] = u32_to_unit(coins.w);
+            t_step += STAMP5() - t0;
+        };
+        auto do_bookkeeping = [&]() {
+            const unsigned long long t0 = STAMP5();
+            // ---------------------------------------------------------------- bookkeeping: decide, commit, proposals, start
+            const bool parked = ps.phase == PH_DONE;
+            const unsigned long long pmask = __ballot(parked);
+            // (the step above has refilled the queue: "nothing in flight" means every chain that is not idle is parked)
+            const bool rays_in_flight = q_count != 0u || __ballot(T.active) != 0ull;
+            if (pmask && (__popcll(pmask) >= batch || !rays_in_flight)) {
+                SECTION_PARAMS(Pm);
+                if (STAMPS) { n_mh++; n_parked += (unsigned long long) __popcll(pmask); }
+                if (qn + 64u > V5_QCAP) v4_flush(Pm, Lq, qn, lane);
+                int commit = 0, kind = 0; // kind: 0 nothing / finished, 1 next mutation, 2 second stage (4: between mutations, resolved below)
+                bool want0 = false, want1 = false, want2 = false;
+                float e0x = 0.f, e0y = 0.f, e0r = 0.f, e0g = 0.f, e0b = 0.f;
+                float e1x = 0.f, e1y = 0.f, e1r = 0.f, e1g = 0.f, e1b = 0.f;
+                float e2x = 0.f, e2y = 0.f, e2r = 0.f, e2g = 0.f, e2b = 0.f;
+                if (parked) {
+                    const MhOutcome o = mh_decide(Pm, cs, smp, ps, ct);
+                    if (o.decided) {
+                        cum += o.w.w0;
+                        const bool a1st = o.commit == SM_STAGE1, a2nd = o.commit == SM_STAGE2;
+                        want1 = !a1st && o.w.w1 > 0.f;
+                        e1x = cs.y.px; e1y = cs.y.py; e1r = cs.y.r * o.w.w1; e1g = cs.y.g * o.w.w1; e1b = cs.y.b * o.w.w1;
+                        want2 = !a2nd && o.w.w2 > 0.f;
+                        e2x = cs.z.px; e2y = cs.z.py; e2r = cs.z.r * o.w.w2; e2g = cs.z.g * o.w.w2; e2b = cs.z.b * o.w.w2;
+                        if (o.commit) {
+                            want0 = cum > 0.f;
+                            e0x = cs.cur.px; e0y = cs.cur.py; e0r = cs.cur.r * cum; e0g = cs.cur.g * cum; e0b = cs.cur.b * cum;
+                            cum = a1st ? o.w.w1 : o.w.w2;
+                            cs.cur = select_splat(a1st, cs.y, cs.z);
+                            if (o.amap) { // acceptance map: the mark goes to the pixel of the state that was LEFT (device_mh.h)
+                                const f3 mc = mh_amap_colour(o.amap);
+                                want1 = true; e1x = e0x; e1y = e0y; e1r = mc.x; e1g = mc.y; e1b = mc.z;
+                            }
+                        }
+                        commit = o.commit;
+                    }
+                    kind = cs.stage < 0 ? 4 : 2; // (stage 2, Green's reverse move, does not occur: type = orbital)
+                }
+                {
+                    // between mutations: go on while short of the target; beyond it (run-ahead) while anybody in the grid is short
+                    const uint32_t done_now = base + cs.it;
+                    const bool under = __ballot(live && done_now < target) != 0ull;
+                    bool more = under;
+                    if (Pm.chain_done) {
+                        if (!under && !reported) { reported = true; if (lane == 0) atomicSub(Pm.waves_left, 1u); }
+                        if (!under) more = __builtin_amdgcn_readfirstlane((int) __hip_atomic_load(Pm.waves_left, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != 0;
+                    }
+                    if (kind == 4) kind = (done_now < target || (done_now < limit && more)) ? 1 : 0;
+                }
+                // the queue holds V5_QCAP entries, a round adds at most 64
+                v4_enqueue(Lq, qn, want0, e0x, e0y, e0r, e0g, e0b);
+                if (qn + 64u > V5_QCAP) v4_flush(Pm, Lq, qn, lane);
+                v4_enqueue(Lq, qn, want1, e1x, e1y, e1r, e1g, e1b);
+                if (qn + 64u > V5_QCAP) v4_flush(Pm, Lq, qn, lane);
+                v4_enqueue(Lq, qn, want2, e2x, e2y, e2r, e2g, e2b);
+
+                // ---- commit (DRMLTSampler::accept: uCurrent = wrap(adopted proposal)) to the state's home in device memory,
+                // flattened: items (accepted chain j, row quad q), chain-minor
+                const unsigned long long cmask = __ballot(commit != 0);
+                if (cmask) {
+                    if (commit) lds_list[prefix(cmask)] = (int) lane;
+                    const uint32_t n = (uint32_t) __popcll(cmask), total = n * nb1;
+                    const float rcp_n = 1.f / (float) n;
+                    for (uint32_t ib = 0u; ib < total; ib += 64u) {
+                        const uint32_t i = ib + lane;
+                        const bool valid = i < total;
+                        const uint32_t ii = valid ? i : 0u;
+                        const uint32_t q = (uint32_t) (((float) ii + 0.5f) * rcp_n), j = ii - q * n;
+                        const uint32_t cj = (uint32_t) lds_list[j];
+                        if (valid) {
+                            const float *src = &lds_x[4u * q * 64u + cj];
+                            float *dst = Pm.x + (size_t) (4u * q) * Pm.n_chains + wave_base + cj;
+    #pragma unroll
+                            for (uint32_t r = 0; r < 4u; ++r)
+                                if (4u * q + r < D) dst[(size_t) r * Pm.n_chains] = wrap01(src[r * 64u]);
                         }
                     }
                 }
-            }
-            const unsigned long long f2mask = __ballot(kind == 2);
-            if (f2mask) { // second-stage proposals (rejected bold steps), in place over the first-stage rows
-                if (kind == 2) lds_list[prefix(f2mask)] = (int) lane;
-                const uint32_t nb2 = Pm.timid_after_large ? nb1 : (D / 2u + 3u) / 4u; // uniforms for a large step: one per dim; else one angle per pair
-                const uint32_t n = (uint32_t) __popcll(f2mask), total = n * nb2;
-                const float rcp_n = 1.f / (float) n;
-                for (uint32_t ib = 0u; ib < total; ib += 64u) {
-                    const uint32_t i = ib + lane;
-                    const bool valid = i < total;
-                    const uint32_t ii = valid ? i : 0u;
-                    const uint32_t b = (uint32_t) (((float) ii + 0.5f) * rcp_n), j = ii - b * n;
-                    const uint32_t cj = (uint32_t) lds_list[j];
-                    const uint32_t mj = (uint32_t) __shfl((int) maj_mine, (int) cj, 64);
-                    const unsigned inf = (unsigned) __shfl((int) info, (int) cj, 64);
-                    if (valid && (inf != 0u || b < (D / 2u + 3u) / 4u)) v5_fill_second(Pm, D, cj, (size_t) wave_base + cj, b, mj, chain_base + cj, inf != 0u);
+                // this wave's own stores to the state rows must have landed before the proposals below read them back (same CU: the
+                // wait is all a workgroup-scope fence amounts to)
+                if (cmask) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+                // ---- start (parked chain lanes): the coins of the mutation that begins were drawn with the previous one
+                if (parked && kind == 1) {
+                    const float *cn = &lds_x[L.coin_off + lane];
+                    cs.large = cn[0] < Pm.p_large;
+                    cs.coin_acc1 = cn[64]; cs.coin_acc2 = cn[128]; cs.coin_mix = cn[192];
+                    cs.stage = 0;
+                    cs.do_second = false;
+                    cs.nd1 = cs.nd2 = 0u;
                 }
-            }
-            // ---- begin the evaluation: film position and camera ray from the first two components; the ray goes into the pool
-            if (parked) {
-                if (kind == 0) ps.phase = PH_IDLE;
-                else {
-                    path_init(Pm, ps);
-                    const float v0 = smp.next(0u), v1 = smp.next(1u);
-                    path_begin(Pm, ps, v0, v1);
-                }
-            }
-        }
-        const unsigned long long s1 = STAMP5();
-
-        // ---------------------------------------------------------------- step: chains whose ray results are in
-        {
-            SECTION_PARAMS(Ps);
-            const int st_c = status[lane], st_s = status[64u + lane];
-            const bool fresh = ps.phase == PH_CLOSEST && st_c == RS_IDLE; // a camera ray of the bookkeeping branch above: not yet in the pool
-            const bool ready = (ps.phase == PH_CLOSEST && st_c == RS_DONE && st_s != RS_BUSY) || (ps.phase == PH_FLUSH && st_s != RS_BUSY);
-            bool push_c = fresh, push_s = false;
-            if (STAMPS) n_stepping += (unsigned long long) __popcll(__ballot(ready));
-            ShadowRay sr;
-            sr.o = ps.o; sr.d = ps.d; sr.tmin = 0.f; sr.tmax = 0.f; sr.valid = false;
-            if (ready) {
-                Hit h{-1, 0.f, 0.f, 0.f};
-                if (ps.phase == PH_CLOSEST) {
-                    h.prim = __float_as_int(pool[lane]); h.t = pool[V5_SLOTS + lane]; h.u = pool[2u * V5_SLOTS + lane]; h.v = pool[3u * V5_SLOTS + lane];
-                }
-                const bool shadow_clear = st_s == RS_DONE ? pool[64u + lane] == 0.f : true;
-                status[lane] = RS_IDLE; status[64u + lane] = RS_IDLE;
-                path_step<true, FEAT, PoolRowSampler, GlobalTables, false>(Ps, GlobalTables{Ps.shade, Ps.bsdfs, Ps.emitters}, ps, smp, h, shadow_clear, sr);
-                push_c = ps.phase == PH_CLOSEST;
-                push_s = sr.valid;
-            }
-            if (push_c) {
-                float *r = pool + lane;
-                r[0] = ps.o.x; r[V5_SLOTS] = ps.o.y; r[2u * V5_SLOTS] = ps.o.z; r[3u * V5_SLOTS] = ps.d.x; r[4u * V5_SLOTS] = ps.d.y; r[5u * V5_SLOTS] = ps.d.z;
-                r[6u * V5_SLOTS] = ps.tmin; r[7u * V5_SLOTS] = ps.tmax;
-                status[lane] = RS_BUSY;
-            }
-            if (push_s) {
-                float *r = pool + 64u + lane;
-                r[0] = sr.o.x; r[V5_SLOTS] = sr.o.y; r[2u * V5_SLOTS] = sr.o.z; r[3u * V5_SLOTS] = sr.d.x; r[4u * V5_SLOTS] = sr.d.y; r[5u * V5_SLOTS] = sr.d.z;
-                r[6u * V5_SLOTS] = sr.tmin; r[7u * V5_SLOTS] = sr.tmax;
-                status[64u + lane] = RS_BUSY;
-            }
-            // ray compaction: the lanes that issued a ray append its slot to the FIFO (ballot + prefix count)
-            const unsigned long long mc = __ballot(push_c);
-            if (push_c) ring[(q_head + q_count + prefix(mc)) & (V5_SLOTS - 1u)] = (unsigned char) lane;
-            q_count += (uint32_t) __popcll(mc);
-            const unsigned long long ms = __ballot(push_s);
-            if (push_s) ring[(q_head + q_count + prefix(ms)) & (V5_SLOTS - 1u)] = (unsigned char) (64u + lane);
-            q_count += (uint32_t) __popcll(ms);
-        }
-        const unsigned long long s2 = STAMP5();
-
-        // ---------------------------------------------------------------- trace: the pool's rays, any lane any ray
-        {
-            SECTION_PARAMS(Pt);
-            const TravLoop<StackT, DParams, OVF || !STACK16, CAP, FEAT> TL(Pt, my_stack);
-            const int yield_lanes = Pt.trace_yield, refill_at = Pt.pool_refill;
-            int finished_closest = 0;
-            bool first = true;
-            if (STAMPS) n_phase++;
-            for (;;) {
-                // idle lanes take pending slots off the queue (at the start of a phase, and whenever a few lanes have run dry)
-                const unsigned long long idle = __ballot(!T.active);
-                if (q_count != 0u && idle != 0ull && (first || __popcll(idle) >= refill_at || idle == ~0ull)) {
-                    const uint32_t rank = prefix(idle);
-                    const bool take = !T.active && rank < q_count;
-                    if (take) {
-                        slot = ring[(q_head + rank) & (V5_SLOTS - 1u)];
-                        const float *r = pool + slot;
-                        trav_begin(T, mk3(r[0], r[V5_SLOTS], r[2u * V5_SLOTS]), mk3(r[3u * V5_SLOTS], r[4u * V5_SLOTS], r[5u * V5_SLOTS]),
-                                   r[6u * V5_SLOTS], r[7u * V5_SLOTS], slot >= 64u);
+                // ---- proposals, flattened: items (chain j, Philox block b) -> dimensions 4b .. 4b+3 of y from the state in device
+                // memory (the commits above are this wave's own stores: visible to its later loads); block nb1 = the four coins of
+                // the NEXT mutation
+                const uint32_t chain_base = Pm.chain_offset + wave_base;
+                const uint32_t maj_mine = base + cs.it; // the mutation in flight
+                const unsigned info = cs.large ? 1u : 0u;
+                const unsigned long long f1mask = __ballot(kind == 1);
+                if (f1mask) {
+                    if (kind == 1) lds_list[prefix(f1mask)] = (int) lane;
+                    const uint32_t n = (uint32_t) __popcll(f1mask), total = n * (nb1 + 1u);
+                    const float rcp_n = 1.f / (float) n;
+                    for (uint32_t ib = 0u; ib < total; ib += 64u) {
+                        const uint32_t i = ib + lane;
+                        const bool valid = i < total;
+                        const uint32_t ii = valid ? i : 0u;
+                        const uint32_t b = (uint32_t) (((float) ii + 0.5f) * rcp_n), j = ii - b * n;
+                        const uint32_t cj = (uint32_t) lds_list[j];
+                        const uint32_t mj = (uint32_t) __shfl((int) maj_mine, (int) cj, 64);
+                        const unsigned inf = (unsigned) __shfl((int) info, (int) cj, 64);
+                        if (valid) {
+                            if (b < nb1) v5_fill_first(Pm, D, cj, (size_t) wave_base + cj, b, mj, chain_base + cj, inf != 0u);
+                            else {
+                                const u4 coins = philox4x32_10(Pm.key0, Pm.key1, 0u, mj + 1u, chain_base + cj, TAG_COIN);
+                                float *dst = &lds_x[L.coin_off + cj];
+                                dst[0] = u32_to_unit(coins.x); dst[64] = u32_to_unit(coins.y); dst[128] = u32_to_unit(coins.z); dst[192] = u32_to_unit(coins.w);
+                            }
+                        }
                     }
-                    const uint32_t taken = min((uint32_t) __popcll(idle), q_count);
+                }
+                const unsigned long long f2mask = __ballot(kind == 2);
+                if (f2mask) { // second-stage proposals (rejected bold steps), in place over the first-stage rows
+                    if (kind == 2) lds_list[prefix(f2mask)] = (int) lane;
+                    const uint32_t nb2 = Pm.timid_after_large ? nb1 : (D / 2u + 3u) / 4u; // uniforms for a large step: one per dim; else one angle per pair
+                    const uint32_t n = (uint32_t) __popcll(f2mask), total = n * nb2;
+                    const float rcp_n = 1.f / (float) n;
+                    for (uint32_t ib = 0u; ib < total; ib += 64u) {
+                        const uint32_t i = ib + lane;
+                        const bool valid = i < total;
+                        const uint32_t ii = valid ? i : 0u;
+                        const uint32_t b = (uint32_t) (((float) ii + 0.5f) * rcp_n), j = ii - b * n;
+                        const uint32_t cj = (uint32_t) lds_list[j];
+                        const uint32_t mj = (uint32_t) __shfl((int) maj_mine, (int) cj, 64);
+                        const unsigned inf = (unsigned) __shfl((int) info, (int) cj, 64);
+                        if (valid && (inf != 0u || b < (D / 2u + 3u) / 4u)) v5_fill_second(Pm, D, cj, (size_t) wave_base + cj, b, mj, chain_base + cj, inf != 0u);
+                    }
+                }
+                // ---- begin the evaluation: film position and camera ray from the first two components; the ray goes into the pool
+                if (parked) {
+                    if (kind == 0) ps.phase = PH_IDLE;
+                    else {
+                        path_init(Pm, ps);
+                        const float v0 = smp.next(0u), v1 = smp.next(1u);
+                        path_begin(Pm, ps, v0, v1);
+                    }
+                }
+                {
+                    ShadowRay none;
+                    none.o = ps.o; none.d = ps.d; none.tmin = 0.f; none.tmax = 0.f; none.valid = false;
+                    push_rays(parked && ps.phase == PH_CLOSEST, false, none); // the camera rays of the evaluations that begin
+                }
+            }
+            t_mh += STAMP5() - t0;
+        };
+        auto do_trace = [&]() {
+            const unsigned long long t0 = STAMP5();
+            // ---------------------------------------------------------------- trace: the pool's rays, any lane any ray
+            if constexpr (FLAT) {
+                // flat scenes: ONE pass of the brute-force loop over up to 64 pending rays; all of them are done when it returns
+                if (q_count != 0u) {
+                    SECTION_PARAMS(Pt);
+                    if (STAMPS) { n_phase++; n_lanes_at_start += (unsigned long long) min(q_count, 64u); }
+                    const bool take = lane < q_count;
+                    slot = ring[(q_head + lane) & (V5_SLOTS - 1u)];
+                    if (take) {
+                        const float *r = pool + slot;
+                        const Hit h = trace<FEAT>(Pt, mk3(r[0], r[V5_SLOTS], r[2u * V5_SLOTS]), mk3(r[3u * V5_SLOTS], r[4u * V5_SLOTS], r[5u * V5_SLOTS]),
+                                                  r[6u * V5_SLOTS], r[7u * V5_SLOTS], slot >= 64u);
+                        if (slot < 64u) {
+                            float *w = pool + slot;
+                            w[0] = __int_as_float(h.prim); w[V5_SLOTS] = h.t; w[2u * V5_SLOTS] = h.u; w[3u * V5_SLOTS] = h.v;
+                        } else {
+                            pool[slot] = h.prim >= 0 ? 1.f : 0.f;
+                        }
+                        status[slot] = RS_DONE;
+                    }
+                    const uint32_t taken = min(q_count, 64u);
                     q_head = (q_head + taken) & (V5_SLOTS - 1u);
                     q_count -= taken;
-                    if (STAMPS) n_refill++;
                 }
-                if (STAMPS && first) n_lanes_at_start += (unsigned long long) __popcll(__ballot(T.active));
-                first = false;
-                if (finished_closest >= yield_lanes) break;
-                bool any;
-                const bool done_now = TL.step(T, true, any);
-                if (!any) break; // (the queue is empty too: an idle wave with pending slots refills above)
-                if (done_now) { // result over the ray's record; the owner chain picks it up in the step phase
-                    if (slot < 64u) {
-                        float *r = pool + slot;
-                        r[0] = __int_as_float(T.h.prim); r[V5_SLOTS] = T.h.t; r[2u * V5_SLOTS] = T.h.u; r[3u * V5_SLOTS] = T.h.v;
-                    } else {
-                        pool[slot] = T.h.prim >= 0 ? 1.f : 0.f;
+            } else {
+                SECTION_PARAMS(Pt);
+                const TravLoop<StackT, DParams, OVF || !STACK16, CAP, FEAT> TL(Pt, my_stack);
+                const int yield_lanes = Pt.trace_yield, refill_at = Pt.pool_refill;
+                int finished_closest = 0;
+                bool first = true;
+                if (STAMPS) n_phase++;
+                for (;;) {
+                    // idle lanes take pending slots off the queue (at the start of a phase, and whenever a few lanes have run dry)
+                    const unsigned long long idle = __ballot(!T.active);
+                    if (q_count != 0u && idle != 0ull && (first || __popcll(idle) >= refill_at || idle == ~0ull)) {
+                        const uint32_t rank = prefix(idle);
+                        const bool take = !T.active && rank < q_count;
+                        if (take) {
+                            slot = ring[(q_head + rank) & (V5_SLOTS - 1u)];
+                            const float *r = pool + slot;
+                            trav_begin(T, mk3(r[0], r[V5_SLOTS], r[2u * V5_SLOTS]), mk3(r[3u * V5_SLOTS], r[4u * V5_SLOTS], r[5u * V5_SLOTS]),
+                                       r[6u * V5_SLOTS], r[7u * V5_SLOTS], slot >= 64u);
+                        }
+                        const uint32_t taken = min((uint32_t) __popcll(idle), q_count);
+                        q_head = (q_head + taken) & (V5_SLOTS - 1u);
+                        q_count -= taken;
+                        if (STAMPS) n_refill++;
                     }
-                    status[slot] = RS_DONE;
+                    if (STAMPS && first) n_lanes_at_start += (unsigned long long) __popcll(__ballot(T.active));
+                    first = false;
+                    if (finished_closest >= yield_lanes) break;
+                    bool any;
+                    const bool done_now = TL.step(T, true, any);
+                    if (!any) break; // (the queue is empty too: an idle wave with pending slots refills above)
+                    if (done_now) { // result over the ray's record; the owner chain picks it up in the step phase
+                        if (slot < 64u) {
+                            float *r = pool + slot;
+                            r[0] = __int_as_float(T.h.prim); r[V5_SLOTS] = T.h.t; r[2u * V5_SLOTS] = T.h.u; r[3u * V5_SLOTS] = T.h.v;
+                        } else {
+                            pool[slot] = T.h.prim >= 0 ? 1.f : 0.f;
+                        }
+                        status[slot] = RS_DONE;
+                    }
+                    finished_closest += __popcll(__ballot(done_now && slot < 64u));
                 }
-                finished_closest += __popcll(__ballot(done_now && slot < 64u));
+        
             }
-        }
-        const unsigned long long s3 = STAMP5();
-        t_mh += s1 - s0; t_step += s2 - s1; t_trace += s3 - s2;
+            t_trace += STAMP5() - t0;
+        };
+        // Flat scenes: every ray of a pass is done when the pass returns, so the chains step first and the bookkeeping branch
+        // sees who parked and what is still queued (it then fires for a full batch, or when nothing else is left to do). BVH
+        // scenes: a phase leaves traversals running; the branch comes first and its camera rays join the phase that follows.
+        if constexpr (FLAT) { do_step(); do_bookkeeping(); do_trace(); }
+        else { do_bookkeeping(); do_step(); do_trace(); }
     }
 #undef STAMP5
     SECTION_PARAMS(Pe);
@@ -1332,7 +1390,7 @@ __global__ void __launch_bounds__(CHAIN_BLOCK, 2) k_mutate_v5(DParams P, uint32_
     if (Pe.chain_done && !reported && lane == 0) atomicSub(Pe.waves_left, 1u); // (a wave none of whose chains had anything to do)
     flush_counters(Pe, ct, lane);
     const unsigned long long decided = wave_sum(live ? cs.it : 0u);
-    const unsigned long long nn = wave_sum(T.n_nodes), np = wave_sum(T.n_prims);
+    const unsigned long long nn = FLAT ? 0ull : wave_sum(T.n_nodes), np = FLAT ? 0ull : wave_sum(T.n_prims);
     if (lane == 0) {
         atomicAdd(Pe.stats + 9, decided);
         atomicAdd(Pe.stats + 10, nn); atomicAdd(Pe.stats + 11, np); atomicAdd(Pe.stats + 12, (unsigned long long) T.it_inner); atomicAdd(Pe.stats + 13, (unsigned long long) T.it_leaf);
@@ -1430,12 +1488,21 @@ void launch_mutate_pssmlt(const DParams &P, uint32_t n_mut, uint32_t mut_base, h
 void launch_mutate(const DParams &P, uint32_t n_mut, uint32_t mut_base, hipStream_t st) {
     const size_t D = (size_t) P.eff_dim, D4 = (D + 3) & ~(size_t) 3;
     const dim3 block(CHAIN_BLOCK);
-    if (P.kernel_variant == 5) { // BVH scenes: ray pool, 64 chains per wave
-        const size_t lds = v5_lds_bytes((uint32_t) D);
-        if (getenv("DRMLT_VERBOSE")) fprintf(stderr, "[drmlt] k_mutate_v5: %zu B of LDS per wave (+ the traversal stack)\n", lds);
+    if (P.kernel_variant == 5) { // ray pool, 64 chains per wave
+        size_t lds = v5_lds_bytes((uint32_t) D);
+        const bool flat = (P.features & 8) == 0;
+        if (flat && P.tables_in_lds) lds += (size_t) P.n_shade * 64 + (size_t) P.n_bsdfs * 48 + (size_t) P.n_emitters * 32;
+        if (getenv("DRMLT_VERBOSE")) fprintf(stderr, "[drmlt] k_mutate_v5: %zu B of LDS per wave%s\n", lds, flat ? "" : " (+ the traversal stack)");
         const dim3 g5((P.n_chains + 63) / 64);
         const bool diffuse = P.features == 8;
-        if (!P.bvh_stack16) { if (diffuse) hipLaunchKernelGGL((k_mutate_v5<8, false, true>), g5, block, lds, st, P, n_mut, mut_base); else hipLaunchKernelGGL((k_mutate_v5<15, false, true>), g5, block, lds, st, P, n_mut, mut_base); }
+        if (flat) { // brute-force loop as the trace phase; tables in LDS when they are small (they are, for scenes this small)
+            if (!P.tables_in_lds) hipLaunchKernelGGL((k_mutate_v5<7, true, false, false, false>), g5, block, lds, st, P, n_mut, mut_base);
+            else if (P.features == 0 && (P.debug & 128)) hipLaunchKernelGGL((k_mutate_v5<0, true, false, true, true>), g5, block, lds, st, P, n_mut, mut_base); // diagnostic stamps
+            else if (P.features == 0) hipLaunchKernelGGL((k_mutate_v5<0, true, false, false, true>), g5, block, lds, st, P, n_mut, mut_base);
+            else if ((P.features & ~3) == 0) hipLaunchKernelGGL((k_mutate_v5<3, true, false, false, true>), g5, block, lds, st, P, n_mut, mut_base);
+            else hipLaunchKernelGGL((k_mutate_v5<7, true, false, false, true>), g5, block, lds, st, P, n_mut, mut_base);
+        }
+        else if (!P.bvh_stack16) { if (diffuse) hipLaunchKernelGGL((k_mutate_v5<8, false, true>), g5, block, lds, st, P, n_mut, mut_base); else hipLaunchKernelGGL((k_mutate_v5<15, false, true>), g5, block, lds, st, P, n_mut, mut_base); }
         else if (P.bvh_overflow) { if (diffuse) hipLaunchKernelGGL((k_mutate_v5<8, true, true>), g5, block, lds, st, P, n_mut, mut_base); else hipLaunchKernelGGL((k_mutate_v5<15, true, true>), g5, block, lds, st, P, n_mut, mut_base); }
         else if (diffuse && (P.debug & 128)) hipLaunchKernelGGL((k_mutate_v5<8, true, false, true>), g5, block, lds, st, P, n_mut, mut_base); // diagnostic stamps
         else if (diffuse) hipLaunchKernelGGL((k_mutate_v5<8, true, false>), g5, block, lds, st, P, n_mut, mut_base);

@@ -37,10 +37,15 @@ CASES = [
     ("triangle_soup", dict(n_tris=40000), dict(type="orbital"), {}),                                 # 32-bit stacks, overflow area in use
     ("caustic_c5", {}, dict(type="orbital"), dict(DRMLT_BVH_THRESHOLD=0)),                           # spheres + dielectric in the leaves
     ("door_c3", {}, dict(type="orbital"), dict(DRMLT_BVH_THRESHOLD=0)),                              # rough conductor
+    # flat scenes: the same kernel with the brute-force loop as its trace phase, scene tables in LDS
+    ("cornell_c2", {}, dict(type="orbital"), {}),
+    ("cornell_c2", {}, dict(type="orbital", use_mixture=1, timid_after_large=0), {}),
+    ("caustic_c5", {}, dict(type="orbital", timid_after_large=1), {}),
+    ("door_c3", {}, dict(type="orbital"), {}),
 ]
 
 
-@pytest.mark.parametrize("scene,skw,kw,env", CASES, ids=["soup-orbital", "soup-timid", "soup-mixture", "soup-short", "soup40k", "caustic-bvh", "door-bvh"])
+@pytest.mark.parametrize("scene,skw,kw,env", CASES, ids=["soup-orbital", "soup-timid", "soup-mixture", "soup-short", "soup40k", "caustic-bvh", "door-bvh", "flat-cornell", "flat-cornell-mixture", "flat-caustic-timid", "flat-door"])
 def test_ray_pool_kernel_runs_the_same_chains(pkg, native_lib, scene, skw, kw, env):
     sd = pkg.scenes.SCENES[scene](res=32, **skw)
     n_chains, n_mut = 1000, 60                       # 1000: the last wave of either kernel is ragged
@@ -62,6 +67,7 @@ def test_ray_pool_kernel_runs_the_same_chains(pkg, native_lib, scene, skw, kw, e
         assert getattr(s5, k + "_base") == getattr(s4, k + "_base") and getattr(s5, k + "_acc") == getattr(s4, k + "_acc"), k
     assert s5.accepted == s4.accepted and s5.rays == s4.rays and s5.path_evals == s4.path_evals
     assert s5.bvh_node_visits == s4.bvh_node_visits and s5.bvh_prim_tests == s4.bvh_prim_tests   # the same rays, traversed the same way
+    assert (s5.bvh_node_visits > 0) == (scene == "triangle_soup" or "DRMLT_BVH_THRESHOLD" in env)
     assert lum(f5).sum() == pytest.approx(lum(f4).sum(), rel=1e-5)
     assert np.abs(lum(f5) - lum(f4)).sum() / lum(f4).sum() < 1e-4
 
