@@ -897,7 +897,8 @@ __global__ void __launch_bounds__(CHAIN_BLOCK) k_mutate_v4(DParams P, uint32_t n
 }
 
 // ------------------------------------------------------------------------------------------
-// k_mutate_v5: the chain loop for BVH scenes with MORE RAYS THAN LANES (type = orbital; the iid kernels stay on v4).
+// k_mutate_v5: the chain loop with MORE RAYS THAN LANES (types orbital and green; Mira, whose transition ratio needs x, y and z
+// of every dimension at once, stays on k_mutate_v4).
 //
 // In k_mutate_v4 a ray belongs to a lane: chain lane i traverses its camera / bounce ray, helper lane 32 + i the shadow ray
 // of the same vertex. On a scene that is traversed (not looped over) the wave then advances ~22 of its 64 lanes per node
@@ -965,16 +966,22 @@ DEV void v5_fill_first(const DParams &P, uint32_t D, uint32_t col, size_t xcol, 
     const float *xs = P.x + (size_t) (4u * b) * P.n_chains + xcol;
     const float x0 = load_global_f32(xs), x1 = load_global_f32(xs + P.n_chains);
     const float x2 = load_global_f32(xs + (hi ? 2u : 0u) * (size_t) P.n_chains), x3 = load_global_f32(xs + (hi ? 3u : 1u) * (size_t) P.n_chains);
-    // pairwise orbital: radius from the Kelemen kernel (x 1.9), uniform angle (drmlt_sampler.cpp:354-361)
-    const float d0 = kelemen_sample(u0, KELEMEN_S2 * ORBITAL_SCALE), d1 = kelemen_sample(u2, KELEMEN_S2 * ORBITAL_SCALE);
-    const float y0 = fmaf(d0, cos_rev(u1), x0), y1 = fmaf(d0, cos_rev(u1 - 0.25f), x1);
-    const float y2 = fmaf(d1, cos_rev(u3), x2), y3 = fmaf(d1, cos_rev(u3 - 0.25f), x3);
+    float y0, y1, y2, y3;
+    if (P.type == 2) { // pairwise orbital: radius from the Kelemen kernel (x 1.9), uniform angle (drmlt_sampler.cpp:354-361)
+        const float d0 = kelemen_sample(u0, KELEMEN_S2 * ORBITAL_SCALE), d1 = kelemen_sample(u2, KELEMEN_S2 * ORBITAL_SCALE);
+        y0 = fmaf(d0, cos_rev(u1), x0); y1 = fmaf(d0, cos_rev(u1 - 0.25f), x1);
+        y2 = fmaf(d1, cos_rev(u3), x2); y3 = fmaf(d1, cos_rev(u3 - 0.25f), x3);
+    } else { // iid Kelemen kernel (Green, Mira)
+        y0 = x0 + kelemen_sample(u0, KELEMEN_S2); y1 = x1 + kelemen_sample(u1, KELEMEN_S2);
+        y2 = x2 + kelemen_sample(u2, KELEMEN_S2); y3 = x3 + kelemen_sample(u3, KELEMEN_S2);
+    }
     float *ys = &lds_x[4u * b * 64u + col];
     ys[0] = large ? u0 : y0; ys[64] = large ? u1 : y1;
     if (hi) { ys[128] = large ? u2 : y2; ys[192] = large ? u3 : y3; }
 }
 // second-stage proposal from Philox block b of the TAG_S2 stream, written OVER the first-stage rows: a large step
-// (timidAfterLarge) -> dims 4b .. 4b+3 (uniforms); otherwise the orbital angles of pairs 4b .. 4b+3 = dims 8b .. 8b+7
+// (timidAfterLarge) -> dims 4b .. 4b+3 (uniforms); orbital -> the angles of pairs 4b .. 4b+3 = dims 8b .. 8b+7 (reads the y rows
+// it replaces); iid kernels -> the Gaussian perturbations of dims 2b, 2b+1 (draws 2k, 2k+1 belong to dim k)
 DEV void v5_fill_second(const DParams &P, uint32_t D, uint32_t col, size_t xcol, uint32_t b, uint32_t major, uint32_t chain, bool large) {
     FP_STRICT;
     const u4 r = philox4x32_10(P.key0, P.key1, b, major, chain, TAG_S2);
@@ -983,6 +990,13 @@ DEV void v5_fill_second(const DParams &P, uint32_t D, uint32_t col, size_t xcol,
 #pragma unroll
         for (uint32_t i = 0; i < 4u; ++i)
             if (4u * b + i < D) lds_x[(4u * b + i) * 64u + col] = u[i];
+        return;
+    }
+    if (P.type != 2) {
+        const uint32_t k = 2u * b; // (k + 1 < D: the caller's block count)
+        const float x0 = load_global_f32(P.x + (size_t) k * P.n_chains + xcol), x1 = load_global_f32(P.x + (size_t) (k + 1u) * P.n_chains + xcol);
+        lds_x[k * 64u + col] = x0 + gaussian_sample(u[0], u[1], P.sigma2);
+        lds_x[(k + 1u) * 64u + col] = x1 + gaussian_sample(u[2], u[3], P.sigma2);
         return;
     }
 #pragma unroll
@@ -1002,6 +1016,41 @@ DEV void v5_fill_second(const DParams &P, uint32_t D, uint32_t col, size_t xcol,
             lds_x[(k0 + 1u) * 64u + col] = y1 + (st * dx0 + ct * dx1);
         }
     }
+}
+// Green & Mira's reverse move and the adoption of a second-stage proposal under Green, for the iid kernels: dims 2b, 2b+1
+// from Philox block b of TAG_S2 (z = x + g), block b / 2 of TAG_S1 (y = x + kelemen) and the state in device memory.
+//   reverse:  rows := y* = z - (y - x)   (drmlt_proc.cpp:588-598; the rows held z, which is recomputed, not read)
+//   !reverse: state := wrap(z)            (the rows hold y* by then: DRMLTSampler::accept(second), drmlt_sampler.cpp:189-199)
+// A large step (timidAfterLarge): y and z are the uniforms themselves, dims 4b .. 4b+3 of block b of either stream.
+DEV void v5_iid_second_again(const DParams &P, uint32_t D, uint32_t col, size_t xcol, uint32_t b, uint32_t major, uint32_t chain, bool large, bool reverse) {
+    FP_STRICT;
+    const u4 r2 = philox4x32_10(P.key0, P.key1, b, major, chain, TAG_S2);
+    const float u2[4] = {u32_to_unit(r2.x), u32_to_unit(r2.y), u32_to_unit(r2.z), u32_to_unit(r2.w)};
+    if (large) {
+        u4 r1 = r2;
+        if (reverse) r1 = philox4x32_10(P.key0, P.key1, b, major, chain, TAG_S1);
+        const float u1[4] = {u32_to_unit(r1.x), u32_to_unit(r1.y), u32_to_unit(r1.z), u32_to_unit(r1.w)};
+#pragma unroll
+        for (uint32_t i = 0; i < 4u; ++i) {
+            const uint32_t k = 4u * b + i;
+            if (k < D) {
+                float *xg = P.x + (size_t) k * P.n_chains + xcol;
+                if (reverse) lds_x[k * 64u + col] = u2[i] - (u1[i] - load_global_f32(xg));
+                else *xg = wrap01(u2[i]);
+            }
+        }
+        return;
+    }
+    const uint32_t k = 2u * b;
+    float *xg0 = P.x + (size_t) k * P.n_chains + xcol, *xg1 = xg0 + P.n_chains;
+    const float x0 = load_global_f32(xg0), x1 = load_global_f32(xg1);
+    const float z0 = x0 + gaussian_sample(u2[0], u2[1], P.sigma2), z1 = x1 + gaussian_sample(u2[2], u2[3], P.sigma2);
+    if (!reverse) { *xg0 = wrap01(z0); *xg1 = wrap01(z1); return; }
+    const u4 r1 = philox4x32_10(P.key0, P.key1, k >> 2, major, chain, TAG_S1);
+    const float ua = (k & 2u) ? u32_to_unit(r1.z) : u32_to_unit(r1.x), ub = (k & 2u) ? u32_to_unit(r1.w) : u32_to_unit(r1.y);
+    const float y0 = x0 + kelemen_sample(ua, KELEMEN_S2), y1 = x1 + kelemen_sample(ub, KELEMEN_S2);
+    lds_x[k * 64u + col] = z0 - (y0 - x0);
+    lds_x[(k + 1u) * 64u + col] = z1 - (y1 - x1);
 }
 
 // FEAT & 8 (BVH scenes): the traversal loop described above. Flat scenes (FEAT without bit 3; LDS_TABLES: their shading /
@@ -1177,7 +1226,7 @@ __global__ void __launch_bounds__(CHAIN_BLOCK, 2) k_mutate_v5(DParams P, uint32_
                         }
                         commit = o.commit;
                     }
-                    kind = cs.stage < 0 ? 4 : 2; // (stage 2, Green's reverse move, does not occur: type = orbital)
+                    kind = cs.stage < 0 ? 4 : (cs.stage == 1 ? 2 : 3); // 3: Green's reverse move
                 }
                 {
                     // between mutations: go on while short of the target; beyond it (run-ahead) while anybody in the grid is short
@@ -1199,9 +1248,12 @@ __global__ void __launch_bounds__(CHAIN_BLOCK, 2) k_mutate_v5(DParams P, uint32_
 
                 // ---- commit (DRMLTSampler::accept: uCurrent = wrap(adopted proposal)) to the state's home in device memory,
                 // flattened: items (accepted chain j, row quad q), chain-minor
-                const unsigned long long cmask = __ballot(commit != 0);
+                // Under Green an adopted SECOND stage finds the rows holding the reverse move y*, not z: those chains' commits
+                // recompute z from the state and the stream (v5_iid_second_again); every other adoption copies the rows.
+                const bool green = Pm.type == 0 && !Pm.use_mixture;
+                const unsigned long long cmask = __ballot(commit != 0 && !(green && commit == SM_STAGE2));
                 if (cmask) {
-                    if (commit) lds_list[prefix(cmask)] = (int) lane;
+                    if (commit != 0 && !(green && commit == SM_STAGE2)) lds_list[prefix(cmask)] = (int) lane;
                     const uint32_t n = (uint32_t) __popcll(cmask), total = n * nb1;
                     const float rcp_n = 1.f / (float) n;
                     for (uint32_t ib = 0u; ib < total; ib += 64u) {
@@ -1213,15 +1265,35 @@ __global__ void __launch_bounds__(CHAIN_BLOCK, 2) k_mutate_v5(DParams P, uint32_
                         if (valid) {
                             const float *src = &lds_x[4u * q * 64u + cj];
                             float *dst = Pm.x + (size_t) (4u * q) * Pm.n_chains + wave_base + cj;
-    #pragma unroll
+#pragma unroll
                             for (uint32_t r = 0; r < 4u; ++r)
                                 if (4u * q + r < D) dst[(size_t) r * Pm.n_chains] = wrap01(src[r * 64u]);
                         }
                     }
                 }
+                const uint32_t chain_base = Pm.chain_offset + wave_base;
+                const uint32_t maj_done = base + cs.it - 1u; // the mutation just decided (cs.it was advanced by the decision)
+                const unsigned large_done = cs.large ? 1u : 0u;
+                const unsigned long long gmask = __ballot(green && commit == SM_STAGE2);
+                if (gmask) {
+                    if (green && commit == SM_STAGE2) lds_list[prefix(gmask)] = (int) lane;
+                    const uint32_t nbz = Pm.timid_after_large ? max(nb1, D / 2u) : D / 2u;
+                    const uint32_t n = (uint32_t) __popcll(gmask), total = n * nbz;
+                    const float rcp_n = 1.f / (float) n;
+                    for (uint32_t ib = 0u; ib < total; ib += 64u) {
+                        const uint32_t i = ib + lane;
+                        const bool valid = i < total;
+                        const uint32_t ii = valid ? i : 0u;
+                        const uint32_t bq = (uint32_t) (((float) ii + 0.5f) * rcp_n), j = ii - bq * n;
+                        const uint32_t cj = (uint32_t) lds_list[j];
+                        const uint32_t mj = (uint32_t) __shfl((int) maj_done, (int) cj, 64);
+                        const unsigned lg = (unsigned) __shfl((int) large_done, (int) cj, 64);
+                        if (valid && bq < (lg ? nb1 : D / 2u)) v5_iid_second_again(Pm, D, cj, (size_t) wave_base + cj, bq, mj, chain_base + cj, lg != 0u, false);
+                    }
+                }
                 // this wave's own stores to the state rows must have landed before the proposals below read them back (same CU: the
                 // wait is all a workgroup-scope fence amounts to)
-                if (cmask) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+                if (cmask | gmask) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
                 // ---- start (parked chain lanes): the coins of the mutation that begins were drawn with the previous one
                 if (parked && kind == 1) {
                     const float *cn = &lds_x[L.coin_off + lane];
@@ -1234,7 +1306,6 @@ __global__ void __launch_bounds__(CHAIN_BLOCK, 2) k_mutate_v5(DParams P, uint32_
                 // ---- proposals, flattened: items (chain j, Philox block b) -> dimensions 4b .. 4b+3 of y from the state in device
                 // memory (the commits above are this wave's own stores: visible to its later loads); block nb1 = the four coins of
                 // the NEXT mutation
-                const uint32_t chain_base = Pm.chain_offset + wave_base;
                 const uint32_t maj_mine = base + cs.it; // the mutation in flight
                 const unsigned info = cs.large ? 1u : 0u;
                 const unsigned long long f1mask = __ballot(kind == 1);
@@ -1263,7 +1334,9 @@ __global__ void __launch_bounds__(CHAIN_BLOCK, 2) k_mutate_v5(DParams P, uint32_
                 const unsigned long long f2mask = __ballot(kind == 2);
                 if (f2mask) { // second-stage proposals (rejected bold steps), in place over the first-stage rows
                     if (kind == 2) lds_list[prefix(f2mask)] = (int) lane;
-                    const uint32_t nb2 = Pm.timid_after_large ? nb1 : (D / 2u + 3u) / 4u; // uniforms for a large step: one per dim; else one angle per pair
+                    // blocks per chain: uniforms for a large step (one per dim), the orbital angles (one per pair), Gaussian pairs (one block per two dims)
+                    const uint32_t nbs = Pm.type == 2 ? (D / 2u + 3u) / 4u : D / 2u;
+                    const uint32_t nb2 = Pm.timid_after_large ? max(nb1, nbs) : nbs;
                     const uint32_t n = (uint32_t) __popcll(f2mask), total = n * nb2;
                     const float rcp_n = 1.f / (float) n;
                     for (uint32_t ib = 0u; ib < total; ib += 64u) {
@@ -1274,7 +1347,24 @@ __global__ void __launch_bounds__(CHAIN_BLOCK, 2) k_mutate_v5(DParams P, uint32_
                         const uint32_t cj = (uint32_t) lds_list[j];
                         const uint32_t mj = (uint32_t) __shfl((int) maj_mine, (int) cj, 64);
                         const unsigned inf = (unsigned) __shfl((int) info, (int) cj, 64);
-                        if (valid && (inf != 0u || b < (D / 2u + 3u) / 4u)) v5_fill_second(Pm, D, cj, (size_t) wave_base + cj, b, mj, chain_base + cj, inf != 0u);
+                        if (valid && b < (inf ? nb1 : nbs)) v5_fill_second(Pm, D, cj, (size_t) wave_base + cj, b, mj, chain_base + cj, inf != 0u);
+                    }
+                }
+                const unsigned long long f3mask = __ballot(kind == 3);
+                if (f3mask) { // Green's reverse move y* = z - (y - x), over the rows that held z
+                    if (kind == 3) lds_list[prefix(f3mask)] = (int) lane;
+                    const uint32_t nb3 = Pm.timid_after_large ? max(nb1, D / 2u) : D / 2u;
+                    const uint32_t n = (uint32_t) __popcll(f3mask), total = n * nb3;
+                    const float rcp_n = 1.f / (float) n;
+                    for (uint32_t ib = 0u; ib < total; ib += 64u) {
+                        const uint32_t i = ib + lane;
+                        const bool valid = i < total;
+                        const uint32_t ii = valid ? i : 0u;
+                        const uint32_t b = (uint32_t) (((float) ii + 0.5f) * rcp_n), j = ii - b * n;
+                        const uint32_t cj = (uint32_t) lds_list[j];
+                        const uint32_t mj = (uint32_t) __shfl((int) maj_mine, (int) cj, 64);
+                        const unsigned inf = (unsigned) __shfl((int) info, (int) cj, 64);
+                        if (valid && b < (inf ? nb1 : D / 2u)) v5_iid_second_again(Pm, D, cj, (size_t) wave_base + cj, b, mj, chain_base + cj, inf != 0u, true);
                     }
                 }
                 // ---- begin the evaluation: film position and camera ray from the first two components; the ray goes into the pool

@@ -1,8 +1,9 @@
 """k_mutate_v5, the ray-pool chain kernel of BVH scenes (64 chains per wave, rays queued in LDS, any lane traverses any
 ray; north_star's "wavefront ballot / prefix-sum ray compaction"): it must run the chains of k_mutate_v4 / k_mutate_v3 bit
 for bit -- same addressed draws, same proposal arithmetic, same acceptance code (device_mh.h) -- whatever the order in
-which the wave happens to traverse its rays. (type = orbital: the kernel keeps one proposal row group in LDS; Green / Mira
-scenes stay on k_mutate_v4, which the last test checks.)"""
+which the wave happens to traverse its rays. (Types orbital and green: the kernel keeps ONE proposal row group in LDS and
+recomputes what Green's reverse move needs; Mira's transition ratio wants x, y and z of every dimension at once and stays
+on k_mutate_v4, which the last test checks.)"""
 import os
 
 import numpy as np
@@ -42,10 +43,17 @@ CASES = [
     ("cornell_c2", {}, dict(type="orbital", use_mixture=1, timid_after_large=0), {}),
     ("caustic_c5", {}, dict(type="orbital", timid_after_large=1), {}),
     ("door_c3", {}, dict(type="orbital"), {}),
+    # Green & Mira's rule: second stage x + g over the rows, reverse move recomputed from the stream, adoption of z recomputed
+    ("triangle_soup", dict(n_tris=2000), dict(type="green"), {}),
+    ("triangle_soup", dict(n_tris=2000), dict(type="green", timid_after_large=1, p_large=0.5), {}),
+    ("triangle_soup", dict(n_tris=2000), dict(type="green", use_mixture=1), {}),
+    ("door_c3", {}, dict(type="green"), {}),                                                          # BASELINE config 3's kernel
+    ("cornell_c2", {}, dict(type="green", timid_after_large=1, max_depth=5, rr_depth=2), {}),
 ]
 
 
-@pytest.mark.parametrize("scene,skw,kw,env", CASES, ids=["soup-orbital", "soup-timid", "soup-mixture", "soup-short", "soup40k", "caustic-bvh", "door-bvh", "flat-cornell", "flat-cornell-mixture", "flat-caustic-timid", "flat-door"])
+@pytest.mark.parametrize("scene,skw,kw,env", CASES, ids=["soup-orbital", "soup-timid", "soup-mixture", "soup-short", "soup40k", "caustic-bvh", "door-bvh", "flat-cornell", "flat-cornell-mixture", "flat-caustic-timid", "flat-door",
+                              "soup-green", "soup-green-timid", "soup-green-mixture", "flat-door-green", "flat-cornell-green-timid"])
 def test_ray_pool_kernel_runs_the_same_chains(pkg, native_lib, scene, skw, kw, env):
     sd = pkg.scenes.SCENES[scene](res=32, **skw)
     n_chains, n_mut = 1000, 60                       # 1000: the last wave of either kernel is ragged
@@ -94,9 +102,9 @@ def test_ray_pool_kernel_with_run_ahead_and_acceptance_map(pkg, native_lib):
         np.testing.assert_array_equal(f, res[0][2])                                   # marks are whole numbers of box weights: exact
 
 
-def test_iid_kernel_types_stay_on_v4(pkg, native_lib, capfd):
+def test_mira_stays_on_v4(pkg, native_lib, capfd):
     sd = pkg.scenes.triangle_soup(2000, 32)
-    cfg = pkg.abi.make_config(type="green", max_depth=8, direct_samples=-1, luminance_samples=20000, work_units=512, sample_count=1)
+    cfg = pkg.abi.make_config(type="mira", max_depth=8, direct_samples=-1, luminance_samples=20000, work_units=512, sample_count=1)
     ctx = ctx_with_env(pkg, cfg, sd, DRMLT_KERNEL=5, DRMLT_VERBOSE=1)
     ctx.seed(1)
     os.environ["DRMLT_VERBOSE"] = "1"
