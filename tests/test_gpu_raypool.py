@@ -114,3 +114,56 @@ def test_mira_stays_on_v4(pkg, native_lib, capfd):
         del os.environ["DRMLT_VERBOSE"]
     err = capfd.readouterr().err
     assert "k_mutate_v4" in err and "k_mutate_v5" not in err
+
+
+@pytest.mark.parametrize("scene,skw,filt", [("triangle_soup", dict(n_tris=2000), "box"), ("cornell_c2", {}, "gauss")], ids=["soup-importance", "cornell-gaussian-importance"])
+def test_ray_pool_kernel_with_importance_map_and_gaussian_film(pkg, native_lib, scene, skw, filt):
+    """Two-stage MLT's luminance image (SplatList::normalize divides every splat by it, pathsampler.cpp:1001-1020) and the gaussian
+    film filter go through the same shared code in both kernels: same chains, same film."""
+    abi = pkg.abi
+    kw = dict(skw)
+    if filt == "gauss":
+        kw["filt"] = abi.FILTER_GAUSSIAN
+    sd = pkg.scenes.SCENES[scene](res=32, **kw)
+    rng = np.random.default_rng(3)
+    imp = (0.2 + rng.random((32, 32))).astype(np.float32)
+    imp[:4, :4] = 0.0                                              # unlit region: proposals into it are rejected (luminance inf)
+    n_chains, n_mut = 1536, 50
+    cfg = abi.make_config(type="orbital", max_depth=8, direct_samples=-1, luminance_samples=20000, work_units=n_chains, sample_count=1)
+    res = []
+    for kern in (4, 5):
+        ctx = ctx_with_env(pkg, cfg, sd, DRMLT_KERNEL=kern)
+        ctx.set_importance_map(imp)
+        ctx.seed(77)
+        ctx.run(n_chains * n_mut)
+        res.append((ctx.chain_state(34)[1], ctx.stats(), ctx.film(), ctx.develop()))
+        ctx.close()
+    (u4, s4, f4, i4), (u5, s5, f5, i5) = res
+    assert np.array_equal(u5, u4) and s5.accepted == s4.accepted and s5.rays == s4.rays
+    assert np.abs(lum(f5) - lum(f4)).sum() / lum(f4).sum() < 1e-4
+    np.testing.assert_allclose(i5, i4, rtol=2e-3, atol=1e-6)
+
+
+def test_default_kernel_choice(pkg, native_lib, capfd):
+    """Which chain kernel runs where: BVH scenes -> the ray pool (any chain count); flat scenes -> the ray pool from 98 304
+    chains up (workUnits = -1 derives 131 072), the lane-pair kernel below (BASELINE config 2's 65 536 chains)."""
+    def kernel_of(sd, **kw):
+        cfg = pkg.abi.make_config(max_depth=8, direct_samples=-1, luminance_samples=1000, **kw)
+        os.environ["DRMLT_VERBOSE"] = "1"
+        try:
+            ctx = pkg.Context(cfg, sd)
+            ctx.seed(1)
+            capfd.readouterr()
+            ctx.run(ctx.stats().n_chains * 2)
+            err = capfd.readouterr().err
+            n = ctx.stats().n_chains
+            ctx.close()
+        finally:
+            del os.environ["DRMLT_VERBOSE"]
+        return ("v5" if "k_mutate_v5" in err else "v4" if "k_mutate_v4" in err else "?"), n
+    soup, cornell = pkg.scenes.triangle_soup(2000, 64), pkg.scenes.cornell_c2(512)
+    assert kernel_of(soup, type="orbital", work_units=1024, sample_count=1) == ("v5", 1024)
+    assert kernel_of(soup, type="mira", work_units=1024, sample_count=1) == ("v4", 1024)
+    assert kernel_of(cornell, type="orbital", work_units=65536, sample_count=256) == ("v4", 65536)      # BASELINE configs[1]
+    assert kernel_of(cornell, type="orbital", work_units=-1, sample_count=256) == ("v5", 131072)
+    assert kernel_of(cornell, type="green", work_units=131072, sample_count=256) == ("v5", 131072)
