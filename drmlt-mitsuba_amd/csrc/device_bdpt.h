@@ -335,9 +335,6 @@ DEV void eval_bdpt(const DParams &P, const TablesT &T, MSampler &smp, uint32_t c
 #pragma nounroll
         for (int t = maxT; t >= minT; --t) {
             if (!has_s || t > nS - 1) continue;
-            // cells that cannot contribute are decided from one or two fields, before the other twenty are fetched: s = 0 needs a
-            // sensor vertex on an emitter (rare: the workspace rows of all the others stay where they are, in device memory)
-            if (s == 0 && __float_as_int(W.f(BV_EMIT, ME + t - 1)) < 0) continue;
             BVert vt;
             f3 thr_t;
             W.get(ME + t - 1, vt, thr_t);
