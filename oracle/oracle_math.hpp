@@ -4,12 +4,16 @@
 // written from the reference's behaviour, templated on Float = float | double.
 // Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may use it.
 //
-// Parity status: image-level parity is UNPINNED by the reference (it ships no
-// test, scene or golden image for drmlt/pssmlt/PathSampler). What
-// IS pinned: the four transition kernels are cross-checked against the
-// reference's own tools/transition.h compiled from /root/reference (oracle/_ref,
-// vectors committed under tests/golden/), and every sampling routine is
-// chi^2-tested against its pdf the way the reference's test_chisquare.cpp does.
+// Parity status: PARITY UNPINNED. The reference ships no test, scene, golden vector or image for drmlt / pssmlt /
+// PathSampler, and none of its sources on this path builds here without stand-ins for Mitsuba's headers
+// (Boost, Xerces, OpenEXR are absent): there is no reference build and no reference-generated fixture. What holds the
+// restatement instead: line-by-line citations; Philox against Random123's published known answers; every sampling
+// routine chi^2-tested against its own pdf (the reference's test_chisquare.cpp strategy); detailed balance of every
+// acceptance rule on an analytic target; the estimators against analytic form factors and against each other; and a
+// literal replay of the reference's order of operations for the acceptance map (tests/test_oracle_process.py).
+// tests/golden/transition_kat.json holds numbers produced in round 1 by compiling the reference's tools/transition.h
+// behind a 15-line stand-in for Float / Random / math::* (`make -C oracle ref`): a cross-check of four formulas, NOT a
+// reference build by the project's rules, and not claimed as pinning.
 //
 // This file: small vector math, constants, frames, warps, Fresnel.
 #pragma once
