@@ -114,3 +114,23 @@ def test_rccl_exchange_from_cpp_world_size_one(pkg, native_lib):
     assert rows2 == (0, 50)
     with pytest.raises(pkg.DrmltError, match="bad rank"):
         ctx.comm_init(uid, 2, 2)
+
+
+def test_two_node_ranks_on_a_bvh_scene_run_the_ray_pool_kernel(pkg, native_lib, monkeypatch):
+    """The same identity on a scene that is traversed (k_mutate_v5: 64 chains per wave, state in device memory, ragged last
+    waves on both ranks): two loopback ranks of 1000 chains each == one context with the 2000 chains of the same pool."""
+    sd = pkg.scenes.triangle_soup(2000, 48)
+    n, total = 1000, 48 * 48 * 8
+    monkeypatch.setenv("DRMLT_TEST_HOOKS", "1")
+    monkeypatch.setenv("DRMLT_NODE_DEVICES", "0,0")
+    node = pkg.Node(_cfg(pkg, n, sample_count=8), sd, device_mask=1)
+    monkeypatch.delenv("DRMLT_NODE_DEVICES")
+    big = pkg.Context(_cfg(pkg, 2 * n, sample_count=8), sd)
+    assert node.seed(0x5EED) == big.seed_pool(0x5EED, 0, 2 * n)
+    node.run(total); big.run(total)
+    sn, sb = node.stats(), big.stats()
+    assert sn.mutations == sb.mutations == total // (2 * n) * 2 * n and sn.accepted == sb.accepted and sn.rays == sb.rays
+    assert sn.bvh_node_visits == sb.bvh_node_visits > 0
+    np.testing.assert_allclose(node.film(0) + node.film(1), big.film(), rtol=2e-4, atol=1e-6)
+    np.testing.assert_allclose(node.develop(), big.develop(), rtol=5e-4, atol=1e-6)
+    node.close(); big.close()
