@@ -449,17 +449,6 @@ __global__ void __launch_bounds__(CHAIN_BLOCK) k_mutate_v3(DParams P, uint32_t n
 #define V4_STACK32_CAP 11 // LDS entries of a 32-bit traversal stack (the rest spills): 11 + 3 spare rows of 256 B keep eight waves on a CU
 #define V4_QCAP_BVH 100u // BVH scenes: their kernel also keeps the traversal stack in LDS (6 KB); flushes are a negligible part of it
 
-// field-by-field copy of the parameter block out of the kernarg segment (constant address space: scalar loads)
-typedef const DParams __attribute__((address_space(4))) *KArgPtr;
-DEV void load_params(DParams &dst, KArgPtr src) {
-    static_assert(sizeof(DParams) % 8 == 0, "DParams is copied in 8-byte words");
-    typedef const unsigned long long __attribute__((address_space(4))) *KWords;
-    const KWords q = (KWords) src;
-    unsigned long long *d = reinterpret_cast<unsigned long long *>(&dst);
-#pragma unroll
-    for (unsigned i = 0; i < sizeof(DParams) / 8u; ++i) d[i] = q[i];
-}
-
 struct V4Lds {
     uint32_t coin_off, list_off, q_off; // float offsets into lds_x
     uint32_t qcap;                      // queue entries (row length of the five queue rows)
