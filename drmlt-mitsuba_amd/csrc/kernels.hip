@@ -912,7 +912,10 @@ __global__ void __launch_bounds__(CHAIN_BLOCK) k_mutate_v4(DParams P, uint32_t n
 // chain enters its second stage (the orbital rule needs only the luminances of y afterwards; Green's reverse move and Mira's
 // ratio need x, y and z together, which is why those types keep k_mutate_v4). Bookkeeping is v4's: decide per lane, commit /
 // proposals / coins flattened over the 64 lanes. Same addressed draws, same arithmetic per component: the same chains.
-#define V5_QCAP 96u
+#define V5_QCAP 96u        // splat queue entries (a round of the bookkeeping branch adds at most 64: flushed in between)
+#define V5_QCAP_STACK32 0u  // the builds with 32-bit traversal stacks splat straight from the bookkeeping branch: their LDS goes to the stack column
+#define V5_STACK32_CAP 25 // (no splat queue, coins drawn per lane instead of kept in four rows: 28 rows of 256 B for the column; measured on 50 000 /
+                          // 1 000 000 triangles: 11 entries 2.23e8 / 5.65e7, 16 2.48e8 / 7.03e7, 20 2.69e8 / 7.62e7)
 #define V5_SLOTS 128u
 enum { RS_IDLE = 0, RS_BUSY = 1, RS_DONE = 2 };
 
@@ -923,17 +926,17 @@ struct V5Lds {
     uint32_t ring_off;           // pending slots, FIFO: V5_SLOTS bytes
     uint32_t status_off;         // RS_* per slot: V5_SLOTS bytes
 };
-DEV V5Lds v5_layout(uint32_t D) {
+DEV V5Lds v5_layout(uint32_t D, uint32_t qcap, bool coin_rows) {
     V5Lds L;
     L.coin_off = D * 64u;
-    L.list_off = L.coin_off + 4u * 64u;
+    L.list_off = L.coin_off + (coin_rows ? 4u * 64u : 0u);
     L.q_off = L.list_off + 64u;
-    L.pool_off = L.q_off + 5u * V5_QCAP;
+    L.pool_off = L.q_off + 5u * qcap;
     L.ring_off = L.pool_off + 8u * V5_SLOTS;
     L.status_off = L.ring_off + V5_SLOTS / 4u;
     return L;
 }
-static size_t v5_lds_bytes(uint32_t D) { return ((size_t) D * 64u + 4u * 64u + 64u + 5u * V5_QCAP + 8u * V5_SLOTS + 2u * (V5_SLOTS / 4u)) * sizeof(float); } // (+ the scene tables, when they are staged)
+static size_t v5_lds_bytes(uint32_t D, uint32_t qcap, bool coin_rows) { return ((size_t) D * 64u + (coin_rows ? 4u * 64u : 0u) + 64u + 5u * qcap + 8u * V5_SLOTS + 2u * (V5_SLOTS / 4u)) * sizeof(float); } // (+ the scene tables, when they are staged)
 
 // the proposal rows as the path step sees them: whatever stage is being evaluated sits in the one row group
 struct PoolRowSampler {
@@ -1049,6 +1052,8 @@ DEV void v5_iid_second_again(const DParams &P, uint32_t D, uint32_t col, size_t 
 template <int FEAT, bool STACK16, bool OVF, bool STAMPS = false, bool LDS_TABLES = false>
 __global__ void __launch_bounds__(CHAIN_BLOCK, 2) k_mutate_v5(DParams P, uint32_t n_mut, uint32_t mut_base) {
     constexpr bool FLAT = (FEAT & 8) == 0;
+    constexpr uint32_t QCAP = (FLAT || STACK16) ? V5_QCAP : V5_QCAP_STACK32;
+    constexpr bool COIN_ROWS = FLAT || STACK16; // coins drawn one mutation ahead by the flattened proposal pass (else: per lane, when a mutation starts)
     // per-section copies of the parameter block, read through a kernarg pointer the compiler cannot see through (see k_mutate_v4):
     // the fields a section uses are scalar loads at its head and dead at its end, instead of ~200 spilled scalar registers
     typedef const DParams __attribute__((address_space(4))) *KArg;
@@ -1065,8 +1070,8 @@ __global__ void __launch_bounds__(CHAIN_BLOCK, 2) k_mutate_v5(DParams P, uint32_
     const bool live = c < P0.n_chains;
     const uint32_t cc = live ? c : P0.n_chains - 1;
     const uint32_t D = (uint32_t) P0.eff_dim, nb1 = (D + 3u) / 4u;
-    const V5Lds L = v5_layout(D);
-    const V4Lds Lq{0u, 0u, L.q_off, V5_QCAP};
+    const V5Lds L = v5_layout(D, QCAP, COIN_ROWS);
+    const V4Lds Lq{0u, 0u, L.q_off, QCAP};
     unsigned char *const ring = reinterpret_cast<unsigned char *>(&lds_x[L.ring_off]);
     unsigned char *const status = reinterpret_cast<unsigned char *>(&lds_x[L.status_off]);
     int *const lds_list = reinterpret_cast<int *>(&lds_x[L.list_off]);
@@ -1099,7 +1104,7 @@ __global__ void __launch_bounds__(CHAIN_BLOCK, 2) k_mutate_v5(DParams P, uint32_
     bool reported = false;
     ps.phase = (live && base < limit) ? PH_DONE : PH_IDLE;
     const int batch = P0.mh_batch > 64 ? 64 : P0.mh_batch;
-    { // coins of every chain's first mutation of this launch (afterwards they are drawn one mutation ahead, beside the proposal)
+    if (COIN_ROWS) { // coins of every chain's first mutation of this launch (afterwards they are drawn one mutation ahead, beside the proposal)
         const u4 coins = philox4x32_10(P0.key0, P0.key1, 0u, base, P0.chain_offset + cc, TAG_COIN);
         float *dst = &lds_x[L.coin_off + lane];
         dst[0] = u32_to_unit(coins.x); dst[64] = u32_to_unit(coins.y); dst[128] = u32_to_unit(coins.z); dst[192] = u32_to_unit(coins.w);
@@ -1107,7 +1112,7 @@ __global__ void __launch_bounds__(CHAIN_BLOCK, 2) k_mutate_v5(DParams P, uint32_
 
     // traversal: this lane's column of the stack, the ray it is working on (`slot`), the FIFO of pending slots
     typedef typename std::conditional<STACK16, short, int>::type StackT;
-    constexpr int CAP = STACK16 ? BVH_STACK : V4_STACK32_CAP;
+    constexpr int CAP = STACK16 ? BVH_STACK : V5_STACK32_CAP;
     __shared__ StackT v5_stack[FLAT ? 1 : (CAP + 3) * 64];
     StackT *const my_stack = v5_stack + (FLAT ? 0u : lane);
     Trav T;
@@ -1188,7 +1193,7 @@ __global__ void __launch_bounds__(CHAIN_BLOCK, 2) k_mutate_v5(DParams P, uint32_
             if (pmask && (__popcll(pmask) >= batch || !rays_in_flight)) {
                 SECTION_PARAMS(Pm);
                 if (STAMPS) { n_mh++; n_parked += (unsigned long long) __popcll(pmask); }
-                if (qn + 64u > V5_QCAP) v4_flush(Pm, Lq, qn, lane);
+                if (QCAP != 0u && qn + 64u > QCAP) v4_flush(Pm, Lq, qn, lane);
                 int commit = 0, kind = 0; // kind: 0 nothing / finished, 1 next mutation, 2 second stage (4: between mutations, resolved below)
                 bool want0 = false, want1 = false, want2 = false;
                 float e0x = 0.f, e0y = 0.f, e0r = 0.f, e0g = 0.f, e0b = 0.f;
@@ -1228,12 +1233,17 @@ __global__ void __launch_bounds__(CHAIN_BLOCK, 2) k_mutate_v5(DParams P, uint32_
                     }
                     if (kind == 4) kind = (done_now < target || (done_now < limit && more)) ? 1 : 0;
                 }
-                // the queue holds V5_QCAP entries, a round adds at most 64
-                v4_enqueue(Lq, qn, want0, e0x, e0y, e0r, e0g, e0b);
-                if (qn + 64u > V5_QCAP) v4_flush(Pm, Lq, qn, lane);
-                v4_enqueue(Lq, qn, want1, e1x, e1y, e1r, e1g, e1b);
-                if (qn + 64u > V5_QCAP) v4_flush(Pm, Lq, qn, lane);
-                v4_enqueue(Lq, qn, want2, e2x, e2y, e2r, e2g, e2b);
+                if constexpr (QCAP != 0u) { // the queue holds QCAP entries, a round adds at most 64
+                    v4_enqueue(Lq, qn, want0, e0x, e0y, e0r, e0g, e0b);
+                    if (qn + 64u > QCAP) v4_flush(Pm, Lq, qn, lane);
+                    v4_enqueue(Lq, qn, want1, e1x, e1y, e1r, e1g, e1b);
+                    if (qn + 64u > QCAP) v4_flush(Pm, Lq, qn, lane);
+                    v4_enqueue(Lq, qn, want2, e2x, e2y, e2r, e2g, e2b);
+                } else { // no queue in this build: ImageBlock::put straight away (film_put applies the validity test)
+                    if (want0) film_put(Pm, e0x, e0y, mk3(e0r, e0g, e0b));
+                    if (want1) film_put(Pm, e1x, e1y, mk3(e1r, e1g, e1b));
+                    if (want2) film_put(Pm, e2x, e2y, mk3(e2r, e2g, e2b));
+                }
 
                 // ---- commit (DRMLTSampler::accept: uCurrent = wrap(adopted proposal)) to the state's home in device memory,
                 // flattened: items (accepted chain j, row quad q), chain-minor
@@ -1285,9 +1295,15 @@ __global__ void __launch_bounds__(CHAIN_BLOCK, 2) k_mutate_v5(DParams P, uint32_
                 if (cmask | gmask) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
                 // ---- start (parked chain lanes): the coins of the mutation that begins were drawn with the previous one
                 if (parked && kind == 1) {
-                    const float *cn = &lds_x[L.coin_off + lane];
-                    cs.large = cn[0] < Pm.p_large;
-                    cs.coin_acc1 = cn[64]; cs.coin_acc2 = cn[128]; cs.coin_mix = cn[192];
+                    if (COIN_ROWS) {
+                        const float *cn = &lds_x[L.coin_off + lane];
+                        cs.large = cn[0] < Pm.p_large;
+                        cs.coin_acc1 = cn[64]; cs.coin_acc2 = cn[128]; cs.coin_mix = cn[192];
+                    } else {
+                        const u4 coins = philox4x32_10(Pm.key0, Pm.key1, 0u, base + cs.it, Pm.chain_offset + cc, TAG_COIN);
+                        cs.large = u32_to_unit(coins.x) < Pm.p_large;
+                        cs.coin_acc1 = u32_to_unit(coins.y); cs.coin_acc2 = u32_to_unit(coins.z); cs.coin_mix = u32_to_unit(coins.w);
+                    }
                     cs.stage = 0;
                     cs.do_second = false;
                     cs.nd1 = cs.nd2 = 0u;
@@ -1300,7 +1316,7 @@ __global__ void __launch_bounds__(CHAIN_BLOCK, 2) k_mutate_v5(DParams P, uint32_
                 const unsigned long long f1mask = __ballot(kind == 1);
                 if (f1mask) {
                     if (kind == 1) lds_list[prefix(f1mask)] = (int) lane;
-                    const uint32_t n = (uint32_t) __popcll(f1mask), total = n * (nb1 + 1u);
+                    const uint32_t n = (uint32_t) __popcll(f1mask), total = n * (nb1 + (COIN_ROWS ? 1u : 0u));
                     const float rcp_n = 1.f / (float) n;
                     for (uint32_t ib = 0u; ib < total; ib += 64u) {
                         const uint32_t i = ib + lane;
@@ -1458,9 +1474,11 @@ __global__ void __launch_bounds__(CHAIN_BLOCK, 2) k_mutate_v5(DParams P, uint32_
         atomicAdd(Pe.stats + 23, n_mh); atomicAdd(Pe.stats + 24, n_parked); atomicAdd(Pe.stats + 25, n_stepping);
     }
     // "Perform the last splat": the current states with what they have accumulated since they were adopted
-    if (qn + 64u > V5_QCAP) v4_flush(Pe, Lq, qn, lane);
-    v4_enqueue(Lq, qn, live && cum > 0.f, cs.cur.px, cs.cur.py, cs.cur.r * cum, cs.cur.g * cum, cs.cur.b * cum);
-    v4_flush(Pe, Lq, qn, lane);
+    if constexpr (QCAP != 0u) {
+        if (qn + 64u > QCAP) v4_flush(Pe, Lq, qn, lane);
+        v4_enqueue(Lq, qn, live && cum > 0.f, cs.cur.px, cs.cur.py, cs.cur.r * cum, cs.cur.g * cum, cs.cur.b * cum);
+        v4_flush(Pe, Lq, qn, lane);
+    } else if (live && cum > 0.f) film_put(Pe, cs.cur.px, cs.cur.py, mk3(cs.cur.r * cum, cs.cur.g * cum, cs.cur.b * cum));
     if (live) { // (the PSS state is at home in device memory already)
         Pe.cur_lum[c] = cs.cur.lum; Pe.cur_px[c] = cs.cur.px; Pe.cur_py[c] = cs.cur.py;
         Pe.cur_r[c] = cs.cur.r; Pe.cur_g[c] = cs.cur.g; Pe.cur_b[c] = cs.cur.b;
@@ -1568,8 +1586,8 @@ void launch_mutate(const DParams &P, uint32_t n_mut, uint32_t mut_base, hipStrea
     const size_t D = (size_t) P.eff_dim, D4 = (D + 3) & ~(size_t) 3;
     const dim3 block(CHAIN_BLOCK);
     if (P.kernel_variant == 5) { // ray pool, 64 chains per wave
-        size_t lds = v5_lds_bytes((uint32_t) D);
         const bool flat = (P.features & 8) == 0;
+        size_t lds = v5_lds_bytes((uint32_t) D, (flat || P.bvh_stack16) ? V5_QCAP : V5_QCAP_STACK32, flat || P.bvh_stack16);
         if (flat && P.tables_in_lds) lds += (size_t) P.n_shade * 64 + (size_t) P.n_bsdfs * 48 + (size_t) P.n_emitters * 32;
         if (getenv("DRMLT_VERBOSE")) fprintf(stderr, "[drmlt] k_mutate_v5: %zu B of LDS per wave%s\n", lds, flat ? "" : " (+ the traversal stack)");
         const dim3 g5((P.n_chains + 63) / 64);
