@@ -1596,6 +1596,7 @@ void launch_mutate(const DParams &P, uint32_t n_mut, uint32_t mut_base, hipStrea
             if (!P.tables_in_lds) hipLaunchKernelGGL((k_mutate_v5<7, true, false, false, false>), g5, block, lds, st, P, n_mut, mut_base);
             else if (P.features == 0 && (P.debug & 128)) hipLaunchKernelGGL((k_mutate_v5<0, true, false, true, true>), g5, block, lds, st, P, n_mut, mut_base); // diagnostic stamps
             else if (P.features == 0) hipLaunchKernelGGL((k_mutate_v5<0, true, false, false, true>), g5, block, lds, st, P, n_mut, mut_base);
+            else if (P.features == 1) hipLaunchKernelGGL((k_mutate_v5<1, true, false, false, true>), g5, block, lds, st, P, n_mut, mut_base); // rough conductors, no dielectric (config 3)
             else if ((P.features & ~3) == 0) hipLaunchKernelGGL((k_mutate_v5<3, true, false, false, true>), g5, block, lds, st, P, n_mut, mut_base);
             else hipLaunchKernelGGL((k_mutate_v5<7, true, false, false, true>), g5, block, lds, st, P, n_mut, mut_base);
         }
