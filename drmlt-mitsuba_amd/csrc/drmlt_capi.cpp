@@ -435,8 +435,8 @@ drmlt_ctx *drmlt_create(const drmlt_config *cfg, const drmlt_scene *scene, int d
             work_units = (int) std::max<uint64_t>(1, (budget + per_unit - 1) / per_unit);
         } else {
             // (k_mutate_v5, the ray-pool kernel, carries 64 chains per wave: 131 072 fill the device; it is the path technique's kernel
-            // for every type but Mira -- flat scenes included: 2.15e9 at 131 072 chains against k_mutate_v4's 1.79e9 at 65 536)
-            const bool pool_kernel = !mmlt && !bdpt && cfg->algo != DRMLT_ALGO_PSSMLT && cfg->type != DRMLT_TYPE_MIRA && !getenv("DRMLT_KERNEL");
+            // for all three types -- flat scenes included: 2.15e9 at 131 072 chains against k_mutate_v4's 1.79e9 at 65 536)
+            const bool pool_kernel = !mmlt && !bdpt && cfg->algo != DRMLT_ALGO_PSSMLT && !getenv("DRMLT_KERNEL");
             const uint64_t fill = mmlt ? 262144 : ((bdpt || pool_kernel) ? 131072 : 65536); // mmlt: two rounds of waves, run in depth order
             work_units = (int) std::min<uint64_t>(fill, std::max<uint64_t>(64, budget / 64 / 64 * 64));
         }
@@ -531,13 +531,13 @@ drmlt_ctx *drmlt_create(const drmlt_config *cfg, const drmlt_scene *scene, int d
     for (const DPrim &g : ctx->prims) if (g.type == PRIM_SPHERE) P.features |= 4;
     if (P.use_bvh) P.features |= 8;
     if (getenv("DRMLT_FEAT_ALL")) P.features = 15;
-    // the ray-pool kernel is the BVH scenes' (flat scenes loop over their records: rays need no regrouping there), and it keeps ONE
-    // proposal row group in LDS: type = orbital only (Green's reverse move and Mira's ratio need x, y and z together)
+    // the ray-pool kernel keeps ONE proposal row group in LDS: Green's reverse move and Mira's ratio, which need x, y and z together,
+    // recompute what is not there from the state in device memory and the addressed stream.
     // On flat scenes it needs the chains to put two of its 64-chain waves on a SIMD: from 98 304 chains up it is the default
     // (Cornell: v5 2.15e9 at 131 072 chains, 1.11e9 at 65 536; v4 1.79e9 at 65 536, 1.55e9 at 131 072). BASELINE's config 2 fixes
     // 65 536 chains and therefore runs k_mutate_v4.
     const bool v5_forced = getenv("DRMLT_KERNEL") && atoi(getenv("DRMLT_KERNEL")) == 5;
-    if (P.kernel_variant == 5 && (cfg->type == DRMLT_TYPE_MIRA || (!P.use_bvh && !v5_forced && ctx->n_chains < 98304u))) P.kernel_variant = 4;
+    if (P.kernel_variant == 5 && !P.use_bvh && !v5_forced && ctx->n_chains < 98304u) P.kernel_variant = 4;
     // (v5 on the Cornell scene, 131 072 chains: batch 16 1.98e9, 24 2.08e9, 32 2.13e9, 48 1.84e9; on the soup: 8 5.05e8, 16 5.24e8, 32 5.06e8)
     P.mh_batch = P.kernel_variant == 5 ? (P.use_bvh ? 16 : 32) : (P.kernel_variant == 4 ? (P.use_bvh ? (P.bvh_stack16 ? 6 : 4) : (P.features == 0 ? 12 : 8)) : 32); // v4 / v5: chains run free, the bookkeeping branch fires as soon as a few are parked
     if (const char *k = getenv("DRMLT_MH_BATCH")) P.mh_batch = std::max(1, std::min(64, atoi(k)));

@@ -886,8 +886,7 @@ __global__ void __launch_bounds__(CHAIN_BLOCK) k_mutate_v4(DParams P, uint32_t n
 }
 
 // ------------------------------------------------------------------------------------------
-// k_mutate_v5: the chain loop with MORE RAYS THAN LANES (types orbital and green; Mira, whose transition ratio needs x, y and z
-// of every dimension at once, stays on k_mutate_v4).
+// k_mutate_v5: the chain loop with MORE RAYS THAN LANES (all three types).
 //
 // In k_mutate_v4 a ray belongs to a lane: chain lane i traverses its camera / bounce ray, helper lane 32 + i the shadow ray
 // of the same vertex. On a scene that is traversed (not looped over) the wave then advances ~22 of its 64 lanes per node
@@ -909,9 +908,10 @@ __global__ void __launch_bounds__(CHAIN_BLOCK) k_mutate_v4(DParams P, uint32_t n
 // layout it has between launches anyway): it is read when a mutation's proposal is made (flattened over the wave, chain-minor:
 // partly coalesced 256 B rows) and written when a proposal is adopted -- SURVEY 8(d)'s B_state, now real traffic (~250 B per
 // mutation, L2 / MALL resident). LDS holds ONE row group: the proposal under evaluation -- y, overwritten in place by z when a
-// chain enters its second stage (the orbital rule needs only the luminances of y afterwards; Green's reverse move and Mira's
-// ratio need x, y and z together, which is why those types keep k_mutate_v4). Bookkeeping is v4's: decide per lane, commit /
-// proposals / coins flattened over the 64 lanes. Same addressed draws, same arithmetic per component: the same chains.
+// chain enters its second stage. The orbital rule needs only the luminances of y afterwards; Green's reverse move and Mira's
+// ratio need x, y and z together and RECOMPUTE what the rows no longer hold from the state and the addressed stream (Green:
+// v5_iid_second_again, flattened; Mira: PoolRowSampler::y_raw, per deciding lane -- a twentieth of the mutations get that far).
+// Bookkeeping is v4's: decide per lane, commit / proposals / coins flattened over the 64 lanes. Same addressed draws, same arithmetic per component: the same chains.
 #define V5_QCAP 96u        // splat queue entries (a round of the bookkeeping branch adds at most 64: flushed in between)
 #define V5_QCAP_STACK32 0u  // the builds with 32-bit traversal stacks splat straight from the bookkeeping branch: their LDS goes to the stack column
 #define V5_STACK32_CAP 25 // (no splat queue, coins drawn per lane instead of kept in four rows: 28 rows of 256 B for the column; measured on 50 000 /
@@ -941,11 +941,22 @@ static size_t v5_lds_bytes(uint32_t D, uint32_t qcap, bool coin_rows) { return (
 // the proposal rows as the path step sees them: whatever stage is being evaluated sits in the one row group
 struct PoolRowSampler {
     uint32_t lane;
-    DEV void reset_caches() {}
+    // Mira's ratio alone looks behind the rows (they hold z by then): the state in device memory and the first-stage draws,
+    // set by the kernel before a decision (mira_*), block cache of the TAG_S1 stream
+    const float *mira_x = nullptr;
+    size_t mira_stride = 0;
+    uint32_t mira_k0 = 0u, mira_k1 = 0u, mira_major = 0u, mira_chain = 0u, cached = 0xffffffffu;
+    u4 blk = {0u, 0u, 0u, 0u};
+    DEV void reset_caches() { cached = 0xffffffffu; }
     DEV float row(uint32_t k) const { return lds_x[k * 64u + lane]; }
     DEV float next(uint32_t k) const { return wrap01(row(k)); }
-    DEV float x(uint32_t k) const { return row(k); }      // (Mira's ratio: never evaluated here, the launcher routes type = orbital only)
-    DEV float y_raw(uint32_t k) const { return row(k); }
+    DEV float x(uint32_t k) const { return load_global_f32(mira_x + (size_t) k * mira_stride); }
+    DEV float y_raw(uint32_t k) { // iid Kelemen step, small (the only caller: mira_ratio)
+        FP_STRICT;
+        if (cached != (k >> 2)) { cached = k >> 2; blk = philox4x32_10(mira_k0, mira_k1, cached, mira_major, mira_chain, TAG_S1); }
+        const uint32_t c = k & 3u, w = c == 0u ? blk.x : (c == 1u ? blk.y : (c == 2u ? blk.z : blk.w));
+        return x(k) + kelemen_sample(u32_to_unit(w), KELEMEN_S2);
+    }
     DEV float z_raw(uint32_t k) const { return row(k); }
 };
 
@@ -1200,6 +1211,10 @@ __global__ void __launch_bounds__(CHAIN_BLOCK, 2) k_mutate_v5(DParams P, uint32_
                 float e1x = 0.f, e1y = 0.f, e1r = 0.f, e1g = 0.f, e1b = 0.f;
                 float e2x = 0.f, e2y = 0.f, e2r = 0.f, e2g = 0.f, e2b = 0.f;
                 if (parked) {
+                    if (Pm.type == 1) { // Mira: what its ratio reads (PoolRowSampler)
+                        smp.mira_x = Pm.x + cc; smp.mira_stride = Pm.n_chains; smp.mira_k0 = Pm.key0; smp.mira_k1 = Pm.key1;
+                        smp.mira_major = base + cs.it; smp.mira_chain = Pm.chain_offset + cc; smp.reset_caches();
+                    }
                     const MhOutcome o = mh_decide(Pm, cs, smp, ps, ct);
                     if (o.decided) {
                         cum += o.w.w0;

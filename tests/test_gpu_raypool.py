@@ -1,9 +1,8 @@
 """k_mutate_v5, the ray-pool chain kernel of BVH scenes (64 chains per wave, rays queued in LDS, any lane traverses any
 ray; north_star's "wavefront ballot / prefix-sum ray compaction"): it must run the chains of k_mutate_v4 / k_mutate_v3 bit
 for bit -- same addressed draws, same proposal arithmetic, same acceptance code (device_mh.h) -- whatever the order in
-which the wave happens to traverse its rays. (Types orbital and green: the kernel keeps ONE proposal row group in LDS and
-recomputes what Green's reverse move needs; Mira's transition ratio wants x, y and z of every dimension at once and stays
-on k_mutate_v4, which the last test checks.)"""
+which the wave happens to traverse its rays. (The kernel keeps ONE proposal row group in LDS and recomputes, from the state
+in device memory and the addressed stream, what Green's reverse move and Mira's transition ratio need beside it.)"""
 import os
 
 import numpy as np
@@ -49,11 +48,17 @@ CASES = [
     ("triangle_soup", dict(n_tris=2000), dict(type="green", use_mixture=1), {}),
     ("door_c3", {}, dict(type="green"), {}),                                                          # BASELINE config 3's kernel
     ("cornell_c2", {}, dict(type="green", timid_after_large=1, max_depth=5, rr_depth=2), {}),
+    # Tierney & Mira's rule: the ratio Q1(y|z) / Q1(y|x) from the rows (z), the state (x) and the first-stage draws again (y)
+    ("triangle_soup", dict(n_tris=2000), dict(type="mira"), {}),
+    ("triangle_soup", dict(n_tris=2000), dict(type="mira", timid_after_large=1, p_large=0.5), {}),
+    ("door_c3", {}, dict(type="mira"), {}),
+    ("cornell_c2", {}, dict(type="mira", max_depth=5, rr_depth=2), {}),
 ]
 
 
 @pytest.mark.parametrize("scene,skw,kw,env", CASES, ids=["soup-orbital", "soup-timid", "soup-mixture", "soup-short", "soup40k", "caustic-bvh", "door-bvh", "flat-cornell", "flat-cornell-mixture", "flat-caustic-timid", "flat-door",
-                              "soup-green", "soup-green-timid", "soup-green-mixture", "flat-door-green", "flat-cornell-green-timid"])
+                              "soup-green", "soup-green-timid", "soup-green-mixture", "flat-door-green", "flat-cornell-green-timid",
+                              "soup-mira", "soup-mira-timid", "flat-door-mira", "flat-cornell-mira-short"])
 def test_ray_pool_kernel_runs_the_same_chains(pkg, native_lib, scene, skw, kw, env):
     sd = pkg.scenes.SCENES[scene](res=32, **skw)
     n_chains, n_mut = 1000, 60                       # 1000: the last wave of either kernel is ragged
@@ -100,20 +105,6 @@ def test_ray_pool_kernel_with_run_ahead_and_acceptance_map(pkg, native_lib):
     for u, s, f in res[1:]:
         assert np.array_equal(u, res[0][0]) and s.accepted == res[0][1].accepted and s.mutations == n_chains * per_chain
         np.testing.assert_array_equal(f, res[0][2])                                   # marks are whole numbers of box weights: exact
-
-
-def test_mira_stays_on_v4(pkg, native_lib, capfd):
-    sd = pkg.scenes.triangle_soup(2000, 32)
-    cfg = pkg.abi.make_config(type="mira", max_depth=8, direct_samples=-1, luminance_samples=20000, work_units=512, sample_count=1)
-    ctx = ctx_with_env(pkg, cfg, sd, DRMLT_KERNEL=5, DRMLT_VERBOSE=1)
-    ctx.seed(1)
-    os.environ["DRMLT_VERBOSE"] = "1"
-    try:
-        ctx.run(512 * 4)
-    finally:
-        del os.environ["DRMLT_VERBOSE"]
-    err = capfd.readouterr().err
-    assert "k_mutate_v4" in err and "k_mutate_v5" not in err
 
 
 @pytest.mark.parametrize("scene,skw,filt", [("triangle_soup", dict(n_tris=2000), "box"), ("cornell_c2", {}, "gauss")], ids=["soup-importance", "cornell-gaussian-importance"])
@@ -163,7 +154,7 @@ def test_default_kernel_choice(pkg, native_lib, capfd):
         return ("v5" if "k_mutate_v5" in err else "v4" if "k_mutate_v4" in err else "?"), n
     soup, cornell = pkg.scenes.triangle_soup(2000, 64), pkg.scenes.cornell_c2(512)
     assert kernel_of(soup, type="orbital", work_units=1024, sample_count=1) == ("v5", 1024)
-    assert kernel_of(soup, type="mira", work_units=1024, sample_count=1) == ("v4", 1024)
+    assert kernel_of(soup, type="mira", work_units=1024, sample_count=1) == ("v5", 1024)
     assert kernel_of(cornell, type="orbital", work_units=65536, sample_count=256) == ("v4", 65536)      # BASELINE configs[1]
     assert kernel_of(cornell, type="orbital", work_units=-1, sample_count=256) == ("v5", 131072)
     assert kernel_of(cornell, type="green", work_units=131072, sample_count=256) == ("v5", 131072)
