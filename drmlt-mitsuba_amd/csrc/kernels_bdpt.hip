@@ -151,20 +151,27 @@ template <int FEAT, int OCC> __global__ void __launch_bounds__(CHAIN_BLOCK, OCC)
     unsigned long long t_stages = 0, t_splat = 0, t_commit = 0;
 #define BSTAMP() (dbg ? __builtin_amdgcn_s_memtime() : 0ull)
     const unsigned long long k0 = BSTAMP();
-    if (live) for (uint32_t it = 0; it < n_mut; ++it) {
+    // Chains run free: every pass of the loop evaluates ONE path per lane -- the first stage of the lane's next mutation, or the
+    // second stage / Green's reverse move of the one it is in. (A lockstep loop over mutations with the stages inside ran a whole
+    // wave pass for the two or three lanes in sixty-four that go to a second stage -- 2 % of bdpt's mutations, so three passes in
+    // four had one: 1.8 passes per mutation instead of 1.02.)
+    uint32_t it = 0u;
+    int stage = 0;
+    float y_lum = 0.f, z_lum = 0.f, a1 = 0.f;
+    uint32_t ns1 = 0, ne1 = 0, nd1 = 0, ns2 = 0, ne2 = 0, nd2 = 0;
+    for (;;) {
+        const bool run = live && it < n_mut;
+        if (!__builtin_amdgcn_ballot_w64(run)) break;
+        if (!run) continue;
         const uint32_t m = mut_base + it;
         const u4 coins = philox4x32_10(P.key0, P.key1, 0u, m, smp.chain, TAG_COIN);
         const bool large = u32_to_unit(coins.x) < P.p_large;
         smp.major = m;
         smp.large = large;
         const unsigned long long b0 = BSTAMP();
-        float y_lum = 0.f, z_lum = 0.f;
-        uint32_t ns1 = 0, ne1 = 0, nd1 = 0, ns2 = 0, ne2 = 0, nd2 = 0;
-        float a1 = 0.f, a2 = 0.f;
-        bool acc1 = false, acc2 = false, doSecond = false;
-
-#pragma nounroll
-        for (int stage = 0; stage < 3; ++stage) {
+        float a2 = 0.f;
+        bool acc1 = false, acc2 = false, decided = true;
+        {
             smp.mode = stage == 0 ? SM_STAGE1 : (stage == 1 ? SM_STAGE2 : SM_REVERSE);
             BdptResult R;
             // Green's reverse path only needs its luminance; it is written over the first-stage list, which is rejected
@@ -174,23 +181,22 @@ template <int FEAT, int OCC> __global__ void __launch_bounds__(CHAIN_BLOCK, OCC)
             ct.rays += R.nrays;
             const float lum = list_finalize(P, target, R.lum);
             if (stage == 0) {
+                bool doSecond = false;
                 y_lum = lum; ns1 = R.n_sensor; ne1 = R.n_emitter; nd1 = R.n_direct;
+                z_lum = 0.f; ns2 = ne2 = nd2 = 0u;
                 mh_first(mix, false, large, y_lum, cur_lum, u32_to_unit(coins.y), u32_to_unit(coins.w), a1, acc1, doSecond); // timidAfterLarge is refused for bdpt
-                if (!doSecond) break;
+                if (doSecond) { stage = 1; decided = false; }
             } else if (stage == 1) {
                 z_lum = lum; ns2 = R.n_sensor; ne2 = R.n_emitter; nd2 = R.n_direct;
                 if (mix) { // the second proposal replaces the first
-                    acc1 = false; a1 = 0.f;
+                    a1 = 0.f;
                     mh_second_mixture(z_lum, cur_lum, u32_to_unit(coins.z), a2, acc2);
-                    break;
-                }
-                if (lum_invalid(z_lum)) break;
-                if (P.type == 0) {
+                } else if (lum_invalid(z_lum)) {
+                } else if (P.type == 0) {
                     // Green: the first-stage splats must reach the film before the reverse move reuses their list
                     if (!amap && a1 > 0.f) list_splat(P, L1, y_lum, a1);
-                    continue;
-                }
-                if (P.type == 1) {
+                    stage = 2; decided = false;
+                } else if (P.type == 1) {
                     float ratio = 1.f;
                     if (!(fminf(1.f, y_lum / z_lum) >= 1.f)) { // (a large step never gets here: no second stage after it)
                         float num = 0.f, den = 0.f;
@@ -210,14 +216,15 @@ template <int FEAT, int OCC> __global__ void __launch_bounds__(CHAIN_BLOCK, OCC)
                 } else {
                     mh_second_orbital(y_lum, z_lum, cur_lum, u32_to_unit(coins.z), a2, acc2);
                 }
-                break;
             } else {
                 ct.acc2b_rev += 1u << 16;
                 mh_second_green(lum, z_lum, cur_lum, a1, u32_to_unit(coins.z), a2, acc2);
             }
         }
         const unsigned long long b1 = BSTAMP();
-        const bool y_splatted = !mix && !amap && P.type == 0 && doSecond && !lum_invalid(z_lum); // Green went on to the reverse move
+        if (!decided) { t_stages += b1 - b0; continue; }
+        const bool doSecond = stage != 0;
+        const bool y_splatted = stage == 2 && !amap; // Green went on to the reverse move
 
         // Expectation weights (device_mh.h). The current state's share is accumulated and its list splatted once, when the
         // state is replaced or the launch ends (the reference's pssmlt loop does the same, pssmlt_proc.cpp:205-228): the
@@ -250,6 +257,8 @@ template <int FEAT, int OCC> __global__ void __launch_bounds__(CHAIN_BLOCK, OCC)
             const int mark = mh_amap_mark(mix, amap, large, acc1, acc2);
             if (mark) list_splat_const(P, acc1 ? L1 : L2, mh_amap_colour(mark));
         }
+        ++it;
+        stage = 0;
         const unsigned long long b3 = BSTAMP();
         t_stages += b1 - b0; t_splat += b2 - b1; t_commit += b3 - b2;
     }
