@@ -5,18 +5,31 @@
 // accumulates all t >= 2 strategies, every t = 1 strategy adds a light-image splat.
 //
 // Storage per chain:
-//   global workspace `bd_verts`  [BV_FIELDS][NVS][n]   geometry of every stored vertex (SoA, coalesced per field)
+//   global workspace `bd_verts`  [chain][NVS] records of BR_FLOATS floats (80 B): every stored vertex, contiguous -- written by
+//                                the chain's lane during the walks, read by WHICHEVER lane connects a pair of them
 //   LDS rows from `mis_row`      2 x NVS rows           fwd / rev densities (area measure) -- what the MIS sweep reads for every pair
 //   global lists `bd_lists`      [slot][BL_ROWS][n]     splat lists of the current state and the two proposals
 // NVS = ME + MS vertex slots: emitter vertices 1..ME (ME = maxDepth), sensor vertices 1..MS (MS = maxDepth + 1);
 // the supernodes are implicit.
+//
+// Two phases per evaluation:
+//   walks        lane = chain: both random walks, vertex records to the workspace, densities to the LDS rows;
+//   connections  lane = CELL: the (s, t) pairs of all the wave's chains are laid out side by side -- chain after chain, each chain's
+//                cells in the reference's order (s and t descending, pathsampler.cpp:373-380) -- and handed out 64 at a time, whole
+//                chains per round. A cell's lane gathers the two vertex records, connects, traces the visibility ray and weights
+//                with Path::miWeight; a chain's contributions are summed by a segmented scan whose tree depends on nothing but
+//                the chain's own cell count (so a chain's result does not depend on its neighbours in the wave), its light-image
+//                splats numbered by ballot + prefix count. The lockstep alternative -- the wave walks one (s, t) grid, every lane
+//                taking the cells its own subpaths reach -- ran 44 grid iterations per evaluation with 17 of 64 lanes in each.
 #pragma once
 #include "device_bidir.h"
 
-enum { BV_P = 0, BV_N = 3, BV_S = 6, BV_WI = 9, BV_LEN2 = 12, BV_COS = 13, BV_THR = 14, BV_IDS = 17, BV_EMIT = 18, BV_SHADE = 19, BV_GINV = 20, BV_FIELDS = 21 };
+enum { BR_P = 0, BR_N = 3, BR_S = 6, BR_WI = 9, BR_LEN2 = 12, BR_COS = 13, BR_GINV = 14, BR_IDS = 15, BR_THR = 16, BR_SHADE = 19, BR_FLOATS = 20 };
+#define BDPT_MAX_BSDFS 4096      // BR_IDS: kind | bsdf << 4 | (emitter + 1) << 16 (drmlt_create refuses scenes beyond these for technique=bdpt)
+#define BDPT_MAX_EMITTERS 65534
 enum { BL_LUM = 0, BL_META = 1, BL_MAIN = 2, BL_MORE = 7 }; // rows of a splat list; 5 rows (px, py, r, g, b) per splat
 enum { MF_FWD = 0, MF_REV = 1, MF_GROUPS = 2 }; // LDS row groups. The edge factor len^2 / |cos cos| (read by the rare specular-chain correction only) sits in
-// the vertex workspace, the two flag bits per vertex in a 64-bit register.
+// the vertex record, the two flag bits per vertex in a 64-bit register.
 #define BF_CONN 1u
 #define BF_DEGEN 2u
 
@@ -38,6 +51,8 @@ __host__ __device__ inline int bdpt_max_dim(int max_depth, int rr_depth) { // ps
     int d = (max_depth + 2) * (2 + (rr_depth < max_depth ? 1 : 0));
     return d + (d & 1);
 }
+// LDS floats of an evaluation beside the sampler rows: the two density row groups and the 64 segment heads of a connection round
+__host__ __device__ inline int bdpt_eval_lds_floats(int max_depth) { return (2 * (2 * max_depth + 1) + 1) * 64; }
 
 struct BdptResult {
     float lum;
@@ -48,30 +63,28 @@ struct BdptResult {
 
 struct BdptStore {
     float *verts;     // P.bd_verts
-    uint32_t n, chain, NVS;
-    DEV float &f(int field, int slot) const { return verts[((size_t) field * NVS + (uint32_t) slot) * n + chain]; }
-    DEV void put(int slot, const BVert &v, f3 thr) const {
-        f(BV_P, slot) = v.p.x; f(BV_P + 1, slot) = v.p.y; f(BV_P + 2, slot) = v.p.z;
-        f(BV_N, slot) = v.n.x; f(BV_N + 1, slot) = v.n.y; f(BV_N + 2, slot) = v.n.z;
-        f(BV_S, slot) = v.s.x; f(BV_S + 1, slot) = v.s.y; f(BV_S + 2, slot) = v.s.z;
-        f(BV_WI, slot) = v.wi.x; f(BV_WI + 1, slot) = v.wi.y; f(BV_WI + 2, slot) = v.wi.z;
-        f(BV_LEN2, slot) = v.e_len2; f(BV_COS, slot) = v.e_cos;
-        f(BV_THR, slot) = thr.x; f(BV_THR + 1, slot) = thr.y; f(BV_THR + 2, slot) = thr.z;
-        f(BV_IDS, slot) = __int_as_float(v.kind | (v.bsdf << 4));
-        f(BV_EMIT, slot) = __int_as_float(v.emitter);
-        f(BV_SHADE, slot) = __int_as_float(v.shade);
+    uint32_t NVS;
+    DEV float *rec(uint32_t chain, int slot) const { return verts + ((size_t) chain * NVS + (uint32_t) slot) * BR_FLOATS; }
+    DEV float f(uint32_t chain, int slot, int field) const { return rec(chain, slot)[field]; }
+    DEV f3 pos(uint32_t chain, int slot) const { const float *r = rec(chain, slot); return mk3(r[BR_P], r[BR_P + 1], r[BR_P + 2]); }
+    DEV f3 nrm(uint32_t chain, int slot) const { const float *r = rec(chain, slot); return mk3(r[BR_N], r[BR_N + 1], r[BR_N + 2]); }
+    DEV void put(uint32_t chain, int slot, const BVert &v, f3 thr, float ginv) const {
+        float4 *r = reinterpret_cast<float4 *>(rec(chain, slot));
+        r[0] = make_float4(v.p.x, v.p.y, v.p.z, v.n.x);
+        r[1] = make_float4(v.n.y, v.n.z, v.s.x, v.s.y);
+        r[2] = make_float4(v.s.z, v.wi.x, v.wi.y, v.wi.z);
+        r[3] = make_float4(v.e_len2, v.e_cos, ginv, __int_as_float(v.kind | (v.bsdf << 4) | ((v.emitter + 1) << 16)));
+        r[4] = make_float4(thr.x, thr.y, thr.z, __int_as_float(v.shade));
     }
-    DEV void get(int slot, BVert &v, f3 &thr) const {
-        v.p = mk3(f(BV_P, slot), f(BV_P + 1, slot), f(BV_P + 2, slot));
-        v.n = mk3(f(BV_N, slot), f(BV_N + 1, slot), f(BV_N + 2, slot));
-        v.s = mk3(f(BV_S, slot), f(BV_S + 1, slot), f(BV_S + 2, slot));
-        v.wi = mk3(f(BV_WI, slot), f(BV_WI + 1, slot), f(BV_WI + 2, slot));
-        v.e_len2 = f(BV_LEN2, slot); v.e_cos = f(BV_COS, slot);
-        thr = mk3(f(BV_THR, slot), f(BV_THR + 1, slot), f(BV_THR + 2, slot));
-        const int ids = __float_as_int(f(BV_IDS, slot));
-        v.kind = ids & 15; v.bsdf = ids >> 4;
-        v.emitter = __float_as_int(f(BV_EMIT, slot));
-        v.shade = __float_as_int(f(BV_SHADE, slot));
+    DEV void get(uint32_t chain, int slot, BVert &v, f3 &thr) const {
+        const float4 *r = reinterpret_cast<const float4 *>(rec(chain, slot));
+        const float4 a = r[0], b = r[1], c = r[2], d = r[3], e = r[4];
+        v.p = mk3(a.x, a.y, a.z); v.n = mk3(a.w, b.x, b.y); v.s = mk3(b.z, b.w, c.x); v.wi = mk3(c.y, c.z, c.w);
+        v.e_len2 = d.x; v.e_cos = d.y;
+        const int ids = __float_as_int(d.w);
+        v.kind = ids & 15; v.bsdf = (ids >> 4) & 4095; v.emitter = (int) ((uint32_t) ids >> 16) - 1;
+        thr = mk3(e.x, e.y, e.z);
+        v.shade = __float_as_int(e.w);
     }
 };
 
@@ -98,31 +111,44 @@ DEV float emitter_direct_pdf_area(const TablesT &T, f3 ref_p, f3 ref_n, bool ref
     return pdf * (E.cdf_hi - E.cdf_lo);
 }
 
-// `list`: this lane's column of the target splat list (row r at list[r * n])
-// FEAT: as for trace() -- 15 with BVH traversal (and its 6 KB LDS stack), 7 without
+// One evaluation per lane whose `active` is set; EVERY lane of the wave must make the call (the connection phase hands the cells
+// of all chains out to all lanes). `chain`: workspace column; `list`: this lane's column of the target splat list (row r at
+// list[r * n]). FEAT: as for trace() -- 15 with BVH traversal (and its 6 KB LDS stack), 7 without.
+DEV unsigned long long shfl_u64(unsigned long long v, uint32_t src) {
+    const uint32_t lo = (uint32_t) __shfl((int) (uint32_t) v, (int) src, 64), hi = (uint32_t) __shfl((int) (uint32_t) (v >> 32), (int) src, 64);
+    return ((unsigned long long) hi << 32) | lo;
+}
+// cells of row s of a chain whose sensor subpath has nS vertices: t = maxT .. maxT - count + 1 (pathsampler.cpp:373-380;
+// t = 0 needs a sensor that can be hit: a pinhole cannot, vertex.cpp:1405-1413)
+DEV int bdpt_row_cells(const DParams &P, int s, int nS, int &maxT) {
+    int minT = max(2 - s, P.light_image ? 0 : 2);
+    if (minT < 1) minT = 1;
+    maxT = min(min(P.max_depth + 1, P.max_depth + 1 - s), nS - 1);
+    return max(0, maxT - minT + 1);
+}
+
 template <int FEAT = 15, class TablesT>
-DEV void eval_bdpt(const DParams &P, const TablesT &T, MSampler &smp, uint32_t chain, uint32_t mis_row, float *list, BdptResult &R) {
+DEV void eval_bdpt(const DParams &P, const TablesT &T, MSampler &smp, bool active, uint32_t chain, uint32_t mis_row, float *list, BdptResult &R) {
     const uint32_t lane = smp.lane, n = P.n_chains_alloc;
     const int ME = P.max_depth, MS = P.max_depth + 1;
     const uint32_t NVS = (uint32_t) (ME + MS);
-    const BdptStore W{P.bd_verts, n, chain, NVS};
+    const BdptStore W{P.bd_verts, NVS};
     auto mis = [&](int group, int slot) -> float & { return lds_x[(mis_row + (uint32_t) group * NVS + (uint32_t) slot) * 64u + lane]; };
     auto lrow = [&](int r) -> float & { return list[(size_t) r * n]; };
     static_assert(2 * (2 * BDPT_MAX_DEPTH + 1) <= 64, "two flag bits per vertex slot in one 64-bit register");
     unsigned long long flagbits = 0ull; // two bits per vertex slot: BF_CONN, BF_DEGEN (drmlt_create refuses maxDepth > BDPT_MAX_DEPTH)
     auto set_flags = [&](int slot, unsigned v) { flagbits = (flagbits & ~(3ull << (2 * slot))) | ((unsigned long long) v << (2 * slot)); };
-    auto flags = [&](int slot) -> unsigned { return (unsigned) (flagbits >> (2 * slot)) & 3u; };
 
     R.lum = 0.f; R.nrays = 0u; R.n_sensor = R.n_emitter = R.n_direct = 0u; R.n_more = 0; R.has_main = false;
     smp.reset_caches();
-    const bool stamps = (P.debug & 128) != 0; // diagnostic: per-wave cycles of the walks / the pair loop -> stats[16], [17]
+    const bool stamps = (P.debug & 128) != 0; // diagnostic: per-wave cycles of the walks / the connections -> stats[16], [17]
     const unsigned long long st0 = stamps ? __builtin_amdgcn_s_memtime() : 0ull;
 
     // ------------------------------------------------------------ the two random walks (emitter first, :331-340)
     int nE = 1, nS = 1;            // vertices of each subpath, supernode included
     float em0_fwd = 0.f;           // density of the emitter sample (area x emitter choice)
     float film_x = 0.f, film_y = 0.f;
-    {
+    if (active) {
         BVert cur;
         cur.kind = BK_SUPER_E; cur.p = cur.n = cur.s = cur.wi = mk3(0.f, 0.f, 0.f);
         cur.e_len2 = cur.e_cos = 0.f; cur.bsdf = 0; cur.emitter = -1; cur.shade = 0; cur.degenerate = false;
@@ -149,8 +175,8 @@ DEV void eval_bdpt(const DParams &P, const TablesT &T, MSampler &smp, uint32_t c
             if (cur.kind == BK_SUPER_S) {
                 cur.kind = BK_END_S; cur.p = cam_pos(P); cur.n = cam_dir(P); cur.degenerate = false; cur.e_len2 = 0.f; cur.e_cos = 0.f;
                 cur.s = cur.wi = mk3(0.f, 0.f, 0.f);
-                W.put(base, cur, thr);
-                W.f(BV_GINV, base) = 0.f; set_flags(base, 0u);
+                W.put(chain, base, cur, thr, 0.f);
+                set_flags(base, 0u);
                 nS = 2;
                 continue;
             }
@@ -175,8 +201,8 @@ DEV void eval_bdpt(const DParams &P, const TablesT &T, MSampler &smp, uint32_t c
                 const bool sph = (L.bsdf >> 24) == PRIM_SPHERE;
                 cur.kind = BK_END_E; cur.n = sph ? lp : ld3(L.n); cur.p = sph ? fma3(lp, L.eu[0], ld3(L.origin)) : lp; cur.emitter = ei; cur.shade = E.prim; cur.degenerate = false;
                 cur.e_len2 = 0.f; cur.e_cos = 0.f; cur.s = cur.wi = mk3(0.f, 0.f, 0.f);
-                W.put(base, cur, thr);
-                W.f(BV_GINV, base) = 0.f; set_flags(base, 0u);
+                W.put(chain, base, cur, thr, 0.f);
+                set_flags(base, 0u);
                 nE = 2;
                 continue;
             }
@@ -290,8 +316,7 @@ DEV void eval_bdpt(const DParams &P, const TablesT &T, MSampler &smp, uint32_t c
             nv.wi = to_local(nv, -d);
             nv.e_len2 = len2;
             nv.e_cos = cosCur;
-            W.put(base + i, nv, thr);                            // vertex i + 1
-            W.f(BV_GINV, base + i) = len2 / (cosNew * cosCur);   // edge (i, i + 1), kept with vertex i + 1
+            W.put(chain, base + i, nv, thr, len2 / (cosNew * cosCur)); // vertex i + 1, with the factor of edge (i, i + 1)
             set_flags(base + i, nv.degenerate ? BF_DEGEN : 0u);
             if (emitter) nE = i + 2; else nS = i + 2;
             cur = nv;
@@ -301,127 +326,183 @@ DEV void eval_bdpt(const DParams &P, const TablesT &T, MSampler &smp, uint32_t c
 
     const unsigned long long st1 = stamps ? __builtin_amdgcn_s_memtime() : 0ull;
     // ------------------------------------------------------------ the splat list
+    R.has_main = nS > 2; // "if (m_sensorSubpath.vertexCount() > 2)", :357-361
+    const bool direct = P.bd_Dd != 0;
+    auto refn_zero = [&](uint32_t ch, int slot) { return T.bsdf((__float_as_int(W.f(ch, slot, BR_IDS)) >> 4) & 4095).type == 1; }; // records.inl:160-164
+    float re_walk = 0.f;     // ratioEmitterDirect of the emitter walk's own vertices 1 and 2 (every s >= 2 strategy)
+    if (active && direct && nE >= 3)
+        re_walk = emitter_direct_pdf_area(T, W.pos(chain, 1), W.nrm(chain, 1), refn_zero(chain, 1), W.pos(chain, 0), W.nrm(chain, 0),
+                                          (int) ((uint32_t) __float_as_int(W.f(chain, 0, BR_IDS)) >> 16) - 1) / em0_fwd;
+    uint32_t cells = 0u;     // the (s, t) pairs this chain's subpaths reach
+    if (active)
+        for (int s = 0; s <= nE - 1; ++s) { int mt; cells += (uint32_t) bdpt_row_cells(P, s, nS, mt); }
     float total_lum = 0.f;
     f3 main_v = mk3(0.f, 0.f, 0.f);
-    R.has_main = nS > 2; // "if (m_sensorSubpath.vertexCount() > 2)", :357-361
     int n_more = 0;
+    uint32_t kd_total = 0u;  // components of the direct sampler consumed
+    int *const head = reinterpret_cast<int *>(&lds_x[(mis_row + 2u * NVS) * 64u]);
+    const unsigned long long lanes_below = (1ull << lane) - 1ull;
 
-    auto vpos = [&](int slot) { return mk3(W.f(BV_P, slot), W.f(BV_P + 1, slot), W.f(BV_P + 2, slot)); };
-    auto vnrm = [&](int slot) { return mk3(W.f(BV_N, slot), W.f(BV_N + 1, slot), W.f(BV_N + 2, slot)); };
-    auto vrefn_zero = [&](int slot) { return T.bsdf(__float_as_int(W.f(BV_IDS, slot)) >> 4).type == 1; }; // records.inl:160-164
-    const bool direct = P.bd_Dd != 0;
-    uint32_t kd = 0u;        // components of the direct sampler consumed so far
-    float re_walk = 0.f;     // ratioEmitterDirect of the emitter walk's own vertices 1 and 2 (every s >= 2 strategy)
-    if (direct && nE >= 3)
-        re_walk = emitter_direct_pdf_area(T, vpos(1), vnrm(1), vrefn_zero(1), vpos(0), vnrm(0), __float_as_int(W.f(BV_EMIT, 0))) / em0_fwd;
-    float em0 = em0_fwd;     // pImp[1]; the s = 1 direct strategy swaps in its own emitter sample
-    // Canonical order: the wave walks ONE (s, t) grid, every lane taking the cells its own subpaths reach. For each chain
-    // that is the reference's order (s and t descending, :373-380), so the direct sampler's components and the light-image
-    // splats come out in the same sequence -- but s, t and k are wave-uniform: one strategy branch per iteration, uniform
-    // trip counts in the two sweeps of miWeight, scalar slot arithmetic. (Per-lane loops over each chain's own range ran
-    // the same number of iterations, the longest chain's, with every branch populated in most of them.)
-#pragma nounroll
-    for (int s = ME; s >= 0; --s) {
-        const bool has_s = s <= nE - 1;
-        if (!__builtin_amdgcn_ballot_w64(has_s)) continue;
-        BVert vs;
-        f3 thr_s = mk3(1.f, 1.f, 1.f);
-        vs.p = vs.n = vs.s = vs.wi = mk3(0.f, 0.f, 0.f); vs.e_len2 = vs.e_cos = 0.f; vs.kind = BK_SURF; vs.bsdf = 0; vs.emitter = -1; vs.shade = 0;
-        if (s >= 1 && has_s) W.get(s - 1, vs, thr_s);
-        vs.degenerate = (s >= 1 && has_s) ? (flags(s - 1) & BF_DEGEN) != 0u : false;
-        int minT = max(2 - s, P.light_image ? 0 : 2);
-        const int maxT = min(MS, P.max_depth + 1 - s);
-        if (minT < 1) minT = 1; // t = 0 needs a sensor that can be hit: a pinhole cannot (vertex.cpp:1405-1413)
-#pragma nounroll
-        for (int t = maxT; t >= minT; --t) {
-            if (!has_s || t > nS - 1) continue;
-            BVert vt;
-            f3 thr_t;
-            W.get(ME + t - 1, vt, thr_t);
+    // Rounds: chains c0 .. c1 - 1 are the next whole chains whose cells fit the 64 lanes; cell i of the round goes to lane i.
+    // (Only beyond maxDepth 9 can one chain have more than 64 cells: it then gets rounds of its own, 64 of its cells at a time, and
+    // joins the others with what is left -- the order of its sums still depends on its own cell count alone.)
+    uint32_t done = 0u;      // cells of this chain that earlier rounds have dealt with
+    for (uint32_t c0 = 0u; c0 < 64u;) {
+        const uint32_t rem = lane >= c0 ? cells - done : 0u;
+        uint32_t pre = rem; // inclusive prefix sum over the lanes
+#pragma unroll
+        for (uint32_t d = 1u; d < 64u; d <<= 1) {
+            const uint32_t v = (uint32_t) __shfl_up((int) pre, d, 64);
+            if (lane >= d) pre += v;
+        }
+        const uint32_t nfit = (uint32_t) __popcll(__ballot(lane >= c0 && pre <= 64u));
+        const uint32_t c1 = c0 + nfit;
+        const bool alone = nfit == 0u; // chain c0 by itself, 64 of its cells
+        const uint32_t total = alone ? 64u : (uint32_t) __shfl((int) pre, (int) ((c1 - 1u) & 63u), 64);
+        const uint32_t cnt = alone ? (lane == c0 ? 64u : 0u) : (lane < c1 ? rem : 0u);
+        const bool owner = cnt != 0u; // this lane's chain is in the round
+        const uint32_t start = alone ? 0u : pre - rem;
+        const uint32_t progress = done | ((uint32_t) n_more << 8) | (kd_total << 16); // what the chain's cells continue from
+        if (owner) done += cnt;
+        c0 = c1;
+        if (total == 0u) continue;
+
+        // ---- lane -> cell: segment heads through LDS, the chain's data by cross-lane reads
+        __builtin_amdgcn_wave_barrier();
+        head[lane] = 0;
+        __builtin_amdgcn_wave_barrier();
+        if (owner) head[start] = (int) lane + 1;
+        __builtin_amdgcn_wave_barrier();
+        const unsigned long long H = __ballot(head[lane] != 0);
+        const unsigned long long upto = ~0ull >> (63u - lane); // bits 0 .. lane
+        const uint32_t hp = 63u - (uint32_t) __builtin_clzll((H & upto) | 1ull);
+        const unsigned long long above = H & ~upto;
+        const uint32_t seg_end = above ? (uint32_t) __builtin_ctzll(above) : total;
+        const unsigned long long segmask = (seg_end >= 64u ? ~0ull : ((1ull << seg_end) - 1ull)) & ~((1ull << hp) - 1ull);
+        const bool mine = lane < total;
+        const uint32_t c = (uint32_t) max(head[hp] - 1, 0); // the lane of the chain this cell belongs to
+        const uint32_t jj = lane - hp;                      // index of the cell within its chain
+        const uint32_t wc = (uint32_t) __shfl((int) chain, (int) c, 64);
+        const uint32_t nEnS = (uint32_t) __shfl((int) ((uint32_t) nE | ((uint32_t) nS << 8)), (int) c, 64);
+        const int nEc = (int) (nEnS & 255u), nSc = (int) (nEnS >> 8);
+        const unsigned long long fb = shfl_u64(flagbits, c);
+        const float em0_c = __shfl(em0_fwd, (int) c, 64), re_walk_c = __shfl(re_walk, (int) c, 64);
+        float *const list_c = reinterpret_cast<float *>(shfl_u64((unsigned long long) list, c));
+        // the chain's direct sampler, as far as a draw of it needs
+        const uint32_t s_chain = (uint32_t) __shfl((int) smp.chain, (int) c, 64), s_major = (uint32_t) __shfl((int) smp.major, (int) c, 64);
+        const int s_mode = __shfl(smp.mode | (smp.large ? 256 : 0), (int) c, 64);
+        const float *const s_arr = reinterpret_cast<const float *>(shfl_u64((unsigned long long) smp.arr, c));
+        const float *const s_xdir = reinterpret_cast<const float *>(shfl_u64((unsigned long long) smp.x_dir, c));
+        const uint32_t s_boot = (uint32_t) __shfl((int) (R.n_emitter + R.n_sensor), (int) c, 64);
+        const uint32_t prog_c = (uint32_t) __shfl((int) progress, (int) c, 64);
+        auto flags = [&](int slot) -> unsigned { return (unsigned) (fb >> (2 * slot)) & 3u; };
+        auto misc = [&](int group, int slot) -> float { return lds_x[(mis_row + (uint32_t) group * NVS + (uint32_t) slot) * 64u + c]; };
+
+        int s = 0, t = 0;
+        {
+            int j = (int) (jj + (prog_c & 255u));
+            for (int ss = nEc - 1; ss >= 0; --ss) {
+                int mt;
+                const int rc = bdpt_row_cells(P, ss, nSc, mt);
+                if (j < rc) { s = ss; t = mt - j; break; }
+                j -= rc;
+            }
+        }
+        // components of the direct sampler: two per s = 1, t > 1 connection and per t = 1, s > 1 connection whose vertex can be
+        // connected, in cell order (:424-452)
+        const bool consumes = mine && direct && ((s == 1 && t > 1 && !(flags(ME + t - 1) & BF_DEGEN)) || (t == 1 && s > 1 && !(flags(s - 1) & BF_DEGEN)));
+        const unsigned long long CB = __ballot(consumes);
+        const uint32_t kd = (prog_c >> 16) + 2u * (uint32_t) __popcll(CB & segmask & lanes_below);
+
+        f3 value = mk3(0.f, 0.f, 0.f);
+        float light_x = 0.f, light_y = 0.f;
+        bool produced = false, traced = false;
+        if (mine) do {
+            BVert vs, vt;
+            f3 thr_s = mk3(1.f, 1.f, 1.f), thr_t;
+            vs.p = vs.n = vs.s = vs.wi = mk3(0.f, 0.f, 0.f); vs.e_len2 = vs.e_cos = 0.f; vs.kind = BK_SURF; vs.bsdf = 0; vs.emitter = -1; vs.shade = 0;
+            vs.degenerate = false;
+            if (s >= 1) { W.get(wc, s - 1, vs, thr_s); vs.degenerate = (flags(s - 1) & BF_DEGEN) != 0u; }
+            W.get(wc, ME + t - 1, vt, thr_t);
             vt.degenerate = (flags(ME + t - 1) & BF_DEGEN) != 0u;
             const int k = s + t + 1, depth = s + t - 1;
-            f3 value;
             float geo = 1.f;
             float pc_i1, pc_i2, pc_r0 = 0.f, pc_r1 = 0.f;
             float re_s1 = 0.f;
-            em0 = em0_fwd;
+            float em0 = em0_c;   // pImp[1]; the s = 1 direct strategy swaps in its own emitter sample
             if (s == 0) {
-                if (vt.kind != BK_SURF || vt.emitter < 0) continue;
+                if (vt.kind != BK_SURF || vt.emitter < 0) break;
                 const DEmitter E = T.emitter(vt.emitter);
                 const f3 wo = to_world(vt, vt.wi);
                 const float dp = dot3(wo, vt.n);
                 float r = dp < 0.f ? 0.f : INV_PI_F * dp;
                 if (dp != 0.f) r /= fabsf(dp);
                 value = thr_t * (ld3(E.radiance) * (PI_F * r));
-                if (is_zero3(value)) continue;
+                if (is_zero3(value)) break;
                 pc_i1 = T.shade(vt.shade).inv_area * (E.cdf_hi - E.cdf_lo);
                 pc_i2 = (dp < 0.f ? 0.f : INV_PI_F * dp) * vt.e_cos / vt.e_len2;
             } else {
-                if (direct && s == 1) {
+                if (direct && s == 1 && t > 1) {
                     // s = 1, t > 1: the emitter vertex is drawn by direct sampling from vt (:424-437, vertex.cpp:1285-1346,
                     // scene.cpp:879-904 without the visibility test) and replaces the walk's vertex 1, in miWeight too
                     // (:486-503). It goes through the connection code below as a vertex `vs` whose weight makes that code's
-                    // value radiance / (pdf_direct) * f * cos -- lanes at s = 1 and lanes at other s share one code path.
-                    if (t == 1) { W.get(0, vs, thr_s); vs.degenerate = false; }
-                    else {
-                        if (vt.degenerate) continue;
-                        smp.select(SEG_DIRECT);
-                        float sx = smp.next(kd);
-                        const float sy = smp.next(kd + 1u);
-                        kd += 2u;
-                        int ei = 0;
-                        for (int q = 1; q < P.n_emitters; ++q)
-                            if (T.emitter_cdf_lo(q) < sx) ei = q;
-                        const DEmitter E = T.emitter(ei);
-                        const float emPdf = E.cdf_hi - E.cdf_lo;
-                        sx = (sx - E.cdf_lo) / emPdf;
-                        const DShade L = T.shade(E.prim);
-                        f3 ln = ld3(L.n), dd;
-                        float dist, pdf;
-                        if ((L.bsdf >> 24) == PRIM_SPHERE) {
-                            sphere_sample_direct(ld3(L.origin), L.eu[0], L.inv_area, vt.p, sx, sy, dd, dist, ln, pdf);
-                            vs.p = fma3(dd, dist, vt.p);
-                        } else {
-                            if ((L.bsdf >> 24) == PRIM_RECTANGLE) vs.p = fma3(ld3(L.eu), sx, fma3(ld3(L.ev), sy, ld3(L.origin)));
-                            else { const float a = sqrtf(fmaxf(0.f, 1.f - sx)); vs.p = fma3(ld3(L.eu), 1.f - a, fma3(ld3(L.ev), a * sy, ld3(L.origin))); }
-                            const f3 dv = vs.p - vt.p;
-                            const float dist2 = dot3(dv, dv);
-                            dist = sqrtf(dist2);
-                            dd = dv * (1.f / dist);
-                            const float c = dot3(dd, ln);
-                            pdf = c != 0.f ? L.inv_area * dist2 / fabsf(c) : 0.f;
-                        }
-                        const float dln = dot3(dd, ln);
-                        const float dr = T.bsdf(vt.bsdf).type == 1 ? 0.f : dot3(dd, vt.n);
-                        if (!(dr >= 0.f && dln < 0.f && pdf != 0.f)) continue; // AreaLight::sampleDirect, area.cpp:164-178
-                        if (!(dist > 0.f)) continue;
-                        vs.kind = BK_END_E; vs.n = ln; vs.s = vs.wi = mk3(0.f, 0.f, 0.f); vs.e_len2 = vs.e_cos = 0.f;
-                        vs.bsdf = 0; vs.emitter = ei; vs.shade = E.prim; vs.degenerate = false;
-                        // the connection computes thr_s * (1 / pi) * f * cos_s cos_t / len^2: make that radiance / pdf * f * cos_t
-                        thr_s = ld3(E.radiance) * (PI_F * dist * dist / (pdf * emPdf * fabsf(dln)));
-                        em0 = L.inv_area * emPdf;
+                    // value radiance / (pdf_direct) * f * cos -- cells at s = 1 and cells at other s share one code path.
+                    if (vt.degenerate) break;
+                    MSampler sc = smp; // the chain's sampler as far as a draw of its direct segment needs it
+                    sc.chain = s_chain; sc.major = s_major; sc.mode = s_mode & 255; sc.large = (s_mode & 256) != 0; sc.arr = s_arr; sc.x_dir = s_xdir;
+                    sc.lane = c;
+                    sc.reset_caches();
+                    sc.select(SEG_DIRECT);
+                    sc.boot_k = s_boot + kd; // a replayed stream: emitter walk, sensor walk, then the direct components in cell order
+                    float sx = sc.next(kd);
+                    const float sy = sc.next(kd + 1u);
+                    int ei = 0;
+                    for (int q = 1; q < P.n_emitters; ++q)
+                        if (T.emitter_cdf_lo(q) < sx) ei = q;
+                    const DEmitter E = T.emitter(ei);
+                    const float emPdf = E.cdf_hi - E.cdf_lo;
+                    sx = (sx - E.cdf_lo) / emPdf;
+                    const DShade L = T.shade(E.prim);
+                    f3 ln = ld3(L.n), dd;
+                    float dist, pdf;
+                    if ((L.bsdf >> 24) == PRIM_SPHERE) {
+                        sphere_sample_direct(ld3(L.origin), L.eu[0], L.inv_area, vt.p, sx, sy, dd, dist, ln, pdf);
+                        vs.p = fma3(dd, dist, vt.p);
+                    } else {
+                        if ((L.bsdf >> 24) == PRIM_RECTANGLE) vs.p = fma3(ld3(L.eu), sx, fma3(ld3(L.ev), sy, ld3(L.origin)));
+                        else { const float a = sqrtf(fmaxf(0.f, 1.f - sx)); vs.p = fma3(ld3(L.eu), 1.f - a, fma3(ld3(L.ev), a * sy, ld3(L.origin))); }
+                        const f3 dv = vs.p - vt.p;
+                        const float dist2 = dot3(dv, dv);
+                        dist = sqrtf(dist2);
+                        dd = dv * (1.f / dist);
+                        const float cc = dot3(dd, ln);
+                        pdf = cc != 0.f ? L.inv_area * dist2 / fabsf(cc) : 0.f;
                     }
+                    const float dln = dot3(dd, ln);
+                    const float dr = T.bsdf(vt.bsdf).type == 1 ? 0.f : dot3(dd, vt.n);
+                    if (!(dr >= 0.f && dln < 0.f && pdf != 0.f)) break; // AreaLight::sampleDirect, area.cpp:164-178
+                    if (!(dist > 0.f)) break;
+                    vs.kind = BK_END_E; vs.n = ln; vs.s = vs.wi = mk3(0.f, 0.f, 0.f); vs.e_len2 = vs.e_cos = 0.f;
+                    vs.bsdf = 0; vs.emitter = ei; vs.shade = E.prim; vs.degenerate = false;
+                    // the connection computes thr_s * (1 / pi) * f * cos_s cos_t / len^2: make that radiance / pdf * f * cos_t
+                    thr_s = ld3(E.radiance) * (PI_F * dist * dist / (pdf * emPdf * fabsf(dln)));
+                    em0 = L.inv_area * emPdf;
                 }
                 // t = 1 with direct sampling: a pinhole's sampleDirect returns the point the sensor subpath's vertex 1 already is
                 // (perspective.cpp:386-420) and the same value term by term; what remains is that it consumes two components
-                // (only a replayed stream has a position to advance: the chain samplers are functions of the index)
-                if (direct && t == 1 && s > 1) {
-                    if (vs.degenerate) continue;
-                    if (smp.mode == SM_BOOT) { smp.select(SEG_DIRECT); (void) smp.next(kd); (void) smp.next(kd + 1u); }
-                    kd += 2u;
-                }
-                if (vs.degenerate || vt.degenerate) continue;
+                // (counted in `consumes` above)
+                if (vs.degenerate || vt.degenerate) break;
                 f3 dc = vt.p - vs.p;
                 const float len2 = dot3(dc, dc);
                 const float len = sqrtf(len2);
-                if (len == 0.f) continue;
+                if (len == 0.f) break;
                 dc = dc * (1.f / len);
                 const DBsdf Bs = T.bsdf(vs.bsdf), Bt = T.bsdf(vt.bsdf);
                 value = thr_s * thr_t * vert_eval(P, Bs, vs, dc, true) * vert_eval(P, Bt, vt, -dc, false);
-                if (is_zero3(value)) continue;
+                if (is_zero3(value)) break;
                 const Hit h = trace<FEAT>(P, vt.p, -dc, ray_eps_closest(vt.p), len * (1.f - SHADOW_EPSILON_F), true);
-                R.nrays++;
-                if (h.prim >= 0) continue;
+                traced = true;
+                if (h.prim >= 0) { value = mk3(0.f, 0.f, 0.f); break; }
                 const float cs = fabsf(dot3(vs.n, dc)), ct = fabsf(dot3(vt.n, dc));
                 geo = cs * ct / len2;
                 const f3 wos = to_local(vs, dc), wot = to_local(vt, -dc);
@@ -433,7 +514,7 @@ DEV void eval_bdpt(const DParams &P, const TablesT &T, MSampler &smp, uint32_t c
                 else pc_r1 = bsdf_pdf_sa(Bs, wos, vs.wi) * ((wos.z == 0.f || vs.wi.z == 0.f) ? 0.f : 1.f) * vs.e_cos / vs.e_len2;
                 if (direct && s == 1 && t > 1) re_s1 = emitter_direct_pdf_area(T, vt.p, vt.n, Bt.type == 1, vs.p, vs.n, vs.emitter) / em0;
             }
-            if (P.exclude_direct && depth <= 2) continue;
+            if (P.exclude_direct && depth <= 2) { value = mk3(0.f, 0.f, 0.f); break; }
 
             // ---- Path::miWeight over positions 0..k (emitter vertex j at j, sensor vertex j at k - j)
             auto conn = [&](int j) -> bool {
@@ -441,14 +522,14 @@ DEV void eval_bdpt(const DParams &P, const TablesT &T, MSampler &smp, uint32_t c
                 if (j >= k) return false;
                 return (flags(j < s ? j - 1 : ME + (k - j) - 1) & BF_CONN) != 0u;
             };
-            auto ginv = [&](int e) -> float { return e < s ? W.f(BV_GINV, e) : W.f(BV_GINV, ME + (k - e) - 1); }; // edge (e, e + 1)
+            auto ginv = [&](int e) -> float { return e < s ? W.f(wc, e, BR_GINV) : W.f(wc, ME + (k - e) - 1, BR_GINV); }; // edge (e, e + 1)
             auto pImp = [&](int j) -> float {
                 float v;
                 if (j == 0) v = 1.f;
-                else if (j <= s) v = j == 1 ? em0 : mis(MF_FWD, j - 2);
+                else if (j <= s) v = j == 1 ? em0 : misc(MF_FWD, j - 2);
                 else if (j == s + 1) v = pc_i1;
                 else if (j == s + 2) v = pc_i2;
-                else v = mis(MF_REV, ME + (k - j + 1) - 1);
+                else v = misc(MF_REV, ME + (k - j + 1) - 1);
                 const int i = j - 1; // area -> projected solid angle next to a specular vertex (path.cpp:868-882)
                 if (i >= 1 && i <= k - 3 && i != s && conn(i) && !conn(i + 1)) v *= ginv(i);
                 return v;
@@ -456,10 +537,10 @@ DEV void eval_bdpt(const DParams &P, const TablesT &T, MSampler &smp, uint32_t c
             auto pRad = [&](int j) -> float {
                 float v;
                 if (j == k) v = 1.f;
-                else if (j >= s + 1) { const int a = k - j - 1; v = a == 0 ? 1.f : mis(MF_FWD, ME + a - 1); }
+                else if (j >= s + 1) { const int a = k - j - 1; v = a == 0 ? 1.f : misc(MF_FWD, ME + a - 1); }
                 else if (j == s) v = pc_r0;
                 else if (j == s - 1) v = pc_r1;
-                else v = mis(MF_REV, j);                       // emitter vertex j + 1, slot j
+                else v = misc(MF_REV, j);                      // emitter vertex j + 1, slot j
                 const int i = j + 1; // (path.cpp:884-898)
                 if (i <= k - 1 && i >= 3 && j != s && conn(i) && !conn(j)) v *= ginv(j);
                 return v;
@@ -471,8 +552,8 @@ DEV void eval_bdpt(const DParams &P, const TablesT &T, MSampler &smp, uint32_t c
             double initial = 1.0;
             if (sd) {
                 if (s == 1) { re = re_s1; initial = 1.0 / (double) re; }
-                else if (s == 0) { if (conn(2)) re = emitter_direct_pdf_area(T, vpos(ME + t - 2), vnrm(ME + t - 2), vrefn_zero(ME + t - 2), vt.p, vt.n, vt.emitter) / pc_i1; }
-                else if (conn(2)) re = re_walk;
+                else if (s == 0) { if (conn(2)) re = emitter_direct_pdf_area(T, W.pos(wc, ME + t - 2), W.nrm(wc, ME + t - 2), refn_zero(wc, ME + t - 2), vt.p, vt.n, vt.emitter) / pc_i1; }
+                else if (conn(2)) re = re_walk_c;
             }
             double weight = 1.0, pdf = initial;
             for (int i = s + 1; i < k; ++i) {
@@ -489,19 +570,36 @@ DEV void eval_bdpt(const DParams &P, const TablesT &T, MSampler &smp, uint32_t c
                 pdf = next;
             }
             value = value * (geo / (float) weight);
+            if (t == 1 && !cam_sample_position(P, vs.p - vt.p, light_x, light_y)) { value = mk3(0.f, 0.f, 0.f); break; } // light image: its own splat (:514-516)
+            produced = true;
+        } while (0);
+        if (!produced) value = mk3(0.f, 0.f, 0.f);
 
-            if (t == 1) { // light image: its own splat (:514-516)
-                float sx, sy;
-                if (!cam_sample_position(P, vs.p - vt.p, sx, sy)) continue;
-                if (n_more < P.max_depth) {
-                    const int r0 = BL_MORE + 5 * n_more;
-                    lrow(r0) = sx; lrow(r0 + 1) = sy; lrow(r0 + 2) = value.x; lrow(r0 + 3) = value.y; lrow(r0 + 4) = value.z;
-                    ++n_more;
-                }
-            } else {
-                main_v = main_v + value;
+        // ---- a chain's results: light-image splats numbered in cell order, everything else summed over its segment
+        const bool is_light = produced && t == 1;
+        const unsigned long long LB = __ballot(is_light), TB = __ballot(traced);
+        if (is_light) {
+            const int idx = (int) ((prog_c >> 8) & 255u) + (int) __popcll(LB & segmask & lanes_below);
+            if (idx < P.max_depth) {
+                float *l = list_c + (size_t) (BL_MORE + 5 * idx) * n;
+                l[0] = light_x; l[n] = light_y; l[2 * (size_t) n] = value.x; l[3 * (size_t) n] = value.y; l[4 * (size_t) n] = value.z;
             }
-            total_lum += luminance3(value);
+        }
+        float sv0 = is_light ? 0.f : value.x, sv1 = is_light ? 0.f : value.y, sv2 = is_light ? 0.f : value.z, sv3 = luminance3(value);
+#pragma unroll
+        for (uint32_t d = 1u; d < 64u; d <<= 1) { // (a chain has at most 45 cells; the tree of a segment's last element depends on its length alone)
+            const float u0 = __shfl_up(sv0, d, 64), u1 = __shfl_up(sv1, d, 64), u2 = __shfl_up(sv2, d, 64), u3 = __shfl_up(sv3, d, 64);
+            if (jj >= d) { sv0 += u0; sv1 += u1; sv2 += u2; sv3 += u3; }
+        }
+        const int last = (int) ((start + cnt - 1u) & 63u);
+        const float t0 = __shfl(sv0, last, 64), t1 = __shfl(sv1, last, 64), t2 = __shfl(sv2, last, 64), t3 = __shfl(sv3, last, 64);
+        if (owner) {
+            const unsigned long long my = (start + cnt >= 64u ? ~0ull : ((1ull << (start + cnt)) - 1ull)) & ~((1ull << start) - 1ull);
+            main_v = main_v + mk3(t0, t1, t2);
+            total_lum += t3;
+            n_more = min(n_more + (int) __popcll(LB & my), P.max_depth);
+            R.nrays += (uint32_t) __popcll(TB & my);
+            kd_total += 2u * (uint32_t) __popcll(CB & my);
         }
     }
     if (stamps) {
@@ -510,11 +608,13 @@ DEV void eval_bdpt(const DParams &P, const TablesT &T, MSampler &smp, uint32_t c
             atomicAdd(P.stats + 16, st1 - st0); atomicAdd(P.stats + 17, st2 - st1); atomicAdd(P.stats + 19, 1ull);
         }
     }
-    lrow(BL_LUM) = total_lum;
-    lrow(BL_META) = __int_as_float((R.has_main ? 1 : 0) | (n_more << 1));
-    lrow(BL_MAIN) = R.has_main ? film_x : 0.f; lrow(BL_MAIN + 1) = R.has_main ? film_y : 0.f;
-    lrow(BL_MAIN + 2) = main_v.x; lrow(BL_MAIN + 3) = main_v.y; lrow(BL_MAIN + 4) = main_v.z;
+    if (active) {
+        lrow(BL_LUM) = total_lum;
+        lrow(BL_META) = __int_as_float((R.has_main ? 1 : 0) | (n_more << 1));
+        lrow(BL_MAIN) = R.has_main ? film_x : 0.f; lrow(BL_MAIN + 1) = R.has_main ? film_y : 0.f;
+        lrow(BL_MAIN + 2) = main_v.x; lrow(BL_MAIN + 3) = main_v.y; lrow(BL_MAIN + 4) = main_v.z;
+    }
     R.lum = total_lum;
     R.n_more = n_more;
-    R.n_direct = kd;
+    R.n_direct = kd_total;
 }

@@ -321,6 +321,8 @@ drmlt_ctx *drmlt_create(const drmlt_config *cfg, const drmlt_scene *scene, int d
     if (bdpt && cfg->timid_after_large) return bail(nullptr, "timidAfterLarge is not supported for technique=bdpt");
     // device_bdpt.h keeps two flag bits per stored vertex in ONE 64-bit register: 2 maxDepth + 1 slots fit up to maxDepth 15
     if (bdpt && cfg->max_depth > BDPT_MAX_DEPTH) return bail(nullptr, "technique=bdpt: maxDepth above 15 is not supported on the device");
+    // ... and a vertex record packs its bsdf and emitter numbers into one word (device_bdpt.h: BR_IDS)
+    if (bdpt && (scene->n_bsdfs > 4096 || scene->n_emitters > 65534)) return bail(nullptr, "technique=bdpt: more than 4096 bsdfs or 65534 emitters are not supported on the device");
     if (cfg->max_depth <= 0) return bail(nullptr, "technique=path needs a finite maxDepth (pssmlt_utils.h:63)");
     if (mmlt && cfg->max_depth > 24) return bail(nullptr, "technique=mmlt: maxDepth above 24 is not supported on the device");
     // a rejected large step re-draws the strategy; its second stage would read an emitter state that may be
@@ -504,7 +506,7 @@ drmlt_ctx *drmlt_create(const drmlt_config *cfg, const drmlt_scene *scene, int d
     P.bd_verts = nullptr; P.bd_lists = nullptr; P.n_chains_alloc = ctx->n_chains;
     if (bdpt) {
         const size_t nvs = (size_t) 2 * cfg->max_depth + 1, rows = (size_t) 7 + 5 * cfg->max_depth;
-        if (ctx->d_bd_verts.alloc((size_t) 21 * nvs * ctx->n_chains * sizeof(float)) /* BV_FIELDS, device_bdpt.h */ != hipSuccess ||
+        if (ctx->d_bd_verts.alloc((size_t) 20 * nvs * ctx->n_chains * sizeof(float)) /* BR_FLOATS, device_bdpt.h */ != hipSuccess ||
             ctx->d_bd_lists.alloc((size_t) 3 * rows * ctx->n_chains * sizeof(float)) != hipSuccess)
             return bail(ctx, "device allocation of the bdpt workspace failed");
         if (hipMemset(ctx->d_bd_lists.p, 0, (size_t) 3 * rows * ctx->n_chains * sizeof(float)) != hipSuccess) return bail(ctx, "hipMemset of the bdpt workspace failed");

@@ -6,7 +6,7 @@
 //   k_eval_lists_bdpt   sampleSplats(EBidirectional) on caller-supplied PSS points, full splat lists
 //
 // LDS rows ([row][lane]): the walks' part of the chain state [0, S + E) (bdpt_dims_sensor / _emitter), then the two row
-// groups of eval_bdpt: 76 rows = 19 KB for maxDepth 8 -- under the 20 KB that put eight waves on a CU. The direct
+// groups of eval_bdpt and its row of segment heads: 77 rows = 19.25 KB for maxDepth 8 -- under the 20 KB that put eight waves on a CU. The direct
 // sampler's Dd components (directSampling = true) stay in memory: a sample reads at most a few of them. Splat lists live in HBM (`bd_lists`, slot 0 = current state), unnormalised next to their luminance.
 #include <cstdlib>
 #include "device_bdpt.h"
@@ -84,30 +84,35 @@ DEV void list_copy(const DParams &P, float *dst, const float *src) {
 __global__ void __launch_bounds__(CHAIN_BLOCK) k_bootstrap_bdpt(DParams P, uint32_t n, float *lum_out) {
     const uint32_t lane = threadIdx.x;
     const uint32_t c = blockIdx.x * CHAIN_BLOCK + lane; // workspace column
-    if (c >= P.n_chains_alloc) return;
+    const bool has_col = c < P.n_chains_alloc;
+    const uint32_t cc = has_col ? c : P.n_chains_alloc - 1u;
     MSampler smp;
     bsampler_setup(smp, P, lane);
     smp.chain = P.boot_stream; smp.mode = SM_BOOT;
     const GlobalTables T{P.shade, P.bsdfs, P.emitters};
-    for (uint32_t i = c; i < n; i += P.n_chains_alloc) {
+    for (uint32_t i0 = blockIdx.x * CHAIN_BLOCK; i0 < n; i0 += P.n_chains_alloc) { // the whole wave makes every call (eval_bdpt)
+        const uint32_t i = i0 + lane;
+        const bool active = has_col && i < n;
         smp.major = i;
         BdptResult R;
-        eval_bdpt(P, T, smp, c, bdpt_nx_lds(P), list_col(P, 1, c), R);
-        lum_out[i] = R.lum;
+        eval_bdpt(P, T, smp, active, cc, bdpt_nx_lds(P), list_col(P, 1, cc), R);
+        if (active) lum_out[i] = R.lum;
     }
 }
 
 __global__ void __launch_bounds__(CHAIN_BLOCK) k_init_chains_bdpt(DParams P, const uint32_t *seed_index, const float *seed_lum) {
     const uint32_t lane = threadIdx.x;
-    const uint32_t c = blockIdx.x * CHAIN_BLOCK + lane;
-    if (c >= P.n_chains) return;
+    const uint32_t c0 = blockIdx.x * CHAIN_BLOCK + lane;
+    const bool live = c0 < P.n_chains;
+    const uint32_t c = live ? c0 : P.n_chains - 1u;
     MSampler smp;
     bsampler_setup(smp, P, lane);
     smp.chain = P.boot_stream; smp.major = seed_index[c]; smp.mode = SM_BOOT;
     const GlobalTables T{P.shade, P.bsdfs, P.emitters};
     BdptResult R;
     float *cur = list_col(P, 0, c);
-    eval_bdpt(P, T, smp, c, bdpt_nx_lds(P), cur, R);
+    eval_bdpt(P, T, smp, live, c, bdpt_nx_lds(P), cur, R);
+    if (!live) return;
     if (!(fabsf((R.lum - seed_lum[c]) / seed_lum[c]) <= EPSILON_F)) atomicExch(P.error_flag, 1); // drmlt_proc.cpp:509-512
     const float lum = list_finalize(P, cur, R.lum);
     P.cur_lum[c] = lum;
@@ -162,7 +167,6 @@ template <int FEAT, int OCC> __global__ void __launch_bounds__(CHAIN_BLOCK, OCC)
     for (;;) {
         const bool run = live && it < n_mut;
         if (!__builtin_amdgcn_ballot_w64(run)) break;
-        if (!run) continue;
         const uint32_t m = mut_base + it;
         const u4 coins = philox4x32_10(P.key0, P.key1, 0u, m, smp.chain, TAG_COIN);
         const bool large = u32_to_unit(coins.x) < P.p_large;
@@ -171,13 +175,14 @@ template <int FEAT, int OCC> __global__ void __launch_bounds__(CHAIN_BLOCK, OCC)
         const unsigned long long b0 = BSTAMP();
         float a2 = 0.f;
         bool acc1 = false, acc2 = false, decided = true;
+        smp.mode = stage == 0 ? SM_STAGE1 : (stage == 1 ? SM_STAGE2 : SM_REVERSE);
+        BdptResult R;
+        // Green's reverse path only needs its luminance; it is written over the first-stage list, which is rejected
+        // for good by then (acc1 = false) and has already been splatted (see below)
+        float *target = stage == 1 ? L2 : L1;
+        eval_bdpt<FEAT>(P, T, smp, run, cc, NX, target, R); // the whole wave: the connections of all chains go to all lanes
+        if (!run) continue;
         {
-            smp.mode = stage == 0 ? SM_STAGE1 : (stage == 1 ? SM_STAGE2 : SM_REVERSE);
-            BdptResult R;
-            // Green's reverse path only needs its luminance; it is written over the first-stage list, which is rejected
-            // for good by then (acc1 = false) and has already been splatted (see below)
-            float *target = stage == 1 ? L2 : L1;
-            eval_bdpt<FEAT>(P, T, smp, cc, NX, target, R);
             ct.rays += R.nrays;
             const float lum = list_finalize(P, target, R.lum);
             if (stage == 0) {
@@ -278,18 +283,22 @@ template <int FEAT, int OCC> __global__ void __launch_bounds__(CHAIN_BLOCK, OCC)
 // [lum, hasMain, px, py, r, g, b, nMore, nDims, nRays, nMore x (px, py, r, g, b)]
 __global__ void __launch_bounds__(CHAIN_BLOCK) k_eval_lists_bdpt(DParams P, const float *u, uint32_t n, uint32_t dim, float *out, uint32_t stride) {
     const uint32_t lane = threadIdx.x;
-    const uint32_t c = blockIdx.x * CHAIN_BLOCK + lane;
-    if (c >= P.n_chains_alloc) return;
+    const uint32_t c0 = blockIdx.x * CHAIN_BLOCK + lane;
+    const bool has_col = c0 < P.n_chains_alloc;
+    const uint32_t c = has_col ? c0 : P.n_chains_alloc - 1u;
     MSampler smp;
     bsampler_setup(smp, P, lane);
     smp.chain = 0u; smp.major = 0u; smp.mode = SM_ARRAY;
     const GlobalTables T{P.shade, P.bsdfs, P.emitters};
     const size_t na = P.n_chains_alloc;
-    for (uint32_t i = c; i < n; i += P.n_chains_alloc) {
-        smp.arr = u + (size_t) i * dim;
+    for (uint32_t i0 = blockIdx.x * CHAIN_BLOCK; i0 < n; i0 += P.n_chains_alloc) { // the whole wave makes every call (eval_bdpt)
+        const uint32_t i = i0 + lane;
+        const bool active = has_col && i < n;
+        smp.arr = u + (size_t) (active ? i : 0u) * dim;
         BdptResult R;
         float *L = list_col(P, 1, c);
-        eval_bdpt(P, T, smp, c, bdpt_nx_lds(P), L, R);
+        eval_bdpt(P, T, smp, active, c, bdpt_nx_lds(P), L, R);
+        if (!active) continue;
         float *o = out + (size_t) i * stride;
         for (uint32_t k = 0; k < stride; ++k) o[k] = 0.f;
         o[0] = R.lum; o[1] = R.has_main ? 1.f : 0.f;
@@ -302,7 +311,7 @@ __global__ void __launch_bounds__(CHAIN_BLOCK) k_eval_lists_bdpt(DParams P, cons
 
 static size_t bdpt_lds_bytes(const DParams &P) {
     static const size_t pad = getenv("DRMLT_BDPT_LDS_PAD") ? (size_t) atoi(getenv("DRMLT_BDPT_LDS_PAD")) : 0; // diagnostic: occupancy experiments
-    return pad + ((size_t) P.mmlt_S + P.mmlt_E + 2 * ((size_t) 2 * P.max_depth + 1)) * 64 * sizeof(float);
+    return pad + (((size_t) P.mmlt_S + P.mmlt_E) * 64 + (size_t) bdpt_eval_lds_floats(P.max_depth)) * sizeof(float);
 }
 void launch_bootstrap_bdpt(const DParams &P, uint32_t n, float *lum_out, hipStream_t st) {
     hipLaunchKernelGGL(k_bootstrap_bdpt, dim3((P.n_chains_alloc + CHAIN_BLOCK - 1) / CHAIN_BLOCK), dim3(CHAIN_BLOCK), bdpt_lds_bytes(P), st, P, n, lum_out);
