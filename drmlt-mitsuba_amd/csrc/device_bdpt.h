@@ -7,7 +7,8 @@
 // Storage per chain:
 //   global workspace `bd_verts`  [chain][NVS] records of BR_FLOATS floats (80 B): every stored vertex, contiguous -- written by
 //                                the chain's lane during the walks, read by WHICHEVER lane connects a pair of them
-//   LDS rows from `mis_row`      2 x NVS rows           fwd / rev densities (area measure) -- what the MIS sweep reads for every pair
+//                                behind them [NVS][chain] fp64: the part of Path::miWeight's sum that lies beyond each vertex
+//   LDS rows from `mis_row`      2 x NVS rows           fwd / rev densities (area measure) -- what the MIS weight reads for every pair
 //   global lists `bd_lists`      [slot][BL_ROWS][n]     splat lists of the current state and the two proposals
 // NVS = ME + MS vertex slots: emitter vertices 1..ME (ME = maxDepth), sensor vertices 1..MS (MS = maxDepth + 1);
 // the supernodes are implicit.
@@ -63,7 +64,9 @@ struct BdptResult {
 
 struct BdptStore {
     float *verts;     // P.bd_verts
-    uint32_t NVS;
+    uint32_t NVS, n;  // n: columns of the arrays behind the records (P.n_chains_alloc)
+    // behind the records: the MIS sums of the subpaths beyond each vertex (below), [slot][chain], fp64
+    DEV double *tails(uint32_t chain) const { return reinterpret_cast<double *>(verts + (size_t) n * NVS * BR_FLOATS) + chain; }
     DEV float *rec(uint32_t chain, int slot) const { return verts + ((size_t) chain * NVS + (uint32_t) slot) * BR_FLOATS; }
     DEV float f(uint32_t chain, int slot, int field) const { return rec(chain, slot)[field]; }
     DEV f3 pos(uint32_t chain, int slot) const { const float *r = rec(chain, slot); return mk3(r[BR_P], r[BR_P + 1], r[BR_P + 2]); }
@@ -76,11 +79,11 @@ struct BdptStore {
         r[3] = make_float4(v.e_len2, v.e_cos, ginv, __int_as_float(v.kind | (v.bsdf << 4) | ((v.emitter + 1) << 16)));
         r[4] = make_float4(thr.x, thr.y, thr.z, __int_as_float(v.shade));
     }
-    DEV void get(uint32_t chain, int slot, BVert &v, f3 &thr) const {
+    DEV void get(uint32_t chain, int slot, BVert &v, f3 &thr, float &ginv) const {
         const float4 *r = reinterpret_cast<const float4 *>(rec(chain, slot));
         const float4 a = r[0], b = r[1], c = r[2], d = r[3], e = r[4];
         v.p = mk3(a.x, a.y, a.z); v.n = mk3(a.w, b.x, b.y); v.s = mk3(b.z, b.w, c.x); v.wi = mk3(c.y, c.z, c.w);
-        v.e_len2 = d.x; v.e_cos = d.y;
+        v.e_len2 = d.x; v.e_cos = d.y; ginv = d.z;
         const int ids = __float_as_int(d.w);
         v.kind = ids & 15; v.bsdf = (ids >> 4) & 4095; v.emitter = (int) ((uint32_t) ids >> 16) - 1;
         thr = mk3(e.x, e.y, e.z);
@@ -132,7 +135,7 @@ DEV void eval_bdpt(const DParams &P, const TablesT &T, MSampler &smp, bool activ
     const uint32_t lane = smp.lane, n = P.n_chains_alloc;
     const int ME = P.max_depth, MS = P.max_depth + 1;
     const uint32_t NVS = (uint32_t) (ME + MS);
-    const BdptStore W{P.bd_verts, NVS};
+    const BdptStore W{P.bd_verts, NVS, n};
     auto mis = [&](int group, int slot) -> float & { return lds_x[(mis_row + (uint32_t) group * NVS + (uint32_t) slot) * 64u + lane]; };
     auto lrow = [&](int r) -> float & { return list[(size_t) r * n]; };
     static_assert(2 * (2 * BDPT_MAX_DEPTH + 1) <= 64, "two flag bits per vertex slot in one 64-bit register");
@@ -333,6 +336,44 @@ DEV void eval_bdpt(const DParams &P, const TablesT &T, MSampler &smp, bool activ
     if (active && direct && nE >= 3)
         re_walk = emitter_direct_pdf_area(T, W.pos(chain, 1), W.nrm(chain, 1), refn_zero(chain, 1), W.pos(chain, 0), W.nrm(chain, 0),
                                           (int) ((uint32_t) __float_as_int(W.f(chain, 0, BR_IDS)) >> 16) - 1) / em0_fwd;
+    // Path::miWeight (path.cpp:763-1028) sums, over every other strategy i of a path, the squared ratio of its density to the
+    // connection's; the ratios are running products along the path, p_{i+1} = p_i x pdfImp[i] / pdfRad[i] towards the sensor and
+    // the inverse towards the emitter. Two positions on either side of the connection edge involve the connection itself; beyond
+    // them every factor belongs to ONE subpath, so their part of the sum is  p^2 x tail  with a tail that is the same for every
+    // connection made at that vertex:  tail[m] = r_m^2 (c_m + tail[m - 1])  (r: the ratio at vertex m, c: whether that strategy
+    // counts -- both endpoints connectable, not the two-vertex sensor path unless there is a light image, the emitter's
+    // direct-sampling ratio at position 1). One pass over each subpath here; a connection then costs four ratios and two tails
+    // instead of a sweep over the whole path.
+    if (active) {
+        double *const tails = W.tails(chain);
+        auto fl = [&](int slot) -> bool { return ((unsigned) (flagbits >> (2 * slot)) & BF_CONN) != 0u; };
+        const float re_e = (direct && fl(1)) ? re_walk : 0.f; // the sampleDirect ratio of the s >= 4 strategies, at position 1
+        double acc = 0.0;
+        for (int m = 1; m <= nE - 3; ++m) { // emitter vertex m = position m: pdfRad[m] / pdfImp[m] (path.cpp:868-898 for the specular neighbours)
+            const bool cm = fl(m - 1), cm1 = m == 1 ? true : fl(m - 2), cp1 = fl(m);
+            float num = mis(MF_REV, m);
+            if (m >= 2 && cp1 && !cm) num *= W.f(chain, m, BR_GINV);
+            float den = m == 1 ? em0_fwd : mis(MF_FWD, m - 2);
+            if (m >= 2 && cm1 && !cm) den *= W.f(chain, m - 1, BR_GINV);
+            const double r = (double) (num / den);
+            double c = (cm1 && cm) ? 1.0 : 0.0; // strategy i = m - 1
+            if (direct && m == 2) c *= (double) re_e * (double) re_e;
+            acc = r * r * (c + acc);
+            tails[(size_t) (m - 1) * n] = acc;
+        }
+        acc = 0.0;
+        for (int m = 1; m <= nS - 3; ++m) { // sensor vertex m = position k - m: pdfImp / pdfRad
+            const bool cw = fl(ME + m - 1), cwm = m == 1 ? false : fl(ME + m - 2), cwp = fl(ME + m);
+            float num = mis(MF_REV, ME + m);
+            if (m >= 2 && cwp && !cw) num *= W.f(chain, ME + m, BR_GINV);
+            float den = m == 1 ? 1.f : mis(MF_FWD, ME + m - 2);
+            if (m >= 2 && cwm && !cw) den *= W.f(chain, ME + m - 1, BR_GINV);
+            const double r = (double) (num / den);
+            const double c = (cw && cwm && (P.light_image || m - 1 > 1)) ? 1.0 : 0.0;
+            acc = r * r * (c + acc);
+            tails[(size_t) (ME + m - 1) * n] = acc;
+        }
+    }
     uint32_t cells = 0u;     // the (s, t) pairs this chain's subpaths reach
     if (active)
         for (int s = 0; s <= nE - 1; ++s) { int mt; cells += (uint32_t) bdpt_row_cells(P, s, nS, mt); }
@@ -422,8 +463,9 @@ DEV void eval_bdpt(const DParams &P, const TablesT &T, MSampler &smp, bool activ
             f3 thr_s = mk3(1.f, 1.f, 1.f), thr_t;
             vs.p = vs.n = vs.s = vs.wi = mk3(0.f, 0.f, 0.f); vs.e_len2 = vs.e_cos = 0.f; vs.kind = BK_SURF; vs.bsdf = 0; vs.emitter = -1; vs.shade = 0;
             vs.degenerate = false;
-            if (s >= 1) { W.get(wc, s - 1, vs, thr_s); vs.degenerate = (flags(s - 1) & BF_DEGEN) != 0u; }
-            W.get(wc, ME + t - 1, vt, thr_t);
+            float ginv_s = 0.f, ginv_t;
+            if (s >= 1) { W.get(wc, s - 1, vs, thr_s, ginv_s); vs.degenerate = (flags(s - 1) & BF_DEGEN) != 0u; }
+            W.get(wc, ME + t - 1, vt, thr_t, ginv_t);
             vt.degenerate = (flags(ME + t - 1) & BF_DEGEN) != 0u;
             const int k = s + t + 1, depth = s + t - 1;
             float geo = 1.f;
@@ -516,58 +558,55 @@ DEV void eval_bdpt(const DParams &P, const TablesT &T, MSampler &smp, bool activ
             }
             if (P.exclude_direct && depth <= 2) { value = mk3(0.f, 0.f, 0.f); break; }
 
-            // ---- Path::miWeight over positions 0..k (emitter vertex j at j, sensor vertex j at k - j)
-            auto conn = [&](int j) -> bool {
-                if (j == 0 || j == s || j == s + 1) return true;
-                if (j >= k) return false;
-                return (flags(j < s ? j - 1 : ME + (k - j) - 1) & BF_CONN) != 0u;
-            };
-            auto ginv = [&](int e) -> float { return e < s ? W.f(wc, e, BR_GINV) : W.f(wc, ME + (k - e) - 1, BR_GINV); }; // edge (e, e + 1)
-            auto pImp = [&](int j) -> float {
-                float v;
-                if (j == 0) v = 1.f;
-                else if (j <= s) v = j == 1 ? em0 : misc(MF_FWD, j - 2);
-                else if (j == s + 1) v = pc_i1;
-                else if (j == s + 2) v = pc_i2;
-                else v = misc(MF_REV, ME + (k - j + 1) - 1);
-                const int i = j - 1; // area -> projected solid angle next to a specular vertex (path.cpp:868-882)
-                if (i >= 1 && i <= k - 3 && i != s && conn(i) && !conn(i + 1)) v *= ginv(i);
-                return v;
-            };
-            auto pRad = [&](int j) -> float {
-                float v;
-                if (j == k) v = 1.f;
-                else if (j >= s + 1) { const int a = k - j - 1; v = a == 0 ? 1.f : misc(MF_FWD, ME + a - 1); }
-                else if (j == s) v = pc_r0;
-                else if (j == s - 1) v = pc_r1;
-                else v = misc(MF_REV, j);                      // emitter vertex j + 1, slot j
-                const int i = j + 1; // (path.cpp:884-898)
-                if (i <= k - 1 && i >= 3 && j != s && conn(i) && !conn(j)) v *= ginv(j);
-                return v;
-            };
+            // ---- Path::miWeight over positions 0..k (emitter vertex j at j, sensor vertex j at k - j): the two positions on either
+            // side of the connection edge explicitly, the rest of either subpath through its tail (above)
+            auto cflag = [&](int slot) -> bool { return (flags(slot) & BF_CONN) != 0u; };
             // sampleDirect terms (path.cpp:799-824,936-965): the emitter's direct-sampling density relative to its area density
             // at position 1. The sensor's ratio is 1: a pinhole's direct density is discrete, its position density 1.
             const bool sd = direct && k > 3;
+            const bool c2 = t >= 2 && cflag(ME + t - 2); // connectable(s + 2): sensor vertex t - 1
             float re = 0.f;
             double initial = 1.0;
             if (sd) {
                 if (s == 1) { re = re_s1; initial = 1.0 / (double) re; }
-                else if (s == 0) { if (conn(2)) re = emitter_direct_pdf_area(T, W.pos(wc, ME + t - 2), W.nrm(wc, ME + t - 2), refn_zero(wc, ME + t - 2), vt.p, vt.n, vt.emitter) / pc_i1; }
-                else if (conn(2)) re = re_walk_c;
+                else if (s == 0) { if (c2) re = emitter_direct_pdf_area(T, W.pos(wc, ME + t - 2), W.nrm(wc, ME + t - 2), refn_zero(wc, ME + t - 2), vt.p, vt.n, vt.emitter) / pc_i1; }
+                else if (s == 2 || cflag(1)) re = re_walk_c;
             }
-            double weight = 1.0, pdf = initial;
-            for (int i = s + 1; i < k; ++i) {
-                double next = pdf * (double) (pImp(i) / pRad(i)); // ratio in fp32, product in fp64 (see device_bidir.h)
-                const double v = (sd && i == 1) ? next * (double) re : next;
-                if (conn(i) && conn(i + 1) && (P.light_image || k - i - 1 > 1)) weight += v * v;
-                pdf = next;
+            const double *const tails = W.tails(wc);
+            double weight = 1.0;
+            { // towards the sensor: strategies i = s + 1, s + 2, then the tail of sensor vertex t - 2 (ratio in fp32, product in fp64, see device_bidir.h)
+                const float den1 = t == 1 ? 1.f : misc(MF_FWD, ME + t - 2);
+                double pdf = initial * (double) (pc_i1 / den1);
+                const double v1 = (sd && s == 0) ? pdf * (double) re : pdf;
+                if (c2 && (P.light_image || t - 1 > 1)) weight += v1 * v1;
+                if (t >= 2) {
+                    const bool c3 = t >= 3 && cflag(ME + t - 3); // connectable(s + 3): sensor vertex t - 2
+                    float num = pc_i2;
+                    if (t >= 3 && !c2) num *= ginv_t;
+                    float den2 = t == 2 ? 1.f : misc(MF_FWD, ME + t - 3);
+                    if (t >= 3 && c3 && !c2) den2 *= W.f(wc, ME + t - 2, BR_GINV);
+                    pdf *= (double) (num / den2);
+                    if (c2 && c3 && (P.light_image || t - 2 > 1)) weight += pdf * pdf;
+                    if (t >= 3) weight += pdf * pdf * tails[(size_t) (ME + t - 3) * n];
+                }
             }
-            pdf = initial;
-            for (int i = s - 1; i >= 0; --i) {
-                double next = pdf * (double) (pRad(i + 1) / pImp(i + 1));
-                const double v = (sd && i == 1) ? next * (double) re : next;
-                if (conn(i) && conn(i + 1) && (P.light_image || k - i - 1 > 1)) weight += v * v;
-                pdf = next;
+            if (s >= 1) { // towards the emitter: strategies i = s - 1, s - 2, then the tail of emitter vertex s - 2
+                const bool cm1 = s == 1 ? true : cflag(s - 2); // connectable(s - 1)
+                const float den1 = s == 1 ? em0 : misc(MF_FWD, s - 2);
+                double pdf = initial * (double) (pc_r0 / den1);
+                const double v1 = (sd && s == 2) ? pdf * (double) re : pdf;
+                if (cm1) weight += v1 * v1;
+                if (s >= 2) {
+                    const bool cm2 = s == 2 ? true : cflag(s - 3); // connectable(s - 2)
+                    float num = pc_r1;
+                    if (s >= 3 && !cm1) num *= ginv_s;
+                    float den2 = s == 2 ? em0 : misc(MF_FWD, s - 3);
+                    if (s >= 3 && cm2 && !cm1) den2 *= W.f(wc, s - 2, BR_GINV);
+                    pdf *= (double) (num / den2);
+                    const double v2 = (sd && s == 3) ? pdf * (double) re : pdf;
+                    if (cm2 && cm1) weight += v2 * v2;
+                    if (s >= 3) weight += pdf * pdf * tails[(size_t) (s - 3) * n];
+                }
             }
             value = value * (geo / (float) weight);
             if (t == 1 && !cam_sample_position(P, vs.p - vt.p, light_x, light_y)) { value = mk3(0.f, 0.f, 0.f); break; } // light image: its own splat (:514-516)
