@@ -466,6 +466,9 @@ DEV void eval_bdpt(const DParams &P, const TablesT &T, MSampler &smp, bool activ
             float ginv_s = 0.f, ginv_t;
             if (s >= 1) { W.get(wc, s - 1, vs, thr_s, ginv_s); vs.degenerate = (flags(s - 1) & BF_DEGEN) != 0u; }
             W.get(wc, ME + t - 1, vt, thr_t, ginv_t);
+            // the subpaths' tails for the weight at the end: asked for now, so that they arrive behind the connection's arithmetic
+            const double *const tails = W.tails(wc);
+            const double tail_t = t >= 3 ? tails[(size_t) (ME + t - 3) * n] : 0.0, tail_s = s >= 3 ? tails[(size_t) (s - 3) * n] : 0.0;
             vt.degenerate = (flags(ME + t - 1) & BF_DEGEN) != 0u;
             const int k = s + t + 1, depth = s + t - 1;
             float geo = 1.f;
@@ -572,7 +575,6 @@ DEV void eval_bdpt(const DParams &P, const TablesT &T, MSampler &smp, bool activ
                 else if (s == 0) { if (c2) re = emitter_direct_pdf_area(T, W.pos(wc, ME + t - 2), W.nrm(wc, ME + t - 2), refn_zero(wc, ME + t - 2), vt.p, vt.n, vt.emitter) / pc_i1; }
                 else if (s == 2 || cflag(1)) re = re_walk_c;
             }
-            const double *const tails = W.tails(wc);
             double weight = 1.0;
             { // towards the sensor: strategies i = s + 1, s + 2, then the tail of sensor vertex t - 2 (ratio in fp32, product in fp64, see device_bidir.h)
                 const float den1 = t == 1 ? 1.f : misc(MF_FWD, ME + t - 2);
@@ -587,7 +589,7 @@ DEV void eval_bdpt(const DParams &P, const TablesT &T, MSampler &smp, bool activ
                     if (t >= 3 && c3 && !c2) den2 *= W.f(wc, ME + t - 2, BR_GINV);
                     pdf *= (double) (num / den2);
                     if (c2 && c3 && (P.light_image || t - 2 > 1)) weight += pdf * pdf;
-                    if (t >= 3) weight += pdf * pdf * tails[(size_t) (ME + t - 3) * n];
+                    weight += pdf * pdf * tail_t;
                 }
             }
             if (s >= 1) { // towards the emitter: strategies i = s - 1, s - 2, then the tail of emitter vertex s - 2
@@ -605,7 +607,7 @@ DEV void eval_bdpt(const DParams &P, const TablesT &T, MSampler &smp, bool activ
                     pdf *= (double) (num / den2);
                     const double v2 = (sd && s == 3) ? pdf * (double) re : pdf;
                     if (cm2 && cm1) weight += v2 * v2;
-                    if (s >= 3) weight += pdf * pdf * tails[(size_t) (s - 3) * n];
+                    weight += pdf * pdf * tail_s;
                 }
             }
             value = value * (geo / (float) weight);
