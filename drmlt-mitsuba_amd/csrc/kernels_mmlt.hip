@@ -96,7 +96,21 @@ template <int FEAT> __global__ void __launch_bounds__(CHAIN_BLOCK, 2) k_mutate_m
     const bool amap = P.acceptance_map != 0;
     const bool mix = P.use_mixture != 0;
 
-    if (live) for (uint32_t it = 0; it < n_mut; ++it) {
+    // Chains run free: every pass of the loop evaluates ONE path per lane -- the first stage of the lane's next mutation, or the
+    // second stage / Green's reverse move of the one it is in. (In a lockstep loop over mutations with the stages inside, the few
+    // lanes in sixty-four that go to a second stage -- 8 % of the mutations -- cost the wave a whole second pass nearly every time.)
+    uint32_t it = 0u;
+    int stage = 0;
+    DSplat y, z;
+    y.lum = 0.f; y.px = y.py = y.r = y.g = y.b = 0.f;
+    z = y;
+    int y_t = 0, z_t = 0;
+    uint32_t ns1 = 0, ne1 = 0, ns2 = 0, ne2 = 0;
+    float a1 = 0.f;
+    for (;;) {
+        const bool run = live && it < n_mut;
+        if (!__builtin_amdgcn_ballot_w64(run)) break;
+        if (!run) continue;
         const uint32_t m = mut_base + it;
         const u4 coins = philox4x32_10(P.key0, P.key1, 0u, m, smp.chain, TAG_COIN);
         const bool large = u32_to_unit(coins.x) < P.p_large;
@@ -104,16 +118,9 @@ template <int FEAT> __global__ void __launch_bounds__(CHAIN_BLOCK, 2) k_mutate_m
         smp.large = large;
         // fixEmitterPath: the emitter sampler moves in the second stage only for pure light tracing (drmlt_proc.cpp:566-573)
         smp.emitter_ident2 = P.fix_emitter_path != 0 && cur_t != 1;
-        DSplat y, z;
-        y.lum = 0.f; y.px = y.py = y.r = y.g = y.b = 0.f;
-        z = y;
-        int y_t = 0, z_t = 0;
-        uint32_t ns1 = 0, ne1 = 0, ns2 = 0, ne2 = 0;
-        float a1 = 0.f, a2 = 0.f;
-        bool acc1 = false, acc2 = false, doSecond = false;
-
-#pragma nounroll
-        for (int stage = 0; stage < 3; ++stage) {
+        float a2 = 0.f;
+        bool acc1 = false, acc2 = false, decided = true;
+        {
             smp.mode = stage == 0 ? SM_STAGE1 : (stage == 1 ? SM_STAGE2 : SM_REVERSE);
             MmltResult R;
             eval_mmlt<FEAT>(P, T, smp, depth, NX, R);
@@ -121,19 +128,20 @@ template <int FEAT> __global__ void __launch_bounds__(CHAIN_BLOCK, 2) k_mutate_m
             DSplat res = R.splat;
             normalize_splat(res, P);
             if (stage == 0) {
+                bool doSecond = false;
                 y = res; y_t = R.t; ns1 = R.n_sensor; ne1 = R.n_emitter;
+                z.lum = 0.f; z.px = z.py = z.r = z.g = z.b = 0.f; z_t = 0; ns2 = ne2 = 0u;
                 mh_first(mix, false, large, y.lum, cur.lum, u32_to_unit(coins.y), u32_to_unit(coins.w), a1, acc1, doSecond); // timidAfterLarge is refused for mmlt
-                if (!doSecond) break;
+                if (doSecond) { stage = 1; decided = false; }
             } else if (stage == 1) {
                 z = res; z_t = R.t; ns2 = R.n_sensor; ne2 = R.n_emitter;
                 if (mix) { // the second proposal replaces the first
-                    acc1 = false; a1 = 0.f;
+                    a1 = 0.f;
                     mh_second_mixture(z.lum, cur.lum, u32_to_unit(coins.z), a2, acc2);
-                    break;
-                }
-                if (lum_invalid(z.lum)) break;
-                if (P.type == 0) continue; // Green: the reverse move first
-                if (P.type == 1) { // Tierney & Mira: product of the three samplers' ratios (drmlt_proc.cpp:633-637)
+                } else if (lum_invalid(z.lum)) {
+                } else if (P.type == 0) { // Green: the reverse move first
+                    stage = 2; decided = false;
+                } else if (P.type == 1) { // Tierney & Mira: product of the three samplers' ratios (drmlt_proc.cpp:633-637)
                     float ratio = 1.f;
                     if (!(fminf(1.f, y.lum / z.lum) >= 1.f)) { // (a large step never gets here: no second stage after it)
                         float num = 0.f, den = 0.f;
@@ -153,12 +161,13 @@ template <int FEAT> __global__ void __launch_bounds__(CHAIN_BLOCK, 2) k_mutate_m
                 } else {
                     mh_second_orbital(y.lum, z.lum, cur.lum, u32_to_unit(coins.z), a2, acc2);
                 }
-                break;
             } else {
                 ct.acc2b_rev += 1u << 16;
                 mh_second_green(res.lum, z.lum, cur.lum, a1, u32_to_unit(coins.z), a2, acc2);
             }
         }
+        if (!decided) continue;
+        const bool doSecond = stage != 0;
 
         const MhWeights w = mh_weights(mix, amap, doSecond, a1, a2);
         if (w.w0 > 0.f) film_put(P, cur.px, cur.py, mk3(cur.r * w.w0, cur.g * w.w0, cur.b * w.w0));
@@ -182,6 +191,8 @@ template <int FEAT> __global__ void __launch_bounds__(CHAIN_BLOCK, 2) k_mutate_m
             cur = select_splat(acc1, y, z);
             cur_t = acc1 ? y_t : z_t;
         }
+        ++it;
+        stage = 0;
     }
 
     if (live) {
