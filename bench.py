@@ -343,6 +343,11 @@ def main():
                 "note": "north_star's '>= 30 % of the HBM-read roofline' is not met and cannot be on this scene class: "
                         "scene (scalar cache / LDS) and chain state (LDS) are on chip, compulsory HBM traffic is the film "
                         "atomics (SURVEY 8d); the kernel is bound by VALU issue x lane utilisation: see roofline_valu"}
+        if args.config == "bdpt":
+            roof["note"] = ("bdpt keeps every stored vertex in device memory (80 B records, written by the walks, gathered two per connection "
+                            "cell: ~17 cells per evaluation) next to its splat lists: `traffic` is what of that misses the L2s; "
+                            "`algorithmic_bytes_per_mutation` is SURVEY 8(d)'s state + lists + film formula and leaves the vertex workspace out. "
+                            "Bound by VALU issue x lane utilisation: see roofline_valu")
         if bvh_scene:
             # requested bytes that L2 serves must never stand in for HBM bytes. On BVH scenes the node / primitive
             # fetches the kernel counts are (mostly) L2 hits, so `achieved` / `frac` are the MEASURED HBM figure here (PMC
