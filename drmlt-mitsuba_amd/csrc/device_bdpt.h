@@ -149,6 +149,7 @@ DEV void eval_bdpt(const DParams &P, const TablesT &T, MSampler &smp, bool activ
 
     // ------------------------------------------------------------ the two random walks (emitter first, :331-340)
     int nE = 1, nS = 1;            // vertices of each subpath, supernode included
+    uint32_t emit_bits = 0u;       // bit t: sensor vertex t lies on an emitter (the s = 0 strategies that exist at all)
     float em0_fwd = 0.f;           // density of the emitter sample (area x emitter choice)
     float film_x = 0.f, film_y = 0.f;
     if (active) {
@@ -321,7 +322,7 @@ DEV void eval_bdpt(const DParams &P, const TablesT &T, MSampler &smp, bool activ
             nv.e_cos = cosCur;
             W.put(chain, base + i, nv, thr, len2 / (cosNew * cosCur)); // vertex i + 1, with the factor of edge (i, i + 1)
             set_flags(base + i, nv.degenerate ? BF_DEGEN : 0u);
-            if (emitter) nE = i + 2; else nS = i + 2;
+            if (emitter) nE = i + 2; else { nS = i + 2; if (nv.emitter >= 0) emit_bits |= 1u << (i + 1); }
             cur = nv;
         }
 #undef WALK_FAIL
@@ -376,7 +377,13 @@ DEV void eval_bdpt(const DParams &P, const TablesT &T, MSampler &smp, bool activ
     }
     uint32_t cells = 0u;     // the (s, t) pairs this chain's subpaths reach
     if (active)
-        for (int s = 0; s <= nE - 1; ++s) { int mt; cells += (uint32_t) bdpt_row_cells(P, s, nS, mt); }
+    {   // row s = 0 (the sensor subpath ends on an emitter, :381-395) has a cell only where it does: most of its vertices do not
+        int mt;
+        const int rc = bdpt_row_cells(P, 0, nS, mt);
+        emit_bits &= rc > 0 ? ((2u << mt) - 1u) & ~((1u << (mt - rc + 1)) - 1u) : 0u;
+        cells = (uint32_t) __popc(emit_bits);
+        for (int s = 1; s <= nE - 1; ++s) cells += (uint32_t) bdpt_row_cells(P, s, nS, mt);
+    }
     float total_lum = 0.f;
     f3 main_v = mk3(0.f, 0.f, 0.f);
     int n_more = 0;
@@ -426,6 +433,7 @@ DEV void eval_bdpt(const DParams &P, const TablesT &T, MSampler &smp, bool activ
         const uint32_t wc = (uint32_t) __shfl((int) chain, (int) c, 64);
         const uint32_t nEnS = (uint32_t) __shfl((int) ((uint32_t) nE | ((uint32_t) nS << 8)), (int) c, 64);
         const int nEc = (int) (nEnS & 255u), nSc = (int) (nEnS >> 8);
+        const uint32_t emit_c = (uint32_t) __shfl((int) emit_bits, (int) c, 64);
         const unsigned long long fb = shfl_u64(flagbits, c);
         const float em0_c = __shfl(em0_fwd, (int) c, 64), re_walk_c = __shfl(re_walk, (int) c, 64);
         float *const list_c = reinterpret_cast<float *>(shfl_u64((unsigned long long) list, c));
@@ -442,11 +450,17 @@ DEV void eval_bdpt(const DParams &P, const TablesT &T, MSampler &smp, bool activ
         int s = 0, t = 0;
         {
             int j = (int) (jj + (prog_c & 255u));
-            for (int ss = nEc - 1; ss >= 0; --ss) {
+            bool found = false;
+            for (int ss = nEc - 1; ss >= 1; --ss) {
                 int mt;
                 const int rc = bdpt_row_cells(P, ss, nSc, mt);
-                if (j < rc) { s = ss; t = mt - j; break; }
+                if (j < rc) { s = ss; t = mt - j; found = true; break; }
                 j -= rc;
+            }
+            if (!found) { // row s = 0: the j-th emitter hit of the sensor subpath, t descending
+                uint32_t eb = emit_c;
+                for (; j > 0 && eb; --j) eb &= ~(0x80000000u >> __builtin_clz(eb));
+                t = eb ? 31 - __builtin_clz(eb) : 2;
             }
         }
         // components of the direct sampler: two per s = 1, t > 1 connection and per t = 1, s > 1 connection whose vertex can be
