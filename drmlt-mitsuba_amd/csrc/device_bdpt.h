@@ -67,6 +67,8 @@ struct BdptStore {
     uint32_t NVS, n;  // n: columns of the arrays behind the records (P.n_chains_alloc)
     // behind the records: the MIS sums of the subpaths beyond each vertex (below), [slot][chain], fp64
     DEV double *tails(uint32_t chain) const { return reinterpret_cast<double *>(verts + (size_t) n * NVS * BR_FLOATS) + chain; }
+    // ... and behind those the emitter samples of the s = 1 strategies, rows 2t and 2t + 1 for sensor vertex t, [row][chain]
+    DEV float *direct_samples(uint32_t chain) const { return verts + (size_t) n * NVS * (BR_FLOATS + 2) + chain; }
     DEV float *rec(uint32_t chain, int slot) const { return verts + ((size_t) chain * NVS + (uint32_t) slot) * BR_FLOATS; }
     DEV float f(uint32_t chain, int slot, int field) const { return rec(chain, slot)[field]; }
     DEV f3 pos(uint32_t chain, int slot) const { const float *r = rec(chain, slot); return mk3(r[BR_P], r[BR_P + 1], r[BR_P + 2]); }
@@ -375,6 +377,27 @@ DEV void eval_bdpt(const DParams &P, const TablesT &T, MSampler &smp, bool activ
             tails[(size_t) (ME + m - 1) * n] = acc;
         }
     }
+    // The direct sampler's components (directSampling = true, :424-452): two per t = 1, s > 1 connection and then two per s = 1,
+    // t > 1 connection whose vertex can be connected, in the reference's cell order. Which cells those are follows from the
+    // subpaths alone, so the chain draws its s = 1 emitter samples HERE, in one uniform loop, and the cells pick them up (drawn
+    // in a cell, the sampler -- every mode and kernel of it -- ran for a few lanes in nearly every round).
+    uint32_t kd_total = 0u;
+    if (active && direct && nE >= 2) {
+        auto degen = [&](int slot) -> bool { return ((unsigned) (flagbits >> (2 * slot)) & BF_DEGEN) != 0u; };
+        int mt;
+        for (int s = nE - 1; s >= 2; --s) // t = 1 is the last cell of a row that reaches it (light image)
+            if (P.light_image && bdpt_row_cells(P, s, nS, mt) > 0 && !degen(s - 1)) kd_total += 2u;
+        const int rc = bdpt_row_cells(P, 1, nS, mt);
+        float *const ds = W.direct_samples(chain);
+        smp.select(SEG_DIRECT);
+        for (int t = mt; t > mt - rc && t >= 2; --t) {
+            if (degen(ME + t - 1)) continue;
+            smp.boot_k = R.n_emitter + R.n_sensor + kd_total; // a replayed stream: emitter walk, sensor walk, then the direct components in order
+            ds[(size_t) (2 * t) * n] = smp.next(kd_total);
+            ds[(size_t) (2 * t + 1) * n] = smp.next(kd_total + 1u);
+            kd_total += 2u;
+        }
+    }
     uint32_t cells = 0u;     // the (s, t) pairs this chain's subpaths reach
     if (active)
     {   // row s = 0 (the sensor subpath ends on an emitter, :381-395) has a cell only where it does: most of its vertices do not
@@ -387,7 +410,6 @@ DEV void eval_bdpt(const DParams &P, const TablesT &T, MSampler &smp, bool activ
     float total_lum = 0.f;
     f3 main_v = mk3(0.f, 0.f, 0.f);
     int n_more = 0;
-    uint32_t kd_total = 0u;  // components of the direct sampler consumed
     int *const head = reinterpret_cast<int *>(&lds_x[(mis_row + 2u * NVS) * 64u]);
     const unsigned long long lanes_below = (1ull << lane) - 1ull;
 
@@ -410,7 +432,7 @@ DEV void eval_bdpt(const DParams &P, const TablesT &T, MSampler &smp, bool activ
         const uint32_t cnt = alone ? (lane == c0 ? 64u : 0u) : (lane < c1 ? rem : 0u);
         const bool owner = cnt != 0u; // this lane's chain is in the round
         const uint32_t start = alone ? 0u : pre - rem;
-        const uint32_t progress = done | ((uint32_t) n_more << 8) | (kd_total << 16); // what the chain's cells continue from
+        const uint32_t progress = done | ((uint32_t) n_more << 8); // what the chain's cells continue from
         if (owner) done += cnt;
         c0 = c1;
         if (total == 0u) continue;
@@ -437,12 +459,6 @@ DEV void eval_bdpt(const DParams &P, const TablesT &T, MSampler &smp, bool activ
         const unsigned long long fb = shfl_u64(flagbits, c);
         const float em0_c = __shfl(em0_fwd, (int) c, 64), re_walk_c = __shfl(re_walk, (int) c, 64);
         float *const list_c = reinterpret_cast<float *>(shfl_u64((unsigned long long) list, c));
-        // the chain's direct sampler, as far as a draw of it needs
-        const uint32_t s_chain = (uint32_t) __shfl((int) smp.chain, (int) c, 64), s_major = (uint32_t) __shfl((int) smp.major, (int) c, 64);
-        const int s_mode = __shfl(smp.mode | (smp.large ? 256 : 0), (int) c, 64);
-        const float *const s_arr = reinterpret_cast<const float *>(shfl_u64((unsigned long long) smp.arr, c));
-        const float *const s_xdir = reinterpret_cast<const float *>(shfl_u64((unsigned long long) smp.x_dir, c));
-        const uint32_t s_boot = (uint32_t) __shfl((int) (R.n_emitter + R.n_sensor), (int) c, 64);
         const uint32_t prog_c = (uint32_t) __shfl((int) progress, (int) c, 64);
         auto flags = [&](int slot) -> unsigned { return (unsigned) (fb >> (2 * slot)) & 3u; };
         auto misc = [&](int group, int slot) -> float { return lds_x[(mis_row + (uint32_t) group * NVS + (uint32_t) slot) * 64u + c]; };
@@ -463,12 +479,6 @@ DEV void eval_bdpt(const DParams &P, const TablesT &T, MSampler &smp, bool activ
                 t = eb ? 31 - __builtin_clz(eb) : 2;
             }
         }
-        // components of the direct sampler: two per s = 1, t > 1 connection and per t = 1, s > 1 connection whose vertex can be
-        // connected, in cell order (:424-452)
-        const bool consumes = mine && direct && ((s == 1 && t > 1 && !(flags(ME + t - 1) & BF_DEGEN)) || (t == 1 && s > 1 && !(flags(s - 1) & BF_DEGEN)));
-        const unsigned long long CB = __ballot(consumes);
-        const uint32_t kd = (prog_c >> 16) + 2u * (uint32_t) __popcll(CB & segmask & lanes_below);
-
         f3 value = mk3(0.f, 0.f, 0.f);
         float light_x = 0.f, light_y = 0.f;
         bool produced = false, traced = false;
@@ -507,14 +517,9 @@ DEV void eval_bdpt(const DParams &P, const TablesT &T, MSampler &smp, bool activ
                     // (:486-503). It goes through the connection code below as a vertex `vs` whose weight makes that code's
                     // value radiance / (pdf_direct) * f * cos -- cells at s = 1 and cells at other s share one code path.
                     if (vt.degenerate) break;
-                    MSampler sc = smp; // the chain's sampler as far as a draw of its direct segment needs it
-                    sc.chain = s_chain; sc.major = s_major; sc.mode = s_mode & 255; sc.large = (s_mode & 256) != 0; sc.arr = s_arr; sc.x_dir = s_xdir;
-                    sc.lane = c;
-                    sc.reset_caches();
-                    sc.select(SEG_DIRECT);
-                    sc.boot_k = s_boot + kd; // a replayed stream: emitter walk, sensor walk, then the direct components in cell order
-                    float sx = sc.next(kd);
-                    const float sy = sc.next(kd + 1u);
+                    const float *const ds = W.direct_samples(wc); // drawn by the chain after its walks
+                    float sx = ds[(size_t) (2 * t) * n];
+                    const float sy = ds[(size_t) (2 * t + 1) * n];
                     int ei = 0;
                     for (int q = 1; q < P.n_emitters; ++q)
                         if (T.emitter_cdf_lo(q) < sx) ei = q;
@@ -549,7 +554,7 @@ DEV void eval_bdpt(const DParams &P, const TablesT &T, MSampler &smp, bool activ
                 }
                 // t = 1 with direct sampling: a pinhole's sampleDirect returns the point the sensor subpath's vertex 1 already is
                 // (perspective.cpp:386-420) and the same value term by term; what remains is that it consumes two components
-                // (counted in `consumes` above)
+                // (counted by the chain, above)
                 if (vs.degenerate || vt.degenerate) break;
                 f3 dc = vt.p - vs.p;
                 const float len2 = dot3(dc, dc);
@@ -654,7 +659,6 @@ DEV void eval_bdpt(const DParams &P, const TablesT &T, MSampler &smp, bool activ
             total_lum += t3;
             n_more = min(n_more + (int) __popcll(LB & my), P.max_depth);
             R.nrays += (uint32_t) __popcll(TB & my);
-            kd_total += 2u * (uint32_t) __popcll(CB & my);
         }
     }
     if (stamps) {

@@ -506,7 +506,7 @@ drmlt_ctx *drmlt_create(const drmlt_config *cfg, const drmlt_scene *scene, int d
     P.bd_verts = nullptr; P.bd_lists = nullptr; P.n_chains_alloc = ctx->n_chains;
     if (bdpt) {
         const size_t nvs = (size_t) 2 * cfg->max_depth + 1, rows = (size_t) 7 + 5 * cfg->max_depth;
-        if (ctx->d_bd_verts.alloc((size_t) (20 + 2) * nvs * ctx->n_chains * sizeof(float)) /* records of BR_FLOATS + the fp64 MIS tails, device_bdpt.h */ != hipSuccess ||
+        if (ctx->d_bd_verts.alloc(((size_t) (20 + 2) * nvs + 2 * ((size_t) cfg->max_depth + 2)) * ctx->n_chains * sizeof(float)) /* records of BR_FLOATS, the fp64 MIS tails, the s = 1 emitter samples: device_bdpt.h */ != hipSuccess ||
             ctx->d_bd_lists.alloc((size_t) 3 * rows * ctx->n_chains * sizeof(float)) != hipSuccess)
             return bail(ctx, "device allocation of the bdpt workspace failed");
         if (hipMemset(ctx->d_bd_lists.p, 0, (size_t) 3 * rows * ctx->n_chains * sizeof(float)) != hipSuccess) return bail(ctx, "hipMemset of the bdpt workspace failed");
