@@ -56,6 +56,30 @@ def test_two_contexts_equal_one_context_with_twice_the_chains(pkg, kw, native_li
     assert (img2 @ LUMW).mean() == pytest.approx(b_big, rel=1e-5)
 
 
+@pytest.mark.parametrize("kw", [dict(technique="bdpt", max_depth=6, no_direct_sampling=1), dict(technique="bdpt", max_depth=8, no_direct_sampling=0), dict(technique="mmlt", max_depth=6), dict()],
+                         ids=["bdpt-nodirect", "bdpt-direct", "mmlt", "path"])
+def test_a_chain_does_not_depend_on_its_wave_neighbours(pkg, kw, native_lib):
+    """A RAGGED split of one pool (chains [0, 100) and [100, 356)): every chain of the second context sits in another lane, beside
+    other chains, than in the one-context run -- and must end in the same state bit for bit. (bdpt hands the connections of all
+    the chains of a wave out to all of its lanes and sums a chain's contributions by a segmented scan: the scan's tree depends on
+    the chain's own cell count alone, which is what this test holds it to.)"""
+    sd = pkg.scenes.glass_sphere(32)
+    n_a, n_b, per_chain = 100, 256, 48
+    total = n_a + n_b
+    big = pkg.Context(_cfg(pkg, total, **kw), sd)
+    big.seed_pool(0xBEEF, 0, total)
+    big.run(total * per_chain)
+    a, b = pkg.Context(_cfg(pkg, n_a, **kw), sd), pkg.Context(_cfg(pkg, n_b, **kw), sd)
+    a.seed_pool(0xBEEF, 0, total); b.seed_pool(0xBEEF, n_a, total)
+    a.run(n_a * per_chain); b.run(n_b * per_chain)
+    dim = big.stats().max_dim if kw.get("technique") == "bdpt" else (27 if kw.get("technique") == "mmlt" else 34)
+    (cb_, ub), (ca, ua), (cbb, ubb) = big.chain_state(dim), a.chain_state(dim), b.chain_state(dim)
+    assert np.array_equal(ub[:n_a], ua) and np.array_equal(ub[n_a:], ubb)
+    assert np.array_equal(cb_["luminance"][:n_a], ca["luminance"]) and np.array_equal(cb_["luminance"][n_a:], cbb["luminance"])
+    sa, sb, sbig = a.stats(), b.stats(), big.stats()
+    assert sa.accepted + sb.accepted == sbig.accepted and sa.rays + sb.rays == sbig.rays
+
+
 def test_node_with_two_ranks_on_one_gpu_equals_single_context(pkg, native_lib, monkeypatch):
     """drmlt_node_* with two ranks (both on GPU 0: loopback transport for the reduce-scatter arithmetic): seed pool,
     threaded run, tiled develop, summed stats == one context with twice the chains."""
