@@ -541,7 +541,11 @@ drmlt_ctx *drmlt_create(const drmlt_config *cfg, const drmlt_scene *scene, int d
     const bool v5_forced = getenv("DRMLT_KERNEL") && atoi(getenv("DRMLT_KERNEL")) == 5;
     if (P.kernel_variant == 5 && !P.use_bvh && !v5_forced && ctx->n_chains < 98304u) P.kernel_variant = 4;
     // (v5 on the Cornell scene, 131 072 chains: batch 16 1.98e9, 24 2.08e9, 32 2.13e9, 48 1.84e9; on the soup: 8 5.05e8, 16 5.24e8, 32 5.06e8)
-    P.mh_batch = P.kernel_variant == 5 ? (P.use_bvh ? 16 : 32) : (P.kernel_variant == 4 ? (P.use_bvh ? (P.bvh_stack16 ? 6 : 4) : (P.features == 0 ? 12 : 8)) : 32); // v4 / v5: chains run free, the bookkeeping branch fires as soon as a few are parked
+    // A scene whose nodes and records exceed the L2 caches (8 x 4 MB) is traversed against memory latency: the ray pool then wants
+    // SHORT phases -- chains step and refill it as soon as a few rays are done (1 000 000 triangles, 2-step calls: yield x batch
+    // 20 x 16 6.9e7, 12 x 8 7.5e7, 8 x 8 7.7e7, 4 x 8 7.7e7 mutations/s; 50 000 triangles, in the L2s: 2.82e8 / 2.75e8 / 2.61e8)
+    const bool beyond_l2 = P.use_bvh && (size_t) P.n_bvh_nodes * sizeof(DBvh4Node) + ctx->prims.size() * sizeof(DPrim) > (size_t) 32 << 20;
+    P.mh_batch = P.kernel_variant == 5 ? (P.use_bvh ? (beyond_l2 ? 8 : 16) : 32) : (P.kernel_variant == 4 ? (P.use_bvh ? (P.bvh_stack16 ? 6 : 4) : (P.features == 0 ? 12 : 8)) : 32); // v4 / v5: chains run free, the bookkeeping branch fires as soon as a few are parked
     if (const char *k = getenv("DRMLT_MH_BATCH")) P.mh_batch = std::max(1, std::min(64, atoi(k)));
     P.bvh_overflow = nullptr; P.bvh_ovf_lanes = 0;
     P.exec_order = nullptr;
@@ -549,7 +553,7 @@ drmlt_ctx *drmlt_create(const drmlt_config *cfg, const drmlt_scene *scene, int d
     // stacks, longer traversals): 20 1.90e8, 24 1.86e8, 28 1.79e8; bookkeeping batch there 4 1.89e8, 6 1.86e8, 8 1.82e8
     // k_mutate_v5 (131 072 chains, 3-step calls) on the soup: yield x bookkeeping batch -- 12: 4.84 / 5.13 / 5.12e8 (batch 8 / 16 / 28),
     // 16: 5.08 / 5.37 / 5.20, 20: 5.25 / 5.44 / 5.10, 24: 5.31 / 5.40 / 4.81
-    P.trace_yield = P.kernel_variant == 5 ? 20 : (P.bvh_stack16 ? 24 : 20);
+    P.trace_yield = P.kernel_variant == 5 ? (beyond_l2 ? 8 : 20) : (P.bvh_stack16 ? 24 : 20);
     if (const char *k = getenv("DRMLT_TRACE_YIELD")) P.trace_yield = std::max(0, std::min(64, atoi(k)));
     P.pool_refill = 8; // soup, 131 072 chains: 1 5.38e8, 2 5.41e8, 4 5.43e8, 8 5.45e8, 16 5.37e8 mutations/s
     if (const char *k = getenv("DRMLT_POOL_REFILL")) P.pool_refill = std::max(1, std::min(64, atoi(k)));
