@@ -130,3 +130,37 @@ def test_refusals(pkg, native_lib):
     ctx = pkg.Context(pkg.abi.make_config(technique="bdpt", max_depth=5, work_units=64, no_direct_sampling=1), sd)
     with pytest.raises(pkg.DrmltError, match="drmlt_eval_lists"):
         ctx.eval_paths(np.zeros((4, 64), dtype=np.float32))
+
+
+@pytest.mark.parametrize("tech", ["bdpt", "mmlt"])
+def test_bvh_builds_of_the_bidirectional_kernels_run_the_same_chains(pkg, tech, native_lib, monkeypatch, capfd):
+    """Scenes above the BVH threshold run other builds of the bidirectional kernels (traversal with its LDS stack instead of
+    the brute-force loop -- in bdpt's connection phase under per-cell control flow): forcing the BVH onto a small scene must
+    leave every chain where the flat build puts it, bit for bit (the same intersection routines find the same hits)."""
+    sd = pkg.scenes.glass_sphere(32)
+    n_chains, n_mut = 1000, 40
+    kw = dict(technique=tech, type="orbital", max_depth=6, rr_depth=4, direct_samples=-1, luminance_samples=20000, work_units=n_chains, sample_count=1)
+    if tech == "bdpt":
+        kw["no_direct_sampling"] = 0
+    cfg = pkg.abi.make_config(**kw)
+    res = []
+    for thr in (None, "0"):
+        if thr is None:
+            monkeypatch.delenv("DRMLT_BVH_THRESHOLD", raising=False)
+        else:
+            monkeypatch.setenv("DRMLT_BVH_THRESHOLD", thr)
+        monkeypatch.setenv("DRMLT_VERBOSE", "1")
+        capfd.readouterr()
+        ctx = pkg.Context(cfg, sd)
+        built_bvh = "[drmlt] BVH:" in capfd.readouterr().err
+        monkeypatch.delenv("DRMLT_VERBOSE")
+        ctx.seed(0xB7)
+        ctx.run(n_chains * n_mut)
+        st = ctx.stats()
+        res.append((ctx.chain_state(st.max_dim if tech == "bdpt" else 27), st, ctx.film(), built_bvh))
+        ctx.close()
+    ((cf, uf), sf, ff, bvh_f), ((cb, ub), sb, fb, bvh_b) = res
+    assert not bvh_f and bvh_b
+    assert np.array_equal(ub, uf) and np.array_equal(cb["luminance"], cf["luminance"])
+    assert sb.accepted == sf.accepted and sb.rays == sf.rays and sb.path_evals == sf.path_evals
+    assert lum(fb).sum() == pytest.approx(lum(ff).sum(), rel=1e-5)
