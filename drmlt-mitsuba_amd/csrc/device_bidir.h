@@ -454,10 +454,13 @@ DEV void eval_mmlt(const DParams &P, const TablesT &T, MSampler &smp, int depth,
     else vs = cur;
     if (s >= 1 && !vs.degenerate) conn |= 1u << s;
     if (!vt.degenerate) conn |= 1u << (s + 1);
-    // "Check if subpaths are connectable", pathsampler.cpp:161-173: vertices 2 .. k-2
+    // "Check if subpaths are connectable", pathsampler.cpp:161-173: emitter vertices 2 .. s and sensor vertices 2 .. t, i.e.
+    // positions 2 .. k - 2 -- and position 1 when s = 0, where the sensor subpath's LAST vertex sits (the emitter it has hit: a
+    // camera path that reaches a light over specular vertices only, E S* L, is kept by that vertex)
     {
         uint32_t inner = 0u;
         if (k - 2 >= 2) inner = ((1u << (k - 1)) - 1u) & ~3u;
+        if (s == 0) inner |= 2u;
         if ((conn & inner) == 0u) return;
     }
 

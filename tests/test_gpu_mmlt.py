@@ -52,6 +52,44 @@ def test_eval_matches_oracle(pkg, ob, name, native_lib):
     assert total_g == pytest.approx(total_o, rel=5e-3)
 
 
+def _glint_scene(pkg, res=64):
+    """A big glass sphere in front of the camera under a big ceiling light: camera -> sphere (reflection) -> light is a common path."""
+    S = pkg.scenes
+    sd = S.SceneData("glint")
+    white, red, green, black = sd.diffuse(0.725, 0.71, 0.68), sd.diffuse(0.63, 0.065, 0.05), sd.diffuse(0.14, 0.45, 0.091), sd.diffuse(0.0)
+    glass = sd.dielectric(1.5, 1.0)
+    S._room(sd, white, red, green)
+    sd.sphere((0.0, -0.2, 0.6), 0.6, glass)
+    sd.rectangle(S.translate(0, 0.995, 0) @ S.rotate("x", 90) @ S.scale(0.7), black, radiance=10.0)
+    sd.set_camera(S.lookat((0, 0, 3.9), (0, 0, 0), (0, 1, 0)), 39.3077, res, res, pkg.abi.FILTER_BOX, 0.5)
+    return sd
+
+
+def test_camera_paths_that_reach_a_light_over_specular_vertices_only(pkg, ob, native_lib):
+    """s = 0 with nothing but specular vertices between the camera and the emitter it hits (E S* L: the glint of a light on a
+    glass sphere): the reference's "subpaths are connectable" test (pathsampler.cpp:161-173) runs over the sensor vertices 2 .. t
+    INCLUDING the last one, which lies on the emitter and is connectable -- such paths count. (Until round 3 the device tested
+    positions 2 .. k - 2 only and dropped them: on config 5's scene that is a two-pixel glint at 64 x 64, found by the N = 64
+    parity protocol's permutation test.)"""
+    sd = _glint_scene(pkg)
+    cfg, ctx, orc = make(pkg, ob, sd, type="orbital", work_units=64)
+    rng = np.random.default_rng(21)
+    n = 1 << 17
+    us, ue = rng.random((n, 14), dtype=np.float32), rng.random((n, 14), dtype=np.float32)
+    for depth in (2, 3, 4):
+        ud = (rng.random(n, dtype=np.float32) * np.float32(0.999 / (depth + 1)))      # s = int((depth + 1) * u) = 0: pure camera paths
+        g, stg = ctx.eval_paths_mmlt(depth, us, ue, ud)
+        o, sto = orc.mmlt_eval(depth, us, ue, ud)
+        assert (sto[:, 0] == 0).all() and (stg[:, 0] == 0).all()
+        hit = o["luminance"] > 0
+        assert hit.sum() > 1000
+        both = hit & (g["luminance"] > 0)
+        assert both.sum() >= 0.998 * hit.sum(), (depth, both.sum(), hit.sum())          # (the unfixed kernel: 0.98 at depth 2)
+        rel = np.abs(g["luminance"] - o["luminance"])[both] / o["luminance"][both]
+        assert np.quantile(rel, 0.99) < 5e-3
+        assert g["luminance"].sum() == pytest.approx(o["luminance"].sum(), rel=3e-3)
+
+
 def test_bootstrap_and_seed_replay(pkg, ob, native_lib):
     sd = pkg.scenes.glass_sphere(64)
     cfg, ctx, orc = make(pkg, ob, sd, type="orbital", work_units=2048, sample_count=1, luminance_samples=1000)

@@ -55,6 +55,8 @@ def main():
     ap.add_argument("--ref-samples-per-pixel", type=int, default=8192, help="oracle BDPT samples per pixel (bdpt / mmlt)")
     ap.add_argument("--chains", type=int, default=4096)
     ap.add_argument("--threads", type=int, default=os.cpu_count() or 8)
+    ap.add_argument("--oracle-precision", type=int, default=64, choices=(32, 64), help="the oracle chains' arithmetic: 64 = the reference's default build, 32 = its SINGLE_PRECISION build (Epsilon 1e-4 / ShadowEpsilon 1e-3, as the device)")
+    ap.add_argument("--save-means", default="", help=".npz: the two sides' mean images, the reference and every render's luminance estimate b")
     ap.add_argument("--out", default="")
     a = ap.parse_args()
     conf = CONFIGS[a.config]
@@ -89,20 +91,22 @@ def main():
     ref = 0.5 * (ref_a.astype(np.float64) + ref_b.astype(np.float64))
     ref_noise = rel_mse(ref_a, ref_b) / 4.0            # Var(mean of halves) = Var(difference) / 4
     print("reference: %s, own rMSE %.3g (%.0f s)" % (ref_what, ref_noise, time.time() - t0), flush=True)
-    gpu, orc = [], []
+    gpu, orc, b_gpu, b_orc = [], [], [], []
     t_gpu = t_orc = 0.0
     for i in range(a.n):
         t = time.time()
         c = pkg.Context(cfg, sd)
-        c.seed(1000 + i); c.run(total); gpu.append(c.develop().astype(np.float64)); c.close()
+        b_gpu.append(c.seed(1000 + i)); c.run(total); gpu.append(c.develop().astype(np.float64)); c.close()
         t_gpu += time.time() - t
         t = time.time()
-        o = ob.Oracle(abi, cfg, sd, precision=64, native=True)
-        o.seed(501000 + i); o.run(total, a.threads); orc.append(o.develop().astype(np.float64)); o.close()
+        o = ob.Oracle(abi, cfg, sd, precision=a.oracle_precision, native=True)
+        b_orc.append(o.seed(501000 + i)); o.run(total, a.threads); orc.append(o.develop().astype(np.float64)); o.close()
         t_orc += time.time() - t
         print("render %d/%d  gpu rMSE %.4g  oracle rMSE %.4g  (%.0f s)" % (i + 1, a.n, rel_mse(gpu[-1], ref), rel_mse(orc[-1], ref), time.time() - t0), flush=True)
     gpu, orc = np.array(gpu), np.array(orc)
     N = a.n
+    if a.save_means:
+        np.savez(a.save_means, gpu_mean=gpu.mean(0), orc_mean=orc.mean(0), gpu_var=gpu.var(0, ddof=1), orc_var=orc.var(0, ddof=1), ref=ref, b_gpu=np.array(b_gpu), b_orc=np.array(b_orc))
     mg, mo = gpu.mean(0), orc.mean(0)
     pooled = 0.5 * (mg + mo)
     # (2) per-render noise about the side's own mean (unbiased: x N / (N - 1)), measured with the pooled mean as denominator image
@@ -113,6 +117,16 @@ def main():
     # (1) two-sample: rMSE between the two means vs what two unbiased estimators of one image would show
     between = rel_mse(mg - mo + pooled, pooled)
     expected = (sg.mean() + so.mean()) / N
+    # ... and the same statistic under the null hypothesis, by permutation: the 2N renders dealt into two groups of N at random. MLT noise
+    # is heavy-tailed (a chain parked on a caustic), so the ratio's spread about 1 is wide: the p-value says where the observed one sits
+    rng = np.random.default_rng(12345)
+    both = np.concatenate([gpu, orc])
+    null = []
+    for _ in range(400):
+        idx = rng.permutation(2 * N)
+        null.append(rel_mse(both[idx[:N]].mean(0) - both[idx[N:]].mean(0) + pooled, pooled))
+    null = np.array(null)
+    p_value = float((null >= between).mean())
     # (3) against the reference
     single_g = np.array([rel_mse(x, ref) for x in gpu]); single_o = np.array([rel_mse(x, ref) for x in orc])
     ns = [n for n in (1, 2, 4, 8, 16, 32) if n <= N]
@@ -130,9 +144,11 @@ def main():
     out = {
         "command": "python tools/parity_protocol.py " + " ".join(sys.argv[1:]),
         "scene": "%s %dx%d: %s, %d chains, %d mutations/pixel per render" % (conf["scene"], a.res, a.res, conf["what"], a.chains, a.spp),
-        "n_renders": N, "seeds": "device 1000 + i, oracle 501000 + i (independent estimators)",
+        "n_renders": N, "seeds": "device 1000 + i, oracle 501000 + i (independent estimators)", "oracle_chain_precision": a.oracle_precision,
         "reference": "%s; residual rMSE of the reference itself %.3g" % (ref_what, ref_noise),
         "two_sample": {"rmse_between_means": between, "expected_if_same_expectation": expected, "ratio": between / expected,
+                       "permutation_test": {"n_permutations": 400, "p_value": p_value, "null_median": float(np.median(null)), "null_95th_percentile": float(np.quantile(null, 0.95)),
+                                            "note": "the statistic recomputed with the 2N renders dealt at random into two groups: p = share of deals with a distance at least the observed one"},
                        "note": "ratio ~ 1: the two means differ by no more than their own noise; a bias as large as one render's noise would give ~ %d" % N},
         "noise_single_render_about_own_mean": {"gpu_mean": float(sg.mean()), "gpu_std": float(sg.std(ddof=1)), "oracle_mean": float(so.mean()), "oracle_std": float(so.std(ddof=1))},
         "equal_budget_relative_difference": float(equal_budget), "equal_budget_standard_error": equal_budget_se, "equal_budget_bound": 0.10,
@@ -144,7 +160,7 @@ def main():
         "noise_median_single_render": {"gpu": float(np.median(sg)), "oracle": float(np.median(so)),
                                        "relative_difference_of_medians": float((np.median(sg) - np.median(so)) / np.median(so))},
         "budget_mutations_per_pixel_where_both_meet_1e-3": (min(meet) if meet else None),
-        "summary": {"config": a.config, "two_sample_ratio": between / expected, "equal_budget_rel_diff": float(equal_budget), "equal_budget_se": equal_budget_se,
+        "summary": {"config": a.config, "two_sample_ratio": between / expected, "two_sample_permutation_p": p_value, "equal_budget_rel_diff": float(equal_budget), "equal_budget_se": equal_budget_se,
                     "equal_budget_rel_diff_of_medians": float((np.median(sg) - np.median(so)) / np.median(so)),
                     "bound": 0.10, "slope_gpu": slope(cg), "slope_oracle": slope(co),
                     "slope_gpu_vs_oracle_mean": slope_x(xg, so.mean() / N), "slope_oracle_vs_gpu_mean": slope_x(xo, sg.mean() / N),
