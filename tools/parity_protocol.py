@@ -37,6 +37,11 @@ CONFIGS = {
                what="glass caustic, drmlt technique=mmlt type=orbital fixEmitterPath, RADIANCE output (BASELINE configs[4] without acceptanceMap)"),
     "bdpt": dict(scene="cornell_c2", cfg=dict(technique="bdpt", type="orbital", max_depth=8, rr_depth=5), ref="bdpt",
                  what="Cornell box, drmlt technique=bdpt type=orbital, directSampling=true"),
+    # the specular scene under the other two techniques (glints, caustics: what the Cornell box cannot show)
+    "path_c5": dict(scene="caustic_c5", cfg=dict(technique="path", type="orbital", max_depth=6, rr_depth=5), ref="pt",
+                    what="glass caustic scene, drmlt technique=path type=orbital"),
+    "bdpt_c5": dict(scene="caustic_c5", cfg=dict(technique="bdpt", type="orbital", max_depth=6, rr_depth=5), ref="bdpt",
+                    what="glass caustic scene, drmlt technique=bdpt type=orbital, directSampling=true"),
 }
 
 
@@ -56,6 +61,7 @@ def main():
     ap.add_argument("--chains", type=int, default=4096)
     ap.add_argument("--threads", type=int, default=os.cpu_count() or 8)
     ap.add_argument("--oracle-precision", type=int, default=64, choices=(32, 64), help="the oracle chains' arithmetic: 64 = the reference's default build, 32 = its SINGLE_PRECISION build (Epsilon 1e-4 / ShadowEpsilon 1e-3, as the device)")
+    ap.add_argument("--seed-offset", type=int, default=0, help="added to every chain seed: an independent repetition of the whole protocol")
     ap.add_argument("--save-means", default="", help=".npz: the two sides' mean images, the reference and every render's luminance estimate b")
     ap.add_argument("--out", default="")
     a = ap.parse_args()
@@ -96,11 +102,11 @@ def main():
     for i in range(a.n):
         t = time.time()
         c = pkg.Context(cfg, sd)
-        b_gpu.append(c.seed(1000 + i)); c.run(total); gpu.append(c.develop().astype(np.float64)); c.close()
+        b_gpu.append(c.seed(1000 + a.seed_offset + i)); c.run(total); gpu.append(c.develop().astype(np.float64)); c.close()
         t_gpu += time.time() - t
         t = time.time()
         o = ob.Oracle(abi, cfg, sd, precision=a.oracle_precision, native=True)
-        b_orc.append(o.seed(501000 + i)); o.run(total, a.threads); orc.append(o.develop().astype(np.float64)); o.close()
+        b_orc.append(o.seed(501000 + a.seed_offset + i)); o.run(total, a.threads); orc.append(o.develop().astype(np.float64)); o.close()
         t_orc += time.time() - t
         print("render %d/%d  gpu rMSE %.4g  oracle rMSE %.4g  (%.0f s)" % (i + 1, a.n, rel_mse(gpu[-1], ref), rel_mse(orc[-1], ref), time.time() - t0), flush=True)
     gpu, orc = np.array(gpu), np.array(orc)
@@ -144,7 +150,7 @@ def main():
     out = {
         "command": "python tools/parity_protocol.py " + " ".join(sys.argv[1:]),
         "scene": "%s %dx%d: %s, %d chains, %d mutations/pixel per render" % (conf["scene"], a.res, a.res, conf["what"], a.chains, a.spp),
-        "n_renders": N, "seeds": "device 1000 + i, oracle 501000 + i (independent estimators)", "oracle_chain_precision": a.oracle_precision,
+        "n_renders": N, "seeds": "device %d + i, oracle %d + i (independent estimators)" % (1000 + a.seed_offset, 501000 + a.seed_offset), "oracle_chain_precision": a.oracle_precision,
         "reference": "%s; residual rMSE of the reference itself %.3g" % (ref_what, ref_noise),
         "two_sample": {"rmse_between_means": between, "expected_if_same_expectation": expected, "ratio": between / expected,
                        "permutation_test": {"n_permutations": 400, "p_value": p_value, "null_median": float(np.median(null)), "null_95th_percentile": float(np.quantile(null, 0.95)),
