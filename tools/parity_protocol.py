@@ -63,9 +63,21 @@ def main():
     ap.add_argument("--oracle-precision", type=int, default=64, choices=(32, 64), help="the oracle chains' arithmetic: 64 = the reference's default build, 32 = its SINGLE_PRECISION build (Epsilon 1e-4 / ShadowEpsilon 1e-3, as the device)")
     ap.add_argument("--seed-offset", type=int, default=0, help="added to every chain seed: an independent repetition of the whole protocol")
     ap.add_argument("--save-means", default="", help=".npz: the two sides' mean images, the reference and every render's luminance estimate b")
+    ap.add_argument("--scene", default="", help="override the configuration's scene (a name of drmlt-mitsuba_amd/scenes.py: SCENES)")
+    ap.add_argument("--set", default="", help="override configuration fields: k=v,k=v (make_config names, e.g. technique=mmlt,type=green,use_mixture=1)")
+    ap.add_argument("--no-reference", action="store_true", help="skip the independent reference (two-sample statistics only; the slopes against it are then meaningless)")
     ap.add_argument("--out", default="")
     a = ap.parse_args()
-    conf = CONFIGS[a.config]
+    conf = dict(CONFIGS[a.config])
+    conf["cfg"] = dict(conf["cfg"])
+    if a.scene:
+        conf["scene"] = a.scene
+    for kv in filter(None, a.set.split(",")):
+        k, v = kv.split("=")
+        conf["cfg"][k] = v if not v.lstrip("-").replace(".", "", 1).isdigit() else (float(v) if "." in v else int(v))
+    if a.scene or a.set:
+        conf["what"] = "%s with scene %s and %s" % (a.config, conf["scene"], conf["cfg"])
+        conf["ref"] = {"path": "pt", "bdpt": "bdpt", "mmlt": "mmlt"}[conf["cfg"].get("technique", "path")]
     pkg, ob = g.load_package(), g.load_oracle()
     ob.build(native=True)   # -O3 -march=native build of the restatement for this host
     abi = pkg.abi
@@ -74,7 +86,10 @@ def main():
     cfg = abi.make_config(**kw)
     total = a.res * a.res * a.spp
     t0 = time.time()
-    if conf["ref"] == "pt":
+    if a.no_reference:
+        ref_a = ref_b = None
+        ref_what = "none"
+    elif conf["ref"] == "pt":
         ref_ctx = pkg.Context(cfg, sd)
         half = a.ref_spp // 2
         ref_a, ref_b = ref_ctx.render_pt(half, seed=101), ref_ctx.render_pt(half, seed=202)
@@ -94,6 +109,8 @@ def main():
         ref_b = sum(ro.mmlt_render(d, nsamp, seed=202 + d, nthreads=a.threads)[0].astype(np.float64) for d in range(1, md + 1))
         ro.close()
         ref_what = "oracle's independent-sample multiplexed estimator summed over depths 1..%d (fp64, CPU), 2 x %d samples per pixel and depth" % (md, a.ref_samples_per_pixel // 2)
+    if a.no_reference:   # stand-in so that the per-render progress lines mean something: the first device render
+        c = pkg.Context(cfg, sd); c.seed(77); c.run(4 * total); ref_a = ref_b = c.develop().astype(np.float64); c.close()
     ref = 0.5 * (ref_a.astype(np.float64) + ref_b.astype(np.float64))
     ref_noise = rel_mse(ref_a, ref_b) / 4.0            # Var(mean of halves) = Var(difference) / 4
     print("reference: %s, own rMSE %.3g (%.0f s)" % (ref_what, ref_noise, time.time() - t0), flush=True)
