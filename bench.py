@@ -52,7 +52,7 @@ CONFIGS = {
                    "%(chains)d chains/GPU, sampleCount %(spp)d (BASELINE.json configs[2])"),
     # 262 144 chains: k_mutate_mmlt runs one chain per lane at 256 VGPRs, so 65 536 chains are 1024 waves = one per SIMD
     # (7.3e8 mutations/s); 131 072 put two on a SIMD (1.3e9); 262 144 are two ROUNDS of such waves, and with the chains run in
-    # order of their depth the shallow waves' slots are re-used while the deep ones still run (2.1e9; 2.6e9 since its chains run free). BASELINE's config 5
+    # order of their depth the shallow waves' slots are re-used while the deep ones still run (2.1e9; 2.5e9 since its chains run free). BASELINE's config 5
     # does not fix the chain count.
     "5": dict(scene=("caustic_c5", {}), res=512, chains=262144,
               cfg=dict(technique="mmlt", type="orbital", max_depth=6, fix_emitter_path=1, acceptance_map=1), spp=256,

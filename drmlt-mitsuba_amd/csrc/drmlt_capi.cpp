@@ -691,6 +691,7 @@ static int seed_impl(drmlt_ctx *ctx, uint64_t seed, uint32_t chain_offset, uint3
     if (ctx->cfg.acceptance_map) ctx->b = 1.0;                                       // drmlt.cpp:550-552
     else if (ctx->cfg.average_luminance != -1.0f) ctx->b = ctx->cfg.average_luminance; // drmlt.cpp:555-558
     ctx->seeded = true;
+    ctx->regrouped = false;
     ctx->mutation_base = 0;
     HIP_TRY(ctx, hipMemsetAsync(ctx->d_done.p, 0, ctx->d_done.bytes, ctx->stream));
     if (b_out) *b_out = ctx->b;
@@ -796,6 +797,32 @@ int drmlt_set_luminance(drmlt_ctx *ctx, double b) {
     return DRMLT_OK;
 }
 
+// k_mutate_mmlt's waves are made of chains of one depth (seed_impl); between the launches of a call they are ALSO regrouped by the
+// work of the launch just done. Chains run free (one path evaluation per lane per pass), so a wave lasts as long as its slowest
+// chain, and a chain parked on a glint or a caustic rejects nearly every first stage: two evaluations per mutation, launch after
+// launch. Sorted by (depth, evaluations of the last launch), such chains share waves -- full ones, run first -- instead of holding
+// sixty-three finished lanes each (config 5 with the E S* L paths counted: 2.33e9 -> see DESIGN 7a). Chain ids, states and
+// streams are untouched: the same chains bit for bit, in other lanes. Counting sort, stable: deterministic.
+static int regroup_mmlt(drmlt_ctx *ctx, uint32_t n_mut) {
+    const uint32_t n = ctx->n_chains, padded = (n + 63u) / 64u * 64u, md = (uint32_t) ctx->cfg.max_depth, B = 16u;
+    std::vector<uint32_t> work(n);
+    HIP_TRY(ctx, hipMemcpyAsync(work.data(), ctx->d_done.p, (size_t) n * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    std::vector<uint32_t> start(md * B + 1u, 0u), key(n), order(padded, n);
+    for (uint32_t j = 0; j < n; ++j) {
+        const uint32_t d = ctx->seed_indices[j] % md;                     // deepest first, as at seed time
+        const uint32_t extra = work[j] > n_mut ? work[j] - n_mut : 0u;    // second stages and reverse moves
+        const uint32_t b = std::min<uint32_t>(B - 1u, (uint32_t) ((uint64_t) extra * B / std::max(1u, n_mut)));
+        key[j] = (md - 1u - d) * B + (B - 1u - b);
+        ++start[key[j] + 1u];
+    }
+    for (uint32_t k = 0; k < md * B; ++k) start[k + 1u] += start[k];
+    for (uint32_t j = 0; j < n; ++j) order[start[key[j]]++] = j;
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_order.p, order.data(), order.size() * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); // `order` is a local
+    return DRMLT_OK;
+}
+
 // waves of a chain-kernel launch: k_mutate_v4 carries 32 chains per wave (lane pairs), k_mutate_v5 64
 static uint32_t chain_waves(const drmlt_ctx *ctx) { return ctx->P.kernel_variant == 5 ? (ctx->n_chains + 63u) / 64u : (ctx->n_chains + 31u) / 32u; }
 
@@ -818,11 +845,12 @@ int drmlt_run(drmlt_ctx *ctx, uint64_t total_mutations, volatile int *stop, drml
     const bool ahead = ctx->cfg.technique == DRMLT_TECH_PATH && ctx->cfg.algo != DRMLT_ALGO_PSSMLT && ctx->P.kernel_variant >= 4 &&
                        !getenv("DRMLT_NO_RUN_AHEAD");
     const uint64_t call_base = ctx->mutation_base, call_end = call_base + per_chain;
+    const bool regroup = ctx->cfg.technique == DRMLT_TECH_MMLT && ctx->cfg.algo != DRMLT_ALGO_PSSMLT && ctx->P.exec_order && !getenv("DRMLT_MMLT_NO_REGROUP");
     while (done < per_chain) {
         if (stop && *stop) { rc = DRMLT_E_CANCELLED; break; }
         if (timed && std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count() >= (double) ctx->cfg.timeout_s) break;
         // shorter launches when somebody is watching (cancellation / progress / deadline latency ~ tens of ms)
-        const uint64_t slice = (stop || cb || timed) ? std::min(ctx->slice, 256) : ctx->slice;
+        const uint64_t slice = (stop || cb || timed) ? std::min(ctx->slice, 256) : (regroup && !ctx->regrouped ? std::min(ctx->slice, getenv("DRMLT_REGROUP_FIRST") ? atoi(getenv("DRMLT_REGROUP_FIRST")) : 256) : ctx->slice); // (regrouping: a short first launch, to learn which chains are parked)
         uint32_t n = (uint32_t) std::min<uint64_t>(slice, per_chain - done);
         evs.emplace_back();
         EventPair &ev = evs.back();
@@ -831,7 +859,11 @@ int drmlt_run(drmlt_ctx *ctx, uint64_t total_mutations, volatile int *stop, drml
         ctx->P.luminance_b = (float) ctx->b;
         HIP_TRY(ctx, ensure_overflow(ctx, ctx->P, 2 * (size_t) ctx->P.n_chains_alloc + 128));
         if (ctx->cfg.algo == DRMLT_ALGO_PSSMLT) launch_mutate_pssmlt(ctx->P, n, ctx->mutation_base, ctx->stream);
-        else if (ctx->cfg.technique == DRMLT_TECH_MMLT) launch_mutate_mmlt(ctx->P, n, ctx->mutation_base, ctx->stream);
+        else if (ctx->cfg.technique == DRMLT_TECH_MMLT) {
+            DParams Q = ctx->P;
+            if (regroup) Q.chain_done = ctx->d_done.as<uint32_t>(); // per-chain evaluation counts of this launch
+            launch_mutate_mmlt(Q, n, ctx->mutation_base, ctx->stream);
+        }
         else if (ctx->cfg.technique == DRMLT_TECH_BDPT) launch_mutate_bdpt(ctx->P, n, ctx->mutation_base, ctx->stream);
         else if (ahead) {
             DParams Q = ctx->P;
@@ -846,6 +878,7 @@ int drmlt_run(drmlt_ctx *ctx, uint64_t total_mutations, volatile int *stop, drml
         ctx->mutation_base += n;
         done += n;
         ctx->launches++;
+        if (regroup) { const int rr = regroup_mmlt(ctx, n); if (rr != DRMLT_OK) return rr; ctx->regrouped = true; }
         if (stop || cb || timed) {
             HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
             if (cb) cb(done * ctx->n_chains, per_chain * ctx->n_chains, user);

@@ -99,7 +99,7 @@ template <int FEAT> __global__ void __launch_bounds__(CHAIN_BLOCK, 2) k_mutate_m
     // Chains run free: every pass of the loop evaluates ONE path per lane -- the first stage of the lane's next mutation, or the
     // second stage / Green's reverse move of the one it is in. (In a lockstep loop over mutations with the stages inside, the few
     // lanes in sixty-four that go to a second stage -- 8 % of the mutations -- cost the wave a whole second pass nearly every time.)
-    uint32_t it = 0u;
+    uint32_t it = 0u, work = 0u; // work: path evaluations of this launch (the host groups chains of similar work into waves, drmlt_capi.cpp)
     int stage = 0;
     DSplat y, z;
     y.lum = 0.f; y.px = y.py = y.r = y.g = y.b = 0.f;
@@ -124,6 +124,7 @@ template <int FEAT> __global__ void __launch_bounds__(CHAIN_BLOCK, 2) k_mutate_m
             smp.mode = stage == 0 ? SM_STAGE1 : (stage == 1 ? SM_STAGE2 : SM_REVERSE);
             MmltResult R;
             eval_mmlt<FEAT>(P, T, smp, depth, NX, R);
+            ++work;
             ct.rays += R.nrays;
             DSplat res = R.splat;
             normalize_splat(res, P);
@@ -200,6 +201,7 @@ template <int FEAT> __global__ void __launch_bounds__(CHAIN_BLOCK, 2) k_mutate_m
         P.cur_lum[c] = cur.lum; P.cur_px[c] = cur.px; P.cur_py[c] = cur.py;
         P.cur_r[c] = cur.r; P.cur_g[c] = cur.g; P.cur_b[c] = cur.b;
         P.cur_t[c] = cur_t;
+        if (P.chain_done) P.chain_done[c] = work; // (this kernel has no run-ahead: the array is free for the count)
     }
     flush_counters(P, ct, lane);
 }
