@@ -82,7 +82,8 @@ def main():
     ob.build(native=True)   # -O3 -march=native build of the restatement for this host
     abi = pkg.abi
     sd = pkg.scenes.SCENES[conf["scene"]](res=a.res)
-    kw = dict(direct_samples=-1, work_units=a.chains, sample_count=a.spp, luminance_samples=100000, **conf["cfg"])
+    kw = dict(direct_samples=-1, work_units=a.chains, sample_count=a.spp, luminance_samples=100000)
+    kw.update(conf["cfg"])
     cfg = abi.make_config(**kw)
     total = a.res * a.res * a.spp
     t0 = time.time()

@@ -25,3 +25,18 @@ case $1 in
 5) run door_bdpt_fp32oracle --config bdpt --scene door_c3 --set max_depth=6 --oracle-precision 32 --save-means gpurun_out/door_bdpt_fp32_means.npz
    run door_bdpt_fp32oracle_rep --config bdpt --scene door_c3 --set max_depth=6 --oracle-precision 32 --seed-offset 7000;;
 esac
+case $1 in
+6) run cornell_direct16 --config c2 --set direct_samples=16
+   run door_orbital --config c3 --set type=orbital
+   run door_mira --config c3 --set type=mira
+   run glass_green --config c2 --scene glass_sphere --set type=green,max_depth=6;;
+7) run cornell_pssmlt_gauss --config c2 --set algo=1,kelemen_style_mutation=0
+   run cornell_pssmlt_noweights --config c2 --set algo=1,kelemen_style_weights=0
+   run cornell_short --config c2 --set max_depth=3,rr_depth=2,p_large=0.5
+   run glass_pssmlt --config c2 --scene glass_sphere --set algo=1,max_depth=6;;
+esac
+case $1 in
+8) run cornell_direct16 --config c2 --set direct_samples=16
+   run cornell_mmlt_direct16 --config c5 --scene cornell_c2 --set direct_samples=16,fix_emitter_path=0
+   run cornell_bdpt_mixture --config bdpt --set use_mixture=1;;
+esac
