@@ -45,6 +45,30 @@ def test_lists_match_oracle(pkg, ob, name, direct, native_lib):
     np.testing.assert_allclose(mg[:, :, 2:], mo[:, :, 2:], rtol=3e-2, atol=3e-4)
 
 
+@pytest.mark.parametrize("direct", [0, 1], ids=["nodirect", "direct"])
+def test_lists_of_deep_paths(pkg, ob, direct, native_lib):
+    """maxDepth 12 without russian roulette in a closed box: both walks run to full length, a chain has up to 90 (s, t) cells --
+    more than the 64 lanes of a connection round, so it gets rounds of its own, 64 cells at a time (device_bdpt.h) -- and 46
+    components of the direct sampler. Same lists as the oracle."""
+    sd = pkg.scenes.cornell_c2(64)
+    cfg, ctx, orc = make(pkg, ob, sd, type="orbital", work_units=256, max_depth=12, rr_depth=-1, no_direct_sampling=0 if direct else 1)
+    rng = np.random.default_rng(3)
+    n, w = 3000, 48
+    us, ue, ud = (rng.random((n, w), dtype=np.float32) for _ in range(3))
+    g, o = (ctx.eval_lists_bdpt(us, ue, ud), orc.bdpt_eval(us, ue, ud)) if direct else (ctx.eval_lists_bdpt(us, ue), orc.bdpt_eval(us, ue))
+    same = (g[:, 1] == o[:, 1]) & (g[:, 7] == o[:, 7]) & (g[:, 8] == o[:, 8]) & (g[:, 9] == o[:, 9])
+    assert same.mean() > 0.98, same.mean()
+    deep = o[:, 9] >= 80                                                        # rays: the walks and one per connected cell
+    assert deep.sum() >= 30, (deep.sum(), np.quantile(o[:, 9], [0.5, 0.9, 0.99]), o[:, 9].max())
+    assert same[deep].mean() > 0.95
+    rel = np.abs(g[:, 0] - o[:, 0])[same] / np.maximum(o[:, 0][same], 1e-3)
+    assert np.quantile(rel, 0.99) < 3e-3, np.quantile(rel, 0.99)
+    assert g[:, 0].sum() == pytest.approx(o[:, 0].sum(), rel=2e-3)
+    mg, mo = g[same][:, 10:].reshape(same.sum(), -1, 5), o[same][:, 10:].reshape(same.sum(), -1, 5)
+    np.testing.assert_allclose(mg[:, :, :2], mo[:, :, :2], atol=5e-2)
+    np.testing.assert_allclose(mg[:, :, 2:], mo[:, :, 2:], rtol=5e-2, atol=5e-4)
+
+
 def rel_full(g, o):
     return np.abs(g[:, 0] - o[:, 0]) / np.maximum(o[:, 0], 1e-3)
 
