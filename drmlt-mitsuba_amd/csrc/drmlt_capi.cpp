@@ -676,6 +676,15 @@ static int seed_impl(drmlt_ctx *ctx, uint64_t seed, uint32_t chain_offset, uint3
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); // `order` is a local
         ctx->P.exec_order = P.exec_order = ctx->d_order.as<uint32_t>();
     }
+    if (bdpt && !getenv("DRMLT_NO_REGROUP")) { // execution order of k_mutate_bdpt: identity until the first launch has told the chains' work apart (regroup_chains)
+        const uint32_t n = ctx->n_chains, padded = (n + 63u) / 64u * 64u;
+        std::vector<uint32_t> order(padded, n);
+        for (uint32_t j = 0; j < n; ++j) order[j] = j;
+        HIP_TRY(ctx, ctx->d_order.alloc(order.size() * sizeof(uint32_t)));
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->d_order.p, order.data(), order.size() * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); // `order` is a local
+        ctx->P.exec_order = P.exec_order = ctx->d_order.as<uint32_t>();
+    }
     if (mmlt) launch_init_chains_mmlt(P, d_si.as<uint32_t>(), d_sl.as<float>(), ctx->stream);
     else if (bdpt) launch_init_chains_bdpt(P, d_si.as<uint32_t>(), d_sl.as<float>(), ctx->stream);
     else launch_init_chains(P, d_si.as<uint32_t>(), d_sl.as<float>(), ctx->stream);
@@ -797,14 +806,14 @@ int drmlt_set_luminance(drmlt_ctx *ctx, double b) {
     return DRMLT_OK;
 }
 
-// k_mutate_mmlt's waves are made of chains of one depth (seed_impl); between the launches of a call they are ALSO regrouped by the
-// work of the launch just done. Chains run free (one path evaluation per lane per pass), so a wave lasts as long as its slowest
+// k_mutate_mmlt's waves are made of chains of one depth (seed_impl); between the launches of a call they -- and k_mutate_bdpt's -- are
+// ALSO regrouped by the work of the launch just done. Chains run free (one path evaluation per lane per pass), so a wave lasts as long as its slowest
 // chain, and a chain parked on a glint or a caustic rejects nearly every first stage: two evaluations per mutation, launch after
 // launch. Sorted by (depth, evaluations of the last launch), such chains share waves -- full ones, run first -- instead of holding
 // sixty-three finished lanes each (config 5 with the E S* L paths counted: 2.33e9 -> see DESIGN 7a). Chain ids, states and
 // streams are untouched: the same chains bit for bit, in other lanes. Counting sort, stable: deterministic.
-static int regroup_mmlt(drmlt_ctx *ctx, uint32_t n_mut) {
-    const uint32_t n = ctx->n_chains, padded = (n + 63u) / 64u * 64u, md = (uint32_t) ctx->cfg.max_depth, B = 16u;
+static int regroup_chains(drmlt_ctx *ctx, uint32_t n_mut) {
+    const uint32_t n = ctx->n_chains, padded = (n + 63u) / 64u * 64u, md = ctx->cfg.technique == DRMLT_TECH_MMLT ? (uint32_t) ctx->cfg.max_depth : 1u, B = 16u; // (bdpt: no depth classes)
     std::vector<uint32_t> work(n);
     HIP_TRY(ctx, hipMemcpyAsync(work.data(), ctx->d_done.p, (size_t) n * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -845,7 +854,7 @@ int drmlt_run(drmlt_ctx *ctx, uint64_t total_mutations, volatile int *stop, drml
     const bool ahead = ctx->cfg.technique == DRMLT_TECH_PATH && ctx->cfg.algo != DRMLT_ALGO_PSSMLT && ctx->P.kernel_variant >= 4 &&
                        !getenv("DRMLT_NO_RUN_AHEAD");
     const uint64_t call_base = ctx->mutation_base, call_end = call_base + per_chain;
-    const bool regroup = ctx->cfg.technique == DRMLT_TECH_MMLT && ctx->cfg.algo != DRMLT_ALGO_PSSMLT && ctx->P.exec_order && !getenv("DRMLT_MMLT_NO_REGROUP");
+    const bool regroup = (ctx->cfg.technique == DRMLT_TECH_MMLT || ctx->cfg.technique == DRMLT_TECH_BDPT) && ctx->cfg.algo != DRMLT_ALGO_PSSMLT && ctx->P.exec_order && !getenv("DRMLT_NO_REGROUP");
     while (done < per_chain) {
         if (stop && *stop) { rc = DRMLT_E_CANCELLED; break; }
         if (timed && std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count() >= (double) ctx->cfg.timeout_s) break;
@@ -864,7 +873,11 @@ int drmlt_run(drmlt_ctx *ctx, uint64_t total_mutations, volatile int *stop, drml
             if (regroup) Q.chain_done = ctx->d_done.as<uint32_t>(); // per-chain evaluation counts of this launch
             launch_mutate_mmlt(Q, n, ctx->mutation_base, ctx->stream);
         }
-        else if (ctx->cfg.technique == DRMLT_TECH_BDPT) launch_mutate_bdpt(ctx->P, n, ctx->mutation_base, ctx->stream);
+        else if (ctx->cfg.technique == DRMLT_TECH_BDPT) {
+            DParams Q = ctx->P;
+            if (regroup) Q.chain_done = ctx->d_done.as<uint32_t>(); // per-chain evaluation counts of this launch
+            launch_mutate_bdpt(Q, n, ctx->mutation_base, ctx->stream);
+        }
         else if (ahead) {
             DParams Q = ctx->P;
             const uint64_t target = call_base + done + n;
@@ -878,7 +891,7 @@ int drmlt_run(drmlt_ctx *ctx, uint64_t total_mutations, volatile int *stop, drml
         ctx->mutation_base += n;
         done += n;
         ctx->launches++;
-        if (regroup) { const int rr = regroup_mmlt(ctx, n); if (rr != DRMLT_OK) return rr; ctx->regrouped = true; }
+        if (regroup) { const int rr = regroup_chains(ctx, n); if (rr != DRMLT_OK) return rr; ctx->regrouped = true; }
         if (stop || cb || timed) {
             HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
             if (cb) cb(done * ctx->n_chains, per_chain * ctx->n_chains, user);

@@ -133,7 +133,12 @@ __global__ void __launch_bounds__(CHAIN_BLOCK) k_init_chains_bdpt(DParams P, con
 // best, the SIMD one every 2.
 template <int FEAT, int OCC> __global__ void __launch_bounds__(CHAIN_BLOCK, OCC) k_mutate_bdpt(DParams P, uint32_t n_mut, uint32_t mut_base) {
     const uint32_t lane = threadIdx.x;
-    const uint32_t c = blockIdx.x * CHAIN_BLOCK + lane;
+    // Execution order (drmlt_capi.cpp: regroup_chains): which chain a lane runs. Between the launches of a call the host groups the
+    // chains by the evaluations they needed in the launch just done, so that chains parked on a glint (two evaluations per mutation,
+    // launch after launch) share waves instead of holding sixty-three finished lanes each. Chain ids -- state, streams, workspace
+    // column, lists -- are untouched: the same chains bit for bit, in other lanes.
+    const uint32_t slot = blockIdx.x * CHAIN_BLOCK + lane;
+    const uint32_t c = P.exec_order ? P.exec_order[slot] : slot;
     const bool live = c < P.n_chains;
     const uint32_t cc = live ? c : P.n_chains - 1;
     const uint32_t NX = bdpt_nx_lds(P);
@@ -160,7 +165,7 @@ template <int FEAT, int OCC> __global__ void __launch_bounds__(CHAIN_BLOCK, OCC)
     // second stage / Green's reverse move of the one it is in. (A lockstep loop over mutations with the stages inside ran a whole
     // wave pass for the two or three lanes in sixty-four that go to a second stage -- 2 % of bdpt's mutations, so three passes in
     // four had one: 1.8 passes per mutation instead of 1.02.)
-    uint32_t it = 0u;
+    uint32_t it = 0u, work = 0u; // work: path evaluations of this launch
     int stage = 0;
     float y_lum = 0.f, z_lum = 0.f, a1 = 0.f;
     uint32_t ns1 = 0, ne1 = 0, nd1 = 0, ns2 = 0, ne2 = 0, nd2 = 0;
@@ -182,6 +187,7 @@ template <int FEAT, int OCC> __global__ void __launch_bounds__(CHAIN_BLOCK, OCC)
         float *target = stage == 1 ? L2 : L1;
         eval_bdpt<FEAT>(P, T, smp, run, cc, NX, target, R); // the whole wave: the connections of all chains go to all lanes
         if (!run) continue;
+        ++work;
         {
             ct.rays += R.nrays;
             const float lum = list_finalize(P, target, R.lum);
@@ -273,6 +279,7 @@ template <int FEAT, int OCC> __global__ void __launch_bounds__(CHAIN_BLOCK, OCC)
         if (L0 != list_col(P, 0, cc)) list_copy(P, list_col(P, 0, cc), L0); // slot 0 is where the next launch (and drmlt_chain_state) look
         for (uint32_t k = 0; k < NX; ++k) P.x[(size_t) k * P.n_chains + c] = lds_x[k * 64u + lane];
         P.cur_lum[c] = cur_lum;
+        if (P.chain_done) P.chain_done[c] = work; // (this kernel has no run-ahead: the array is free for the count)
     }
     flush_counters(P, ct, lane);
     if (dbg && lane == 0) { atomicAdd(P.stats + 18, __builtin_amdgcn_s_memtime() - k0); atomicAdd(P.stats + 20, t_stages); atomicAdd(P.stats + 21, t_splat); atomicAdd(P.stats + 22, t_commit); } // per wave

@@ -80,6 +80,31 @@ def test_a_chain_does_not_depend_on_its_wave_neighbours(pkg, kw, native_lib):
     assert sa.accepted + sb.accepted == sbig.accepted and sa.rays + sb.rays == sbig.rays
 
 
+@pytest.mark.parametrize("kw", [dict(technique="bdpt", max_depth=6, no_direct_sampling=0), dict(technique="mmlt", max_depth=6)], ids=["bdpt", "mmlt"])
+def test_regrouping_the_waves_by_work_changes_no_chain(pkg, kw, native_lib, monkeypatch):
+    """Between the launches of a call the host regroups the bidirectional kernels' waves by the evaluations every chain needed in the
+    launch just done (chains parked on a glint share waves): many short launches with and without it end in the same states."""
+    sd = pkg.scenes.caustic_c5(32)
+    n, per_chain = 1000, 96
+    res = []
+    for off in (False, True):
+        monkeypatch.setenv("DRMLT_SLICE", "16")                      # six launches, five regroupings
+        if off:
+            monkeypatch.setenv("DRMLT_NO_REGROUP", "1")
+        else:
+            monkeypatch.delenv("DRMLT_NO_REGROUP", raising=False)
+        ctx = pkg.Context(_cfg(pkg, n, **kw), sd)
+        ctx.seed(0xC0FFEE)
+        ctx.run(n * per_chain)
+        st = ctx.stats()
+        res.append((ctx.chain_state(st.max_dim if kw["technique"] == "bdpt" else 27), st, ctx.film()))
+        ctx.close()
+    ((ca, ua), sa, fa), ((cb, ub), sb, fb) = res
+    assert np.array_equal(ua, ub) and np.array_equal(ca["luminance"], cb["luminance"])
+    assert sa.accepted == sb.accepted and sa.rays == sb.rays and sa.path_evals == sb.path_evals and sa.mutations == sb.mutations == n * per_chain
+    assert (fa @ LUMW).sum() == pytest.approx((fb @ LUMW).sum(), rel=1e-5)
+
+
 def test_node_with_two_ranks_on_one_gpu_equals_single_context(pkg, native_lib, monkeypatch):
     """drmlt_node_* with two ranks (both on GPU 0: loopback transport for the reduce-scatter arithmetic): seed pool,
     threaded run, tiled develop, summed stats == one context with twice the chains."""
