@@ -40,3 +40,8 @@ case $1 in
    run cornell_mmlt_direct16 --config c5 --scene cornell_c2 --set direct_samples=16,fix_emitter_path=0
    run cornell_bdpt_mixture --config bdpt --set use_mixture=1;;
 esac
+case $1 in
+9) run cornell_amap --config c2 --set acceptance_map=1
+   run caustic_mmlt_amap --config c5 --set acceptance_map=1
+   run cornell_bdpt_amap --config bdpt --set acceptance_map=1;;
+esac
