@@ -859,7 +859,7 @@ int drmlt_run(drmlt_ctx *ctx, uint64_t total_mutations, volatile int *stop, drml
         if (stop && *stop) { rc = DRMLT_E_CANCELLED; break; }
         if (timed && std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count() >= (double) ctx->cfg.timeout_s) break;
         // shorter launches when somebody is watching (cancellation / progress / deadline latency ~ tens of ms)
-        const uint64_t slice = (stop || cb || timed) ? std::min(ctx->slice, 256) : (regroup && !ctx->regrouped ? std::min(ctx->slice, getenv("DRMLT_REGROUP_FIRST") ? atoi(getenv("DRMLT_REGROUP_FIRST")) : 256) : ctx->slice); // (regrouping: a short first launch, to learn which chains are parked)
+        const uint64_t slice = (stop || cb || timed) ? std::min(ctx->slice, 256) : (regroup && !ctx->regrouped ? std::min<int>(ctx->slice, getenv("DRMLT_REGROUP_FIRST") ? atoi(getenv("DRMLT_REGROUP_FIRST")) : (int) std::max<uint64_t>(32, std::min<uint64_t>(256, per_chain / 8))) : ctx->slice); // (regrouping: a short first launch -- an eighth of the call, 32 to 256 mutations -- to learn which chains are parked)
         uint32_t n = (uint32_t) std::min<uint64_t>(slice, per_chain - done);
         evs.emplace_back();
         EventPair &ev = evs.back();
