@@ -81,7 +81,9 @@ def main():
     pkg, ob = g.load_package(), g.load_oracle()
     ob.build(native=True)   # -O3 -march=native build of the restatement for this host
     abi = pkg.abi
-    sd = pkg.scenes.SCENES[conf["scene"]](res=a.res)
+    # "triangle_soup:200": a scene builder with its first argument (here the triangle count: a BVH scene the brute-force oracle can still afford)
+    sname, _, sarg = conf["scene"].partition(":")
+    sd = pkg.scenes.SCENES[sname](int(sarg), res=a.res) if sarg else pkg.scenes.SCENES[sname](res=a.res)
     kw = dict(direct_samples=-1, work_units=a.chains, sample_count=a.spp, luminance_samples=100000)
     kw.update(conf["cfg"])
     cfg = abi.make_config(**kw)

@@ -45,3 +45,6 @@ case $1 in
    run caustic_mmlt_amap --config c5 --set acceptance_map=1
    run cornell_bdpt_amap --config bdpt --set acceptance_map=1;;
 esac
+case $1 in
+10) run soup300_path --config c2 --scene triangle_soup:300 --n 32;;
+esac
