@@ -384,7 +384,9 @@ def main():
             "path_evals_per_s": world * evals / elapsed, "rays_per_s": world * rays / elapsed,
             "acceptance": {k: (round(v, 5) if v is not None else None) for k, v in st1.ratios().items()},
         }
-        proto = next((q for q in (os.path.join(ROOT, "profiles", n) for n in ("r03_parity_protocol_c2.json", "r02_parity_protocol.json")) if os.path.exists(q)), "")
+        # the committed device-vs-oracle statistics of THIS configuration (tools/parity_protocol.py; the BVH scenes: the 300-triangle sweep run)
+        pname = {"2": "parity_protocol_c2", "2x": "parity_protocol_c2", "3": "parity_protocol_c3", "5": "parity_protocol_c5", "bdpt": "parity_protocol_bdpt"}.get(args.config, "protocol_sweep_soup300_path")
+        proto = next((q for q in (os.path.join(ROOT, "profiles", n) for n in ("r03_%s.json" % pname, "r02_parity_protocol.json")) if os.path.exists(q)), "")
         if os.path.exists(proto):
             try:
                 out["parity_protocol"] = json.load(open(proto)).get("summary")
