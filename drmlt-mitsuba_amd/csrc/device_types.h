@@ -148,7 +148,7 @@ struct DParams {
     uint32_t bvh_ovf_lanes;      // column count of that area (>= lanes of the launch)
     int32_t trace_vote;          // traversal: the wave tests nodes when 16 * (lanes at a leaf) <= trace_vote * (lanes at a node), leaves otherwise
     int32_t pool_refill;         // k_mutate_v5: idle lanes take pending rays off the queue inside a trace phase once this many lanes have run dry
-    int32_t pad_end;
+    int32_t boot_weighted;       // bootstrap kernels: also write each sample's luminance under the importance map, to lum_out[n + i] (two-stage MLT: seeds drawn from the chains' own target, drmlt_capi.cpp)
 };
 
 // result of one PSS evaluation, SoA-friendly

@@ -555,6 +555,7 @@ drmlt_ctx *drmlt_create(const drmlt_config *cfg, const drmlt_scene *scene, int d
     // 16: 5.08 / 5.37 / 5.20, 20: 5.25 / 5.44 / 5.10, 24: 5.31 / 5.40 / 4.81
     P.trace_yield = P.kernel_variant == 5 ? (beyond_l2 ? 8 : 20) : (P.bvh_stack16 ? 24 : 20);
     if (const char *k = getenv("DRMLT_TRACE_YIELD")) P.trace_yield = std::max(0, std::min(64, atoi(k)));
+    P.boot_weighted = 0;
     P.pool_refill = 8; // soup, 131 072 chains: 1 5.38e8, 2 5.41e8, 4 5.43e8, 8 5.45e8, 16 5.37e8 mutations/s
     if (const char *k = getenv("DRMLT_POOL_REFILL")) P.pool_refill = std::max(1, std::min(64, atoi(k)));
     P.trace_vote = 10; // measured on the 2000-triangle soup: 16 (plain majority) 2.70e8, 10 2.78e8, 5 2.73e8 mutations/s
@@ -606,16 +607,25 @@ static int seed_impl(drmlt_ctx *ctx, uint64_t seed, uint32_t chain_offset, uint3
     if (mmlt) n64 *= (uint64_t) ctx->cfg.max_depth;
     if (n64 > 0x7fffffffull) return ctx->fail(DRMLT_E_INVALID, "too many luminance samples");
     uint32_t n = (uint32_t) n64;
+    // Two-stage MLT: the chains sample f / importance, so that is what their seeds are drawn from (each bootstrap sample's luminance under
+    // the map, second half of the buffer). The reference draws them from f itself (pathsampler.cpp:903-905 takes the luminance BEFORE
+    // SplatList::normalize(importanceMap)) -- chains then start outside their stationary distribution; over its work units of 1e5
+    // mutations that start-up bias is nothing, over the device's short chains it is not (a map of contrast 100 on the Cornell box, 1024
+    // mutations per chain: the bright half + 13 %, the dark half - 15 %; DESIGN section 5, deviation 18). b stays the mean of f.
+    // DRMLT_SEED_BY_PLAIN_LUMINANCE=1 restores the reference's rule (the oracle's: what the chain-tracking tests compare).
+    const bool weighted_seeds = P.importance != nullptr && !getenv("DRMLT_SEED_BY_PLAIN_LUMINANCE");
+    P.boot_weighted = weighted_seeds ? 1 : 0;
     DevBuf d_lum;
-    HIP_TRY(ctx, d_lum.alloc((size_t) n * sizeof(float)));
+    HIP_TRY(ctx, d_lum.alloc((size_t) n * (weighted_seeds ? 2 : 1) * sizeof(float)));
     const bool bdpt = ctx->cfg.technique == DRMLT_TECH_BDPT;
     HIP_TRY(ctx, ensure_overflow(ctx, P, std::max<size_t>(n, 2 * (size_t) P.n_chains_alloc)));
     if (mmlt) launch_bootstrap_mmlt(P, n, d_lum.as<float>(), ctx->stream);
     else if (bdpt) launch_bootstrap_bdpt(P, n, d_lum.as<float>(), ctx->stream);
     else launch_bootstrap(P, n, d_lum.as<float>(), ctx->stream);
     HIP_TRY(ctx, hipGetLastError());
-    std::vector<float> lum(n);
-    HIP_TRY(ctx, hipMemcpyAsync(lum.data(), d_lum.p, (size_t) n * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    std::vector<float> lum((size_t) n * (weighted_seeds ? 2 : 1));
+    HIP_TRY(ctx, hipMemcpyAsync(lum.data(), d_lum.p, lum.size() * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    P.boot_weighted = 0;
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
 
     // generateSeeds, pathsampler.cpp:879-954: mean over non-NaN samples, CDF over the non-zero ones
@@ -628,7 +638,8 @@ static int seed_impl(drmlt_ctx *ctx, uint64_t seed, uint32_t chain_offset, uint3
         if (std::isnan(l)) continue;
         tok += 1.0;
         sum += (double) l;
-        if (l != 0.f) { idx.push_back(i); cdf.push_back(cdf.back() + (double) l); }
+        const float lw = weighted_seeds ? lum[(size_t) n + i] : l; // what the seed is drawn in proportion to
+        if (l != 0.f && lw > 0.f && std::isfinite(lw)) { idx.push_back(i); cdf.push_back(cdf.back() + (double) lw); }
     }
     double mean = tok > 0 ? sum / tok : 0.0;
     if (mmlt) mean *= (double) ctx->cfg.max_depth; // "As we split the path by corresponding depth"
@@ -715,6 +726,7 @@ int drmlt_bootstrap_luminances(drmlt_ctx *ctx, uint64_t seed, uint32_t stream, u
     DParams P = ctx->P;
     P.key0 = (uint32_t) seed; P.key1 = (uint32_t) (seed >> 32);
     P.boot_stream = stream;
+    P.boot_weighted = 0;
     DevBuf d_lum;
     HIP_TRY(ctx, d_lum.alloc((size_t) n * sizeof(float)));
     HIP_TRY(ctx, ensure_overflow(ctx, P, std::max<size_t>(n, 2 * (size_t) P.n_chains_alloc)));

@@ -31,7 +31,9 @@ __global__ void __launch_bounds__(64) k_bootstrap(DParams P, uint32_t n, float *
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     uint32_t nd;
-    lum_out[i] = eval_boot_sample(P, i, nd).lum;
+    DSplat s = eval_boot_sample(P, i, nd);
+    lum_out[i] = s.lum;
+    if (P.boot_weighted) { normalize_splat(s, P); lum_out[(size_t) n + i] = s.lum; } // luminance of f / importance
 }
 
 __global__ void __launch_bounds__(64) k_init_chains(DParams P, const uint32_t *seed_index, const float *seed_lum) {

@@ -96,7 +96,10 @@ __global__ void __launch_bounds__(CHAIN_BLOCK) k_bootstrap_bdpt(DParams P, uint3
         smp.major = i;
         BdptResult R;
         eval_bdpt(P, T, smp, active, cc, bdpt_nx_lds(P), list_col(P, 1, cc), R);
-        if (active) lum_out[i] = R.lum;
+        if (active) {
+            lum_out[i] = R.lum;
+            if (P.boot_weighted) lum_out[(size_t) n + i] = list_finalize(P, list_col(P, 1, cc), R.lum); // luminance of f / importance
+        }
     }
 }
 

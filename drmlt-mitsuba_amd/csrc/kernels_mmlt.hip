@@ -33,6 +33,7 @@ __global__ void __launch_bounds__(CHAIN_BLOCK) k_bootstrap_mmlt(DParams P, uint3
     MmltResult R;
     eval_mmlt(P, T, smp, (int) (i % (uint32_t) P.max_depth) + 1, mmlt_nx(P), R);
     lum_out[i] = R.splat.lum;
+    if (P.boot_weighted) { DSplat w = R.splat; normalize_splat(w, P); lum_out[(size_t) n + i] = w.lum; } // luminance of f / importance
 }
 
 __global__ void __launch_bounds__(CHAIN_BLOCK) k_init_chains_mmlt(DParams P, const uint32_t *seed_index, const float *seed_lum) {

@@ -18,7 +18,8 @@ def test_luminance_map_matches_oracle(pkg, ob, native_lib):
 
 
 @pytest.mark.parametrize("tech", ["path", "mmlt"])
-def test_weighted_chains_track_the_oracle(pkg, ob, tech, native_lib):
+def test_weighted_chains_track_the_oracle(pkg, ob, tech, native_lib, monkeypatch):
+    monkeypatch.setenv("DRMLT_SEED_BY_PLAIN_LUMINANCE", "1")   # the reference's seeding rule (the oracle's): seeds in proportion to f, not f / importance
     sd = pkg.scenes.cornell_c2(32)
     abi = pkg.abi
     ref = pkg.Context(abi.make_config(max_depth=6, rr_depth=100, direct_samples=-1, work_units=64), sd).render_pt(256, seed=3)
@@ -53,7 +54,8 @@ def test_weighted_chains_track_the_oracle(pkg, ob, tech, native_lib):
 
 
 @pytest.mark.parametrize("scene", ["caustic_c5", "door_c3"])
-def test_importance_map_with_unlit_regions_matches_oracle(pkg, ob, scene, native_lib):
+def test_importance_map_with_unlit_regions_matches_oracle(pkg, ob, scene, native_lib, monkeypatch):
+    monkeypatch.setenv("DRMLT_SEED_BY_PLAIN_LUMINANCE", "1")   # the reference's seeding rule (the oracle's): seeds in proportion to f, not f / importance
     """A first-stage image with black regions gives exact zeros in the map (mltLuminancePass applies no floor,
     util.cpp:190-196): SplatList::normalize divides by them, the list luminance is inf and the proposal is rejected
     (drmlt_proc.cpp:428). No 1e-3 floor here; part of the map is forced to zero so that chains do propose into it."""
@@ -101,7 +103,8 @@ def test_importance_map_with_unlit_regions_matches_oracle(pkg, ob, scene, native
         pkg.Context(cfg, sd).set_importance_map(bad)
 
 
-def test_pssmlt_with_importance_map_uses_veach_weights(pkg, ob, native_lib):
+def test_pssmlt_with_importance_map_uses_veach_weights(pkg, ob, native_lib, monkeypatch):
+    monkeypatch.setenv("DRMLT_SEED_BY_PLAIN_LUMINANCE", "1")   # the reference's seeding rule (the oracle's): seeds in proportion to f, not f / importance
     """pssmlt_proc.cpp:203: with an importance map the accepted-branch weights are Veach's expectations even when
     kelemenStyleWeights is set ("these don't work for 2-stage MLT"); the a <= 0 branch keeps the Kelemen form."""
     sd = pkg.scenes.cornell_c1(32)
@@ -129,8 +132,7 @@ def test_two_stage_render_is_unbiased_and_flatter(pkg, native_lib):
     sd = pkg.scenes.glass_sphere(64)
     abi = pkg.abi
     ref = pkg.Context(abi.make_config(max_depth=6, rr_depth=100, direct_samples=-1, work_units=64), sd).render_pt(4096, seed=3)
-    # Seeds are drawn in proportion to the UNWEIGHTED luminance (pathsampler.cpp:901-903) while the chains' target is
-    # f / importance: a start-up bias the reference shares, negligible for its long chains -> long chains here too
+    # (chains long enough that the seeding rule does not matter: the next test is about that)
     cfg = abi.make_config(technique="path", type="orbital", max_depth=6, direct_samples=-1, work_units=2048,
                           sample_count=2048, luminance_samples=200000)
     img, imp, b = pkg.binding.render_two_stage(cfg, sd, 0x5EED, size_reduction=16)
@@ -146,6 +148,40 @@ def test_two_stage_render_is_unbiased_and_flatter(pkg, native_lib):
     dark = (lr > 0) & (lr < np.quantile(lr[lr > 0], 0.25))      # directly visible emitter pixels are 0 in this estimator
     err = lambda a: np.mean(((a @ LUMW) - lr)[dark] ** 2 / lr[dark] ** 2)
     assert err(img) < err(ip)
+
+
+def test_seeds_are_drawn_from_the_weighted_target(pkg, native_lib, monkeypatch):
+    """Two-stage chains sample f / importance. The reference draws their seeds in proportion to f (pathsampler.cpp:903-905: the
+    luminance is taken before SplatList::normalize(importanceMap)), i.e. outside the chains' stationary distribution; over its
+    work units of 1e5 mutations that start-up bias vanishes, over a device's many short chains it does not. The device draws the
+    seeds from f / importance (deviation 18): a map of contrast 100 across the Cornell box, 4096 chains of 1024
+    mutations -- columns within 3 % of a path-traced reference; with the reference's rule (DRMLT_SEED_BY_PLAIN_LUMINANCE=1) the
+    bright half comes out 13 % high and the dark half 15 % low."""
+    abi = pkg.abi
+    sd = pkg.scenes.cornell_c2(64)
+    cfg = abi.make_config(technique="path", type="orbital", max_depth=6, rr_depth=5, direct_samples=-1, work_units=4096, sample_count=1024, luminance_samples=100000)
+    rc = pkg.Context(cfg, sd)
+    ref = 0.5 * (rc.render_pt(16384, seed=11).astype(np.float64) + rc.render_pt(16384, seed=22))
+    rc.close()
+    imp = np.tile(np.where((np.arange(64) + 0.5) / 64 < 0.5, 0.01, 1.0), (64, 1)).astype(np.float32)
+
+    def halves(n_renders):
+        acc = np.zeros((64, 64, 3))
+        for i in range(n_renders):
+            c = pkg.Context(cfg, sd)
+            c.set_importance_map(imp)
+            b = c.seed(100 + i)
+            c.run(64 * 64 * 1024)
+            acc += c.develop()
+            c.close()
+        m, r = (acc / n_renders) @ LUMW, ref @ LUMW
+        return m[:, :32].sum() / r[:, :32].sum(), m[:, 32:].sum() / r[:, 32:].sum(), b
+    dark, bright, b = halves(6)
+    assert abs(dark - 1) < 0.03 and abs(bright - 1) < 0.03, (dark, bright)
+    assert b == pytest.approx((ref @ LUMW).mean(), rel=0.02)                 # b stays the mean of f itself
+    monkeypatch.setenv("DRMLT_SEED_BY_PLAIN_LUMINANCE", "1")
+    dark, bright, _ = halves(6)
+    assert dark < 0.92 and bright > 1.07, (dark, bright)
 
 
 def test_timeout_stops_the_run(pkg, native_lib):
