@@ -16,15 +16,21 @@ def rel_mse(img, ref):
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--scene", default="cornell_c2"); ap.add_argument("--technique", default="path"); ap.add_argument("--type", default="orbital")
-ap.add_argument("--ref-spp", type=int, default=0, help="technique=path: device path-traced reference with this many samples per pixel"); ap.add_argument("--n", type=int, default=64); ap.add_argument("--res", type=int, default=64); ap.add_argument("--spp", type=int, default=1024)
+ap.add_argument("--ref-spp", type=int, default=0, help="technique=path: device path-traced reference with this many samples per pixel"); ap.add_argument("--map", default="", help="steps: a synthetic map of contrast 100 (left half 0.01, right half 1) instead of a first-stage render"); ap.add_argument("--algo", type=int, default=0, help="1: pssmlt"); ap.add_argument("--n", type=int, default=64); ap.add_argument("--res", type=int, default=64); ap.add_argument("--spp", type=int, default=1024)
 a = ap.parse_args()
 pkg = g.load_package(); abi = pkg.abi
 sd = pkg.scenes.SCENES[a.scene](res=a.res)
-cfg = abi.make_config(technique=a.technique, type=a.type, max_depth=6, rr_depth=5, direct_samples=-1, work_units=4096, sample_count=a.spp, luminance_samples=100000)
+cfg = abi.make_config(technique=a.technique, type=a.type, algo=a.algo, max_depth=6, rr_depth=5, direct_samples=-1, work_units=4096, sample_count=a.spp, luminance_samples=100000)
+steps = np.tile(np.where((np.arange(a.res) + 0.5) / a.res < 0.5, 0.01, 1.0), (a.res, 1)).astype(np.float32)
+if a.map == 'const':
+    steps[:] = 0.37
 one, two = [], []
 for i in range(a.n):
     c = pkg.Context(cfg, sd); c.seed(3000 + i); c.run(a.res * a.res * a.spp); one.append(c.develop().astype(np.float64)); c.close()
-    two.append(pkg.binding.render_two_stage(cfg, sd, 9000 + i, size_reduction=8)[0].astype(np.float64))
+    if a.map:
+        c = pkg.Context(cfg, sd); c.set_importance_map(steps); c.seed(9000 + i); c.run(a.res * a.res * a.spp); two.append(c.develop().astype(np.float64)); c.close()
+    else:
+        two.append(pkg.binding.render_two_stage(cfg, sd, 9000 + i, size_reduction=8)[0].astype(np.float64))
 one, two = np.array(one), np.array(two)
 N = a.n
 m1, m2 = one.mean(0), two.mean(0)
