@@ -76,7 +76,7 @@ struct drmlt_ctx {
     double kernel_ms = 0.0, seed_ms = 0.0;
     double kt_ms = 0.0; uint64_t kt_launches = 0; // drmlt_kernel_time window
     uint64_t host_counters[9] = {0};
-    bool regrouped = false; // k_mutate_mmlt's execution order has been regrouped by work at least once since the last seed (drmlt_capi.cpp: regroup_mmlt)
+    bool regrouped = false; // the bidirectional kernels' execution order has been regrouped by work at least once since the last seed (drmlt_capi.cpp: regroup_chains)
     int slice = 1024; // mutations per chain per launch (<= 32768: the per-lane event counters are 16 bit)
     drmlt_comm *comm = nullptr; // set by drmlt_comm_init / drmlt_node_create
 
