@@ -48,3 +48,8 @@ esac
 case $1 in
 10) run soup300_path --config c2 --scene triangle_soup:300 --n 32;;
 esac
+case $1 in
+11) run caustic_bdpt_green --config bdpt_c5 --set type=green
+    run cornell_bdpt_nolightimage --config bdpt --set no_light_image=1
+    run caustic_mmlt_nolightimage --config c5 --set no_light_image=1;;
+esac
