@@ -65,9 +65,14 @@ def main():
     ap.add_argument("--save-means", default="", help=".npz: the two sides' mean images, the reference and every render's luminance estimate b")
     ap.add_argument("--scene", default="", help="override the configuration's scene (a name of drmlt-mitsuba_amd/scenes.py: SCENES)")
     ap.add_argument("--set", default="", help="override configuration fields: k=v,k=v (make_config names, e.g. technique=mmlt,type=green,use_mixture=1)")
+    ap.add_argument("--side", default="both", choices=("both", "gpu", "oracle"), help="render one side only and store its renders (--renders): the oracle needs no GPU, so it can run elsewhere; --combine joins the two")
+    ap.add_argument("--renders", default="", help=".npz of one side's renders (written with --side gpu|oracle)")
+    ap.add_argument("--combine", nargs=2, default=None, metavar=("GPU_NPZ", "ORACLE_NPZ"), help="statistics of two stored sides (implies --no-reference)")
     ap.add_argument("--no-reference", action="store_true", help="skip the independent reference (two-sample statistics only; the slopes against it are then meaningless)")
     ap.add_argument("--out", default="")
     a = ap.parse_args()
+    if a.combine or a.side != "both":
+        a.no_reference = True
     conf = dict(CONFIGS[a.config])
     conf["cfg"] = dict(conf["cfg"])
     if a.scene:
@@ -79,7 +84,8 @@ def main():
         conf["what"] = "%s with scene %s and %s" % (a.config, conf["scene"], conf["cfg"])
         conf["ref"] = {"path": "pt", "bdpt": "bdpt", "mmlt": "mmlt"}[conf["cfg"].get("technique", "path")]
     pkg, ob = g.load_package(), g.load_oracle()
-    ob.build(native=True)   # -O3 -march=native build of the restatement for this host
+    if not a.combine and a.side != "gpu":
+        ob.build(native=True)   # -O3 -march=native build of the restatement for this host
     abi = pkg.abi
     # "triangle_soup:200": a scene builder with its first argument (here the triangle count: a BVH scene the brute-force oracle can still afford)
     sname, _, sarg = conf["scene"].partition(":")
@@ -112,23 +118,39 @@ def main():
         ref_b = sum(ro.mmlt_render(d, nsamp, seed=202 + d, nthreads=a.threads)[0].astype(np.float64) for d in range(1, md + 1))
         ro.close()
         ref_what = "oracle's independent-sample multiplexed estimator summed over depths 1..%d (fp64, CPU), 2 x %d samples per pixel and depth" % (md, a.ref_samples_per_pixel // 2)
-    if a.no_reference:   # stand-in so that the per-render progress lines mean something: the first device render
-        c = pkg.Context(cfg, sd); c.seed(77); c.run(4 * total); ref_a = ref_b = c.develop().astype(np.float64); c.close()
-    ref = 0.5 * (ref_a.astype(np.float64) + ref_b.astype(np.float64))
-    ref_noise = rel_mse(ref_a, ref_b) / 4.0            # Var(mean of halves) = Var(difference) / 4
-    print("reference: %s, own rMSE %.3g (%.0f s)" % (ref_what, ref_noise, time.time() - t0), flush=True)
-    gpu, orc, b_gpu, b_orc = [], [], [], []
-    t_gpu = t_orc = 0.0
-    for i in range(a.n):
-        t = time.time()
-        c = pkg.Context(cfg, sd)
-        b_gpu.append(c.seed(1000 + a.seed_offset + i)); c.run(total); gpu.append(c.develop().astype(np.float64)); c.close()
-        t_gpu += time.time() - t
-        t = time.time()
-        o = ob.Oracle(abi, cfg, sd, precision=a.oracle_precision, native=True)
-        b_orc.append(o.seed(501000 + a.seed_offset + i)); o.run(total, a.threads); orc.append(o.develop().astype(np.float64)); o.close()
-        t_orc += time.time() - t
-        print("render %d/%d  gpu rMSE %.4g  oracle rMSE %.4g  (%.0f s)" % (i + 1, a.n, rel_mse(gpu[-1], ref), rel_mse(orc[-1], ref), time.time() - t0), flush=True)
+    if a.combine:
+        ga, oa = np.load(a.combine[0]), np.load(a.combine[1])
+        gpu, orc, b_gpu, b_orc = list(ga["renders"]), list(oa["renders"]), list(ga["b"]), list(oa["b"])
+        a.n = min(len(gpu), len(orc)); gpu, orc = gpu[:a.n], orc[:a.n]
+        ref = 0.5 * (np.mean(gpu, 0) + np.mean(orc, 0)); ref_noise = 0.0; ref_what = "none (pooled mean)"; t_gpu = t_orc = 0.0
+    else:
+        if a.no_reference and a.side != "oracle":   # stand-in so that the per-render progress lines mean something: a longer device render
+            c = pkg.Context(cfg, sd); c.seed(77); c.run(4 * total); ref_a = ref_b = c.develop().astype(np.float64); c.close()
+        elif a.no_reference:
+            o = ob.Oracle(abi, cfg, sd, precision=a.oracle_precision, native=True); o.seed(77); o.run(total, a.threads); ref_a = ref_b = o.develop().astype(np.float64); o.close()
+        ref = 0.5 * (ref_a.astype(np.float64) + ref_b.astype(np.float64))
+        ref_noise = rel_mse(ref_a, ref_b) / 4.0            # Var(mean of halves) = Var(difference) / 4
+        print("reference: %s, own rMSE %.3g (%.0f s)" % (ref_what, ref_noise, time.time() - t0), flush=True)
+        gpu, orc, b_gpu, b_orc = [], [], [], []
+        t_gpu = t_orc = 0.0
+        for i in range(a.n):
+            if a.side != "oracle":
+                t = time.time()
+                c = pkg.Context(cfg, sd)
+                b_gpu.append(c.seed(1000 + a.seed_offset + i)); c.run(total); gpu.append(c.develop().astype(np.float64)); c.close()
+                t_gpu += time.time() - t
+            if a.side != "gpu":
+                t = time.time()
+                o = ob.Oracle(abi, cfg, sd, precision=a.oracle_precision, native=True)
+                b_orc.append(o.seed(501000 + a.seed_offset + i)); o.run(total, a.threads); orc.append(o.develop().astype(np.float64)); o.close()
+                t_orc += time.time() - t
+            if (i + 1) % 8 == 0:
+                print("render %d/%d (%.0f s)" % (i + 1, a.n, time.time() - t0), flush=True)
+        if a.side != "both":
+            rs, bs = (gpu, b_gpu) if a.side == "gpu" else (orc, b_orc)
+            np.savez_compressed(a.renders, renders=np.array(rs, dtype=np.float32), b=np.array(bs))
+            print("stored %d %s renders in %s" % (len(rs), a.side, a.renders))
+            return
     gpu, orc = np.array(gpu), np.array(orc)
     N = a.n
     if a.save_means:
