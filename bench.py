@@ -9,10 +9,15 @@ reference drmlt_proc.cpp:541).
 
   python bench.py --gpus 1 --steps 10 --warmup 2      # the defaults
   python bench.py --config 3|5|bdpt|soup|soup50k  # the other kernels, same JSON line (roofline of THAT kernel)
+  python bench.py --gpus N --steps K --warmup W       # N > 1, no launcher: ONE process drives the N devices (drmlt_node_*)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-      bench.py --gpus N --steps K --warmup W
+      bench.py --gpus N --steps K --warmup W          # N > 1 under a launcher: one process per GPU (drmlt_comm_*)
 
-N > 1: one process per GPU, chains partitioned by chain id out of ONE seed pool (no data-path collective). The K timed steps
+N > 1 without a launcher (WORLD_SIZE unset): the process creates one drmlt_node over devices 0 .. N-1 -- what the Mitsuba
+plugin does (`devices` property) --, one host thread per device inside the library, an in-process RCCL communicator
+(ncclCommInitAll). It exits non-zero only when fewer than N devices are visible. On a one-GPU box the same code runs with
+`DRMLT_TEST_HOOKS=1 DRMLT_NODE_DEVICES=0,0 python bench.py --gpus 2` (ranks share the device, loopback transport).
+N > 1: chains partitioned by chain id out of ONE seed pool (no data-path collective). The K timed steps
 are ONE render (one drmlt_run call, as the Mitsuba adaptor issues it) that ends with ONE film exchange, issued from C++
 inside libdrmlt_amd.so (drmlt_exchange_tiled) and enqueued behind the chain kernels: ncclReduceScatter(sum) of the
 W*H*3 fp32 film -- rank r keeps rows [r ceil(H/N), ...) -- plus one two-element ncclAllReduce, then every rank develops its
@@ -198,16 +203,27 @@ def main():
     import torch
     import torch.distributed as dist
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    env_world = os.environ.get("WORLD_SIZE")
+    # No launcher and --gpus N > 1: ONE process drives the N devices through drmlt_node_* 
+    node_mode = env_world is None and args.gpus > 1
+    world = args.gpus if node_mode else int(env_world or "1")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the DRMLT path has no CPU fallback")
+    hook = os.environ.get("DRMLT_NODE_DEVICES") if os.environ.get("DRMLT_TEST_HOOKS") == "1" else None
+    if node_mode:
+        node_devices = [int(d) for d in hook.split(",")] if hook else list(range(args.gpus))
+        if len(node_devices) != args.gpus:
+            raise SystemExit("bench.py: --gpus %d but DRMLT_NODE_DEVICES names %d ranks" % (args.gpus, len(node_devices)))
+        if max(node_devices) >= torch.cuda.device_count():
+            raise SystemExit("bench.py: --gpus %d but only %d device(s) visible" % (args.gpus, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
-    # BENCH_FORCE_DIST=1 rehearses the multi-GPU path (process group, RCCL communicator, tiled exchange) on one GPU
-    use_dist = world > 1 or os.environ.get("BENCH_FORCE_DIST") == "1"
+    # BENCH_FORCE_DIST=1 rehearses the one-process-per-GPU path (process group, RCCL communicator, tiled exchange) on one GPU
+    use_dist = not node_mode and (world > 1 or os.environ.get("BENCH_FORCE_DIST") == "1")
+    multi = use_dist or node_mode
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29512")
@@ -221,42 +237,70 @@ def main():
     sd = build_scene(pkg, conf, res)
     # luminanceSamples: the reference's floor max(100000, 10 workUnits) (50 x for mmlt), applied inside drmlt_seed
     cfg = abi.make_config(work_units=args.chains, luminance_samples=100000, **cfg_kw)
-    ctx = pkg.Context(cfg, sd, device=local_rank)
-    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
-
     npix = res * res
-    # bootstrap + seed replay: outside the timed region. One seed pool for the job: every rank finds the same b
-    b = ctx.seed_pool(0x5EED, rank * args.chains, world * args.chains)
-    if use_dist:  # the library's own RCCL communicator: rank 0 creates the id, the process group only carries its 128 bytes
-        uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
-        if rank == 0:
-            uid.copy_(torch.frombuffer(bytearray(pkg.comm_unique_id()), dtype=torch.uint8))
-        dist.broadcast(uid, 0)
-        ctx.comm_init(bytes(uid.cpu().numpy().tobytes()), rank, world)
-    # what the library's communicator says about itself, and which chains of the pool every rank runs
-    rccl_nranks, rccl_rank = ctx.comm_info() if use_dist else (1, 0)
-    mine = {"rank": rank, "rccl_rank": rccl_rank, "rccl_nranks": rccl_nranks, "device": local_rank,
-            "chains": [rank * args.chains, (rank + 1) * args.chains], "film_rows": list(pkg.binding.film_tile(res, rank, world)[:2])}
-    ranks_info = [mine]
-    if use_dist:
-        ranks_info = [None] * world
-        dist.all_gather_object(ranks_info, mine)
+    step_mutations = npix * spp                                # per GPU
+    node = None
+    if node_mode:
+        # cfg.work_units is PER DEVICE; seeds from one pool, one host thread per device, film exchange over the node's communicator
+        node = pkg.Node(cfg, sd, device_mask=sum(1 << d for d in set(node_devices)))
+        if node.device_count != args.gpus:
+            raise SystemExit("bench.py: --gpus %d but the node drives %d device(s)" % (args.gpus, node.device_count))
+        ctxs = [node.context(r) for r in range(world)]
+        ctx = ctxs[0]
+        b = node.seed(0x5EED)
+        ranks_info = []
+        for r in range(world):
+            nr, rr = ctxs[r].comm_info()   # ncclCommCount / ncclCommUserRank of rank r's communicator (loopback: the node's own count)
+            ranks_info.append({"rank": r, "rccl_rank": rr, "rccl_nranks": nr, "device": node_devices[r],
+                               "chains": [r * args.chains, (r + 1) * args.chains], "film_rows": list(pkg.binding.film_tile(res, r, world)[:2])})
+        rccl_nranks = ranks_info[0]["rccl_nranks"]
+    else:
+        ctx = pkg.Context(cfg, sd, device=local_rank)
+        ctxs = [ctx]
+        ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+        # bootstrap + seed replay: outside the timed region. One seed pool for the job: every rank finds the same b
+        b = ctx.seed_pool(0x5EED, rank * args.chains, world * args.chains)
+        if use_dist:  # the library's own RCCL communicator: rank 0 creates the id, the process group only carries its 128 bytes
+            uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
+            if rank == 0:
+                uid.copy_(torch.frombuffer(bytearray(pkg.comm_unique_id()), dtype=torch.uint8))
+            dist.broadcast(uid, 0)
+            ctx.comm_init(bytes(uid.cpu().numpy().tobytes()), rank, world)
+        # what the library's communicator says about itself, and which chains of the pool every rank runs
+        rccl_nranks, rccl_rank = ctx.comm_info() if use_dist else (1, 0)
+        mine = {"rank": rank, "rccl_rank": rccl_rank, "rccl_nranks": rccl_nranks, "device": local_rank,
+                "chains": [rank * args.chains, (rank + 1) * args.chains], "film_rows": list(pkg.binding.film_tile(res, rank, world)[:2])}
+        ranks_info = [mine]
+        if use_dist:
+            ranks_info = [None] * world
+            dist.all_gather_object(ranks_info, mine)
     bad = [r for r in ranks_info if r["rccl_nranks"] != args.gpus or r["rccl_rank"] != r["rank"]]
     if bad or world != args.gpus:
-        raise SystemExit("bench.py: --gpus %d but the RCCL communicator reports %s (WORLD_SIZE=%d)" % (args.gpus, bad or ranks_info, world))
-    step_mutations = npix * spp                                # per GPU
+        raise SystemExit("bench.py: --gpus %d but the RCCL communicator reports %s (WORLD_SIZE=%s)" % (args.gpus, bad or ranks_info, env_world))
 
     def barrier():
         if use_dist:
             dist.barrier()
-        torch.cuda.synchronize()
+        if node_mode:
+            for d in sorted(set(node_devices)):
+                torch.cuda.synchronize(d)
+        else:
+            torch.cuda.synchronize()
+
+    last = {}
 
     def steps(k):
         """k steps of the render = ONE call into the library, which cuts it into launches of 1024 mutations per chain (one per
         step at 65 536 chains) -- as a renderer calls it (the adaptor hands drmlt_run its whole budget). Between those launches
         chains that have reached a launch's target run ahead towards the call's total instead of idling until the slowest chain
         is there; the call returns with every chain at exactly its count. Followed, for N > 1, by the render's film exchange:
-        reduce-scatter + scalar all-reduce + tile develop, all in C++, enqueued behind the chain kernels."""
+        reduce-scatter + scalar all-reduce + tile develop, all in C++ -- enqueued behind the chain kernels (one process per GPU),
+        or drmlt_node_develop, which also brings the stitched image to the host (one process, N devices)."""
+        if node_mode:
+            node.run(k * step_mutations * world)   # the node's total: an N-th of it per device
+            if not os.environ.get("BENCH_SKIP_EXCHANGE"):
+                last["image"] = node.develop()
+            return
         if os.environ.get("BENCH_CALL_PER_STEP"):
             for _ in range(k):
                 ctx.run(step_mutations)
@@ -265,11 +309,17 @@ def main():
         if use_dist and not os.environ.get("BENCH_SKIP_EXCHANGE"):
             ctx.exchange_tiled(b, want_tile=False, wait=False)
 
+    def job_stats():
+        return node.stats() if node_mode else ctx.stats()
+
     if args.warmup:
         steps(args.warmup)
-        ctx.film_clear()
-    ctx.kernel_time(reset=True)
-    st0 = ctx.stats()
+        for c in ctxs:
+            c.film_clear()
+    for c in ctxs:
+        c.kernel_time(reset=True)
+    st0 = job_stats()
+    rank_m0 = [c.stats().mutations for c in ctxs]
     barrier()
     t0 = time.perf_counter()
     steps(args.steps)
@@ -280,8 +330,10 @@ def main():
         dist.all_reduce(et, op=dist.ReduceOp.MAX)
         elapsed = float(et.item())
 
-    st1 = ctx.stats()
-    launch_ms, launches = ctx.kernel_time()
+    st1 = job_stats()
+    # the dominant kernel's launches by HIP events on the launch stream: one process, N devices -> the slowest device's average
+    kt = [c.kernel_time() for c in ctxs]
+    launch_ms, launches = max(kt)
     exchange_ms = None
     if use_dist:  # one BLOCKING exchange on its own clock (the timed region's exchange is enqueued behind the chain kernels)
         barrier()
@@ -291,6 +343,27 @@ def main():
         xt = torch.tensor([time.perf_counter() - te], dtype=torch.float64, device="cuda")
         dist.all_reduce(xt, op=dist.ReduceOp.MAX)
         exchange_ms = 1e3 * float(xt.item())
+    selfcheck = None
+    if node_mode:  # drmlt_node_develop on its own clock: reduce-scatter + all-reduce + develop of every tile + the image to the host
+        te = time.perf_counter()
+        img_node = node.develop()
+        exchange_ms = 1e3 * (time.perf_counter() - te)
+        # self-check inside the line: every device ran its share, and the stitched image is normalised to b
+        rank_muts = [c.stats().mutations - m0 for c, m0 in zip(ctxs, rank_m0)]
+        want_mut = args.steps * step_mutations
+        mean_lum = float(lum(img_node.astype(np.float64)).mean())
+        amap = bool(cfg_kw.get("acceptance_map"))
+        selfcheck = {"rank_mutations": rank_muts, "sum_rank_mutations": int(sum(rank_muts)), "expected_total": int(want_mut * world),
+                     "mutations_ok": all(m == want_mut for m in rank_muts),
+                     "image_mean_luminance": mean_lum, "b": b,
+                     "luminance_ok": True if amap else bool(abs(mean_lum - b) <= 1e-3 * b),
+                     "timed_image_equals_this_one": bool(np.array_equal(last.get("image"), img_node)) if "image" in last else None,
+                     "rank_film_mass": [float(c.film().astype(np.float64).sum()) for c in ctxs]}
+        if not (selfcheck["mutations_ok"] and selfcheck["luminance_ok"]):
+            raise SystemExit("bench.py: self-check failed: %s" % json.dumps(selfcheck))
+    # (one process, N devices: the node's statistics are already sums over its devices)
+    per_dev = 1.0 / world if node_mode else 1.0   # job statistics -> one device's share
+    agg = 1 if node_mode else world                # this process's statistics -> the job's
     muts = st1.mutations - st0.mutations
     accepted = st1.accepted - st0.accepted
     evals = st1.path_evals - st0.path_evals
@@ -310,7 +383,7 @@ def main():
         bvh_prims = (st1.bvh_prim_tests - st0.bvh_prim_tests) / muts
         scene_bytes = 128.0 * bvh_nodes + 64.0 * bvh_prims
         bytes_per_mut += scene_bytes
-        muts_per_launch = muts / max(launches, 1)
+        muts_per_launch = muts * per_dev / max(launches, 1)   # per device, like launch_ms
         achieved = bytes_per_mut * muts_per_launch / (launch_ms * 1e-3) / 1e9 if launch_ms > 0 else 0.0
         traffic = valu_frac = lane_util = None
         traffic_source = None
@@ -375,13 +448,18 @@ def main():
             "config": {"workload": conf["what"] % dict(res=res, chains=args.chains, spp=spp), "name": args.config,
                        "max_depth": cfg_kw["max_depth"], "rr_depth": cfg_kw.get("rr_depth", 5), "p_large": 0.3, "filter": "box",
                        "mutations_per_step_per_gpu": step_mutations,
-                       "parallelism": "chains partitioned x%d, one seed pool; film reduce-scatter + scalar all-reduce (RCCL from C++)" % world
-                       if use_dist else "1 GPU"},
+                       "parallelism": ("chains partitioned x%d, one seed pool; film reduce-scatter + scalar all-reduce (RCCL from C++); " % world +
+                                       ("one process drives the %d devices (drmlt_node_*, ncclCommInitAll)" % world if node_mode else "one process per GPU (drmlt_comm_*)"))
+                       if multi else "1 GPU"},
             "roofline": roof, "roofline_valu": roof_valu,
-            "rccl_nranks": rccl_nranks if use_dist else None, "ranks": ranks_info,
-            "exchanges": (0 if os.environ.get("BENCH_SKIP_EXCHANGE") else 1) if use_dist else 0, "exchange_ms": exchange_ms,
-            "accepted_mutations_per_s": world * accepted / elapsed,
-            "path_evals_per_s": world * evals / elapsed, "rays_per_s": world * rays / elapsed,
+            "rccl_nranks": rccl_nranks if multi else None, "ranks": ranks_info,
+            "launch_mode": "node" if node_mode else ("process-per-gpu" if use_dist else "single"),
+            "transport": None if not multi else ("loopback (test hook: ranks share a device, films summed by a device kernel)"
+                                                 if node_mode and len(set(node_devices)) < len(node_devices) else "rccl"),
+            "exchanges": (0 if os.environ.get("BENCH_SKIP_EXCHANGE") else 1) if multi else 0, "exchange_ms": exchange_ms,
+            "selfcheck": selfcheck,
+            "accepted_mutations_per_s": agg * accepted / elapsed,
+            "path_evals_per_s": agg * evals / elapsed, "rays_per_s": agg * rays / elapsed,
             "acceptance": {k: (round(v, 5) if v is not None else None) for k, v in st1.ratios().items()},
         }
         # the committed device-vs-oracle statistics of THIS configuration (tools/parity_protocol.py; the BVH scenes: the 300-triangle sweep run)
@@ -404,6 +482,8 @@ def main():
             img = np.zeros((res, res, 3), dtype=np.float32)
             for (lo, hi), t in parts:
                 img[lo:hi] = t
+        elif node_mode:
+            img, b_mean = img_node, b
         else:
             img, b_mean = ctx.develop(), b
         if rank == 0:
@@ -427,7 +507,7 @@ def main():
         # north_star's bar (rel. MSE < 1e-3 at equal sample budget) at a NAMED budget: keep mutating, outside the timed region
         goal_mpp = int(os.environ.get("BENCH_QUALITY_MPP", "8192"))
         done_mpp = spp * args.steps * world
-        if goal_mpp > done_mpp and not use_dist:
+        if goal_mpp > done_mpp and not multi:
             ctx.run((goal_mpp - done_mpp) * npix)
             img2 = ctx.develop()
             if rank == 0:
@@ -445,7 +525,10 @@ def main():
         os.dup2(saved_stdout, 1)
         print(json.dumps(_clean(out)), flush=True)
         os.dup2(2, 1)  # whatever is printed during teardown goes to stderr as well
-    ctx.close()
+    for c in ctxs:
+        c.close()
+    if node is not None:
+        node.close()
     if use_dist:
         dist.destroy_process_group()
 

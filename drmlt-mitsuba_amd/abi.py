@@ -8,12 +8,16 @@ SHAPE_TRIANGLE, SHAPE_RECTANGLE, SHAPE_SPHERE = 0, 1, 2
 BSDF_DIFFUSE, BSDF_DIELECTRIC, BSDF_ROUGHCONDUCTOR, BSDF_CONDUCTOR = 0, 1, 2, 3
 EMITTER_AREA = 0
 FILTER_BOX, FILTER_GAUSSIAN = 0, 1
+SEED_TARGET, SEED_REFERENCE = 0, 1            # drmlt_config.seed_rule (two-stage MLT seeding)
+WORK_UNITS_DEVICE, WORK_UNITS_REFERENCE = 0, 1  # drmlt_config.work_units_rule (what workUnits = -1 derives)
 
-ABI_VERSION = 3  # include/drmlt_abi.h: DRMLT_ABI_VERSION
+ABI_VERSION = 4  # include/drmlt_abi.h: DRMLT_ABI_VERSION
 OK, E_INVALID, E_DEVICE, E_STATE, E_ZERO_LUM, E_REPLAY, E_CANCELLED = 0, -1, -2, -3, -4, -5, -6
 
 TYPE_NAMES = {"green": TYPE_GREEN, "mira": TYPE_MIRA, "orbital": TYPE_ORBITAL, "mirasym": TYPE_ORBITAL}
 TECH_NAMES = {"path": TECH_PATH, "bdpt": TECH_BDPT, "mmlt": TECH_MMLT}
+SEED_RULE_NAMES = {"target": SEED_TARGET, "reference": SEED_REFERENCE}
+WORK_UNITS_RULE_NAMES = {"device": WORK_UNITS_DEVICE, "reference": WORK_UNITS_REFERENCE}
 
 
 class Config(C.Structure):
@@ -26,7 +30,7 @@ class Config(C.Structure):
         ("acceptance_map", C.c_int32), ("timid_after_large", C.c_int32), ("fix_emitter_path", C.c_int32),
         ("use_mixture", C.c_int32), ("kelemen_style_weights", C.c_int32), ("kelemen_style_mutation", C.c_int32),
         ("no_light_image", C.c_int32), ("timeout_s", C.c_int32), ("no_direct_sampling", C.c_int32),
-        ("reserved", C.c_int32 * 5),
+        ("seed_rule", C.c_int32), ("work_units_rule", C.c_int32), ("reserved", C.c_int32 * 3),
     ]
 
 
@@ -110,6 +114,10 @@ def make_config(**kw):
             v = TYPE_NAMES[v]
         if k == "technique" and isinstance(v, str):
             v = TECH_NAMES[v]
+        if k == "seed_rule" and isinstance(v, str):
+            v = SEED_RULE_NAMES[v]
+        if k == "work_units_rule" and isinstance(v, str):
+            v = WORK_UNITS_RULE_NAMES[v]
         if not hasattr(c, k):
             raise AttributeError(k)
         setattr(c, k, v)

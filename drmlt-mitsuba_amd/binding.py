@@ -416,9 +416,24 @@ class Node:
 
     def film(self, rank):
         """Raw film of one rank (test inspection)."""
-        out = np.empty((self.height, self.width, 3), dtype=np.float32)
-        h = self.L.drmlt_node_context(self.h, rank)
-        rc = self.L.drmlt_film_read(h, out.ctypes.data)
-        if rc != 0:
-            raise DrmltError(rc, self.L.drmlt_last_error(h).decode())
-        return out
+        return self.context(rank).film()
+
+    def context(self, rank):
+        """Rank `rank`'s context, BORROWED (drmlt_node_context): film / chain inspection, kernel timing, render_pt. The node
+        owns it; closing the returned object only forgets the handle."""
+        return BorrowedContext(self, rank)
+
+
+class BorrowedContext(Context):
+    """A drmlt_ctx owned by a Node. Every inspection call of Context works on it; seed / run / develop belong to the node."""
+
+    def __init__(self, node, rank):
+        h = node.L.drmlt_node_context(node.h, rank)
+        if not h:
+            raise DrmltError(abi.E_INVALID, "node has no rank %d" % rank)
+        self.L, self.h, self.cfg, self.scene_data = node.L, h, node.cfg, node.scene_data
+        self.width, self.height = node.width, node.height
+        self._node, self._cb = node, None   # keeps the owner alive
+
+    def close(self):
+        self.h = None

@@ -317,6 +317,8 @@ drmlt_ctx *drmlt_create(const drmlt_config *cfg, const drmlt_scene *scene, int d
     if (cfg->technique == DRMLT_TECH_MMLT && cfg->max_depth == -1) return bail(nullptr, "Impossible to use MMLT with no max depth");
     if (cfg->fix_emitter_path && cfg->technique != DRMLT_TECH_MMLT) return bail(nullptr, "Impossible to use fixEmitterPath without MMLT");
     if (cfg->scale_second > 1.0f) return bail(nullptr, "scaleSecond is bigger than the first stage");
+    if (cfg->seed_rule != DRMLT_SEED_TARGET && cfg->seed_rule != DRMLT_SEED_REFERENCE) return bail(nullptr, "Unknown seeding rule (firstStageSeeding: target | reference)");
+    if (cfg->work_units_rule != DRMLT_WORK_UNITS_DEVICE && cfg->work_units_rule != DRMLT_WORK_UNITS_REFERENCE) return bail(nullptr, "Unknown work-unit rule (workUnitsRule: device | reference)");
     const bool mmlt = cfg->technique == DRMLT_TECH_MMLT, bdpt = cfg->technique == DRMLT_TECH_BDPT;
     if (bdpt && cfg->timid_after_large) return bail(nullptr, "timidAfterLarge is not supported for technique=bdpt");
     // device_bdpt.h keeps two flag bits per stored vertex in ONE 64-bit register: 2 maxDepth + 1 slots fit up to maxDepth 15
@@ -430,9 +432,8 @@ drmlt_ctx *drmlt_create(const drmlt_config *cfg, const drmlt_scene *scene, int d
         // 100 000 (mmlt, bdpt) mutations each, drmlt.cpp:434-444: a few hundred chains for a whole image. A device wants the
         // count that fills it: 65 536 chains for the path kernels (32 per wave, two waves per SIMD), 131 072 for bdpt's
         // one-chain-per-lane kernel, 262 144 for mmlt's (two rounds, so that shallow waves make room for the next), but never chains shorter than 64 mutations. An explicit workUnits is
-        // taken as given; DRMLT_AUTO_WORK_UNITS=reference restores the reference's formula.
-        const char *mode = getenv("DRMLT_AUTO_WORK_UNITS");
-        if (mode && !strcmp(mode, "reference")) {
+        // taken as given; drmlt_config.work_units_rule = DRMLT_WORK_UNITS_REFERENCE (adaptor: workUnitsRule=reference) restores the reference's formula.
+        if (cfg->work_units_rule == DRMLT_WORK_UNITS_REFERENCE) {
             const uint64_t per_unit = (mmlt || bdpt) ? 100000 : 200000;
             work_units = (int) std::max<uint64_t>(1, (budget + per_unit - 1) / per_unit);
         } else {
@@ -611,9 +612,10 @@ static int seed_impl(drmlt_ctx *ctx, uint64_t seed, uint32_t chain_offset, uint3
     // the map, second half of the buffer). The reference draws them from f itself (pathsampler.cpp:903-905 takes the luminance BEFORE
     // SplatList::normalize(importanceMap)) -- chains then start outside their stationary distribution; over its work units of 1e5
     // mutations that start-up bias is nothing, over the device's short chains it is not (a map of contrast 100 on the Cornell box, 1024
-    // mutations per chain: the bright half + 13 %, the dark half - 15 %; DESIGN section 5, deviation 18). b stays the mean of f.
-    // DRMLT_SEED_BY_PLAIN_LUMINANCE=1 restores the reference's rule (the oracle's: what the chain-tracking tests compare).
-    const bool weighted_seeds = P.importance != nullptr && !getenv("DRMLT_SEED_BY_PLAIN_LUMINANCE");
+    // mutations per chain: the bright half + 13 %, the dark half - 15 %; DESIGN section 5, deviation 19). b stays the mean of f.
+    // drmlt_config.seed_rule = DRMLT_SEED_REFERENCE (adaptor: firstStageSeeding=reference) restores the reference's rule; the oracle
+    // follows the same field, so the chain-tracking tests run under both.
+    const bool weighted_seeds = P.importance != nullptr && ctx->cfg.seed_rule == DRMLT_SEED_TARGET;
     P.boot_weighted = weighted_seeds ? 1 : 0;
     DevBuf d_lum;
     HIP_TRY(ctx, d_lum.alloc((size_t) n * (weighted_seeds ? 2 : 1) * sizeof(float)));
@@ -643,8 +645,11 @@ static int seed_impl(drmlt_ctx *ctx, uint64_t seed, uint32_t chain_offset, uint3
     }
     double mean = tok > 0 ? sum / tok : 0.0;
     if (mmlt) mean *= (double) ctx->cfg.max_depth; // "As we split the path by corresponding depth"
-    if (!(mean > 0.0) || idx.empty())
+    if (!(mean > 0.0))
         return ctx->fail(DRMLT_E_ZERO_LUM, "The average image luminance appears to be zero! This could indicate a problem with the scene setup.");
+    if (idx.empty()) // mean(f) > 0, yet no sample can seed a chain: every contribution lies where the importance map is zero (or not finite)
+        return ctx->fail(DRMLT_E_ZERO_LUM, "No bootstrap sample has a finite positive luminance under the importance map (average luminance %g): "
+                                           "the map is zero wherever the scene contributes; firstStageSeeding=reference seeds from the plain luminance", mean);
     const double norm = 1.0 / cdf.back();
     for (size_t i = 1; i < cdf.size(); ++i) cdf[i] *= norm;
     cdf.back() = 1.0;

@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define DRMLT_ABI_VERSION 3
+#define DRMLT_ABI_VERSION 4
 
 /* ---- enums (values are ABI) ------------------------------------------- */
 
@@ -68,6 +68,22 @@ enum {
 enum { DRMLT_EMITTER_AREA = 0 };   /* src/emitters/area.cpp */
 
 enum { DRMLT_FILTER_BOX = 0, DRMLT_FILTER_GAUSSIAN = 1 };
+
+/* Two-stage MLT: what the chain seeds are resampled in proportion to (drmlt_config.seed_rule; adaptor property
+ * "firstStageSeeding" = "target" | "reference").
+ *   TARGET    (default) the luminance of f / importance -- the chains' own target (they sample the splat list AFTER
+ *             SplatList::normalize(importanceMap), pathsampler.cpp:1001-1020), so every chain starts in its stationary
+ *             distribution. Upstream Mitsuba's rule; a device's tens of thousands of short chains need it (dev. 19).
+ *   REFERENCE the luminance of f itself: this fork's PathSampler::generateSeeds takes it BEFORE the division
+ *             (pathsampler.cpp:901-905). Harmless over the reference's 1e5-mutation work units, a start-up bias over short chains.
+ * Without an importance map the two rules are the same rule. b is the mean of f under both. */
+enum { DRMLT_SEED_TARGET = 0, DRMLT_SEED_REFERENCE = 1 };
+
+/* workUnits = -1 ("derived", drmlt_config.work_units_rule; adaptor property "workUnitsRule" = "device" | "reference").
+ *   DEVICE    (default) a device-filling chain count: 131 072 (path, bdpt), 262 144 (mmlt), pssmlt 65 536; at least 64
+ *             mutations per chain.
+ *   REFERENCE ceil(budget / 200 000) (path) or / 100 000 (bdpt, mmlt): drmlt.cpp:434-444 -- sized for a CPU scheduler. */
+enum { DRMLT_WORK_UNITS_DEVICE = 0, DRMLT_WORK_UNITS_REFERENCE = 1 };
 
 /* error codes (0 = ok, negative = failure; message in the err buffer /
  * drmlt_last_error) */
@@ -108,7 +124,9 @@ typedef struct drmlt_config {
     int32_t  no_light_image;     /* 1 = "lightImage" false (mmlt; default: true)   */
     int32_t  timeout_s;          /* "timeout" default 0: stop drmlt_run after this many seconds (equal-time runs) */
     int32_t  no_direct_sampling; /* 1 = "directSampling" false (default true; bdpt only, forced false for mmlt) */
-    int32_t  reserved[5];
+    int32_t  seed_rule;          /* DRMLT_SEED_*: two-stage MLT seeding, default TARGET (see the enum)            */
+    int32_t  work_units_rule;    /* DRMLT_WORK_UNITS_*: what work_units = -1 derives, default DEVICE            */
+    int32_t  reserved[3];
 } drmlt_config;
 
 /* ---- flat scene description -------------------------------------------- */

@@ -90,6 +90,8 @@ template <typename F> struct Ctx : CtxBase {
         c.maxDim = findMaxDimensionsPath(in.max_depth, in.rr_depth);
         c.fixEmitterPath = in.fix_emitter_path != 0; c.lightImage = in.no_light_image == 0; c.technique = in.technique;
         c.directSampling = bdpt && !in.no_direct_sampling; // drmlt.cpp:228-231 (forced off for mmlt)
+        if (in.seed_rule != DRMLT_SEED_TARGET && in.seed_rule != DRMLT_SEED_REFERENCE) return "Unknown seeding rule";
+        c.seedByTarget = in.seed_rule == DRMLT_SEED_TARGET; // the product's default; DRMLT_SEED_REFERENCE = pathsampler.cpp:901-905
         beval = BDPTEvaluator<F>{&scene, c.maxDepth, c.rrDepth, c.separateDirect, c.lightImage, c.directSampling};
         meval = MMLTEvaluator<F>{&scene, c.maxDepth, c.separateDirect, c.lightImage};
         if (c.acceptanceMap && scene.filterType != DRMLT_FILTER_BOX) return "Box filter required for acceptance map!";
@@ -141,10 +143,14 @@ template <typename F> struct Ctx : CtxBase {
         // drmlt.cpp:454-473; technique=mmlt: x50 and one share per depth (initialisation on one core)
         size_t lumSamples = (size_t) std::max<long long>(cfg.luminance_samples, (long long) nSelect * (mmlt ? 50 : 10));
         if (mmlt) lumSamples *= (size_t) cfg.max_depth;
-        b = mmlt ? generateSeeds<F>(meval, boot, lumSamples, nSelect, seeds, nullptr, cfg.max_depth)
-            : bdpt ? generateSeeds<F>(beval, boot, lumSamples, nSelect, seeds)
-                   : generateSeeds<F>(eval, boot, lumSamples, nSelect, seeds);
-        if (pool && b != 0) seeds.assign(seeds.begin() + chainOffset, seeds.begin() + chainOffset + cfg.work_units);
+        const float *target = c.seedByTarget ? c.importance : nullptr; // two-stage MLT under DRMLT_SEED_TARGET: seeds from f / importance
+        b = mmlt ? generateSeeds<F>(meval, boot, lumSamples, nSelect, seeds, nullptr, cfg.max_depth, target, c.impW, c.impH)
+            : bdpt ? generateSeeds<F>(beval, boot, lumSamples, nSelect, seeds, nullptr, 0, target, c.impW, c.impH)
+                   : generateSeeds<F>(eval, boot, lumSamples, nSelect, seeds, nullptr, 0, target, c.impW, c.impH);
+        if (pool && b != 0) { // this context's slice of the job's list (a temporary: assign() from a vector's own iterators is undefined)
+            std::vector<PathSeed> mine(seeds.begin() + chainOffset, seeds.begin() + chainOffset + cfg.work_units);
+            seeds.swap(mine);
+        }
         if (indices && b != 0) {
             ReplayableSampler<F> rs(&boot);
             SplatList<F> list;

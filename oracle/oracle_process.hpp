@@ -102,6 +102,7 @@ struct PathSeed {
     uint32_t sampleIndex;
     double luminance;
     int depth = -1; // technique=mmlt: the chain's fixed path depth
+    double weight = -1; // what the seed is resampled in proportion to; < 0: the luminance (the reference's rule)
 };
 
 template <typename F> struct Config {
@@ -115,6 +116,11 @@ template <typename F> struct Config {
     bool directSampling = false;                    // technique=bdpt: the s = 1 / t = 1 strategies of pathsampler.cpp:424-452
     const float *importance = nullptr;              // two-stage MLT luminance image (W x H), drmlt.cpp:406-418
     int impW = 0, impH = 0;
+    // Two-stage seeding (drmlt_config.seed_rule). false = DRMLT_SEED_REFERENCE: seeds in proportion to lum(f), what this fork's
+    // generateSeeds does (pathsampler.cpp:901-905: the luminance is read BEFORE SplatList::normalize(importanceMap)). true =
+    // DRMLT_SEED_TARGET, the product's default: in proportion to lum(f / importance), the chains' own target. Only the resampling
+    // weight changes; b stays the mean of lum(f) and the seed keeps lum(f) for the replay check (drmlt_proc.cpp:509-512).
+    bool seedByTarget = false;
 };
 
 // Evaluator over a scene: PathSampler::sampleSplats(EUnidirectional)
@@ -161,7 +167,7 @@ template <typename F>
 inline void selectSeeds(const std::vector<PathSeed> &tempSeeds, Random &bootRandom, size_t seedCount, std::vector<PathSeed> &seeds) {
     std::vector<F> cdf(tempSeeds.size() + 1);
     cdf[0] = 0;
-    for (size_t i = 0; i < tempSeeds.size(); ++i) cdf[i + 1] = cdf[i] + (F) tempSeeds[i].luminance;
+    for (size_t i = 0; i < tempSeeds.size(); ++i) cdf[i + 1] = cdf[i] + (F) (tempSeeds[i].weight >= 0 ? tempSeeds[i].weight : tempSeeds[i].luminance);
     F norm = F(1) / cdf.back();
     for (size_t i = 1; i < cdf.size(); ++i) cdf[i] *= norm;
     cdf.back() = 1;
@@ -181,7 +187,8 @@ inline void selectSeeds(const std::vector<PathSeed> &tempSeeds, Random &bootRand
 // pathsampler.cpp:859-960. Returns b; seeds sorted by sample index.
 template <typename F, typename Eval>
 inline double generateSeeds(const Eval &eval, Random &bootRandom, size_t sampleCount, size_t seedCount,
-                            std::vector<PathSeed> &seeds, std::vector<float> *lumOut = nullptr, int mmltMaxDepth = 0) {
+                            std::vector<PathSeed> &seeds, std::vector<float> *lumOut = nullptr, int mmltMaxDepth = 0,
+                            const float *targetImportance = nullptr, int impW = 0, int impH = 0) {
     ReplayableSampler<F> sampler(&bootRandom);
     std::vector<PathSeed> tempSeeds;
     tempSeeds.reserve(sampleCount);
@@ -197,13 +204,19 @@ inline double generateSeeds(const Eval &eval, Random &bootRandom, size_t sampleC
         if (lumOut) (*lumOut)[i] = (float) lum;
         if (std::isnan(lum)) continue;
         tok += 1;
-        if (lum != 0) tempSeeds.push_back(PathSeed{(uint32_t) i, (double) lum, depth});
+        if (lum != 0 && !targetImportance) tempSeeds.push_back(PathSeed{(uint32_t) i, (double) lum, depth});
+        if (lum != 0 && targetImportance) { // DRMLT_SEED_TARGET: the sample's luminance under the map (SplatList::normalize, :1001-1020)
+            SplatList<F> weighted = list;
+            weighted.normalize(targetImportance, impW, impH);
+            const F lw = weighted.luminance;
+            if (lw > 0 && std::isfinite(lw)) tempSeeds.push_back(PathSeed{(uint32_t) i, (double) lum, depth, (double) lw}); // a sample on a zero of the map seeds nothing
+        }
         F delta = lum - mean; // Knuth / Welford
         mean += delta / tok;
         variance += delta * (lum - mean);
     }
     if (mmltMaxDepth > 0) mean *= (F) mmltMaxDepth; // "As we split the path by corresponding depth", :932-934
-    if (mean == 0) return 0;
+    if (mean == 0 || tempSeeds.empty()) return 0;
     selectSeeds<F>(tempSeeds, bootRandom, seedCount, seeds);
     std::sort(seeds.begin(), seeds.end(), [](const PathSeed &a, const PathSeed &b) { return a.sampleIndex < b.sampleIndex; });
     return (double) mean;
