@@ -71,7 +71,20 @@ public:
         m_cfg.timeout_s = props.getInteger("timeout", 0);
         m_cfg.no_light_image = props.getBoolean("lightImage", true) ? 0 : 1;
         m_cfg.no_direct_sampling = (props.getBoolean("directSampling", true) && m_cfg.technique != DRMLT_TECH_MMLT) ? 0 : 1;
-        // backend parameters (not in the reference): which GPUs of the node render (bit d = HIP device d; `device` is the
+        // backend parameters (not in the reference):
+        //  * firstStageSeeding = target (default) | reference: what two-stage chain seeds are resampled in proportion to -- the
+        //    luminance under the importance map (the chains' own target) or this fork's pathsampler.cpp:901-905 (the plain
+        //    luminance); include/drmlt_abi.h, DRMLT_SEED_*. Scene XML selects the upstream behaviour with "reference".
+        //  * workUnitsRule = device (default) | reference: what workUnits = -1 derives (drmlt.cpp:434-444 under "reference")
+        std::string seeding = props.getString("firstStageSeeding", "target");
+        if (seeding == "target") m_cfg.seed_rule = DRMLT_SEED_TARGET;
+        else if (seeding == "reference") m_cfg.seed_rule = DRMLT_SEED_REFERENCE;
+        else Log(EError, "Unknown firstStageSeeding (target | reference)");
+        std::string wuRule = props.getString("workUnitsRule", "device");
+        if (wuRule == "device") m_cfg.work_units_rule = DRMLT_WORK_UNITS_DEVICE;
+        else if (wuRule == "reference") m_cfg.work_units_rule = DRMLT_WORK_UNITS_REFERENCE;
+        else Log(EError, "Unknown workUnitsRule (device | reference)");
+        //  * which GPUs of the node render (bit d = HIP device d; `device` is the
         // single-GPU shorthand) and a fixed seed for reproducible renders (the reference seeds from /dev/urandom)
         m_deviceMask = props.hasProperty("devices") ? (uint32_t) props.getInteger("devices") : (1u << props.getInteger("device", 0));
         m_hasSeed = props.hasProperty("seed");

@@ -140,6 +140,13 @@ class Oracle:
         self._chk(self.L.oracle_seed_indices(self.h, seed, chain_offset, pool_chains, idx.ctypes.data, C.byref(b)))
         return b.value
 
+    def seed_indices(self):
+        """Bootstrap sample indices of this context's chains after the last seed call (mirrors Context.seed_indices)."""
+        out = np.empty(self.cfg.work_units, dtype=np.uint32)
+        self.L.oracle_picked_seeds.argtypes = [C.c_void_p, C.c_void_p]
+        self._chk(self.L.oracle_picked_seeds(self.h, out.ctypes.data))
+        return out
+
     def seed_pool(self, seed, first_chain, pool_chains):
         """Seeds [first_chain, first_chain + work_units) of ONE pool drawn for `pool_chains` chains (mirrors Context.seed_pool)."""
         b = C.c_double()

@@ -36,6 +36,7 @@ struct CtxBase {
     virtual int renderPT(uint32_t spp, uint64_t seed, int nthreads, float *out) = 0;
     virtual int bootstrapLum(uint64_t seed, uint32_t stream, uint32_t n, float *out) = 0;
     virtual int setImportance(const float *map) = 0;
+    std::vector<uint32_t> pickedSeeds; // bootstrap sample indices of this context's chains after the last seed()
     virtual int bdptRender(uint64_t n, uint64_t seed, int nthreads, float *out) = 0;
     virtual int bdptEval(const float *uSensor, const float *uEmitter, const float *uDirect, uint32_t n, uint32_t dim, float *out, uint32_t stride) = 0;
     virtual int mmltRender(int depth, uint64_t n, uint64_t seed, int lightImage, int nthreads, float *out, double *strat) = 0;
@@ -166,6 +167,8 @@ template <typename F> struct Ctx : CtxBase {
             }
         }
         if (b == 0) { error = "The average image luminance appears to be zero!"; return DRMLT_E_ZERO_LUM; }
+        pickedSeeds.clear();
+        for (const PathSeed &ps : seeds) pickedSeeds.push_back(ps.sampleIndex);
         if (cfg.acceptance_map) b = 1.0;                               // drmlt.cpp:550-552
         else if (cfg.average_luminance != -1.0f) b = cfg.average_luminance; // :555-558
         c.luminance = (F) b;
@@ -482,6 +485,13 @@ const char *oracle_last_error(void *p) { return static_cast<CtxBase *>(p)->error
 int oracle_eval_paths(void *p, const float *u, uint32_t n, uint32_t dim, drmlt_splat *out) { GUARD(static_cast<CtxBase *>(p)->evalPaths(u, n, dim, out)) }
 int oracle_seed(void *p, uint64_t seed, uint32_t chain_offset, double *b) { GUARD(static_cast<CtxBase *>(p)->seed(seed, chain_offset, b)) }
 int oracle_seed_indices(void *p, uint64_t seed, uint32_t chain_offset, uint32_t pool_chains, const uint32_t *indices, double *b) { GUARD(static_cast<CtxBase *>(p)->seed(seed, chain_offset, b, pool_chains, indices)) }
+// the bootstrap sample indices the last seed call gave this context's chains (work_units values): mirrors drmlt_seed_indices
+int oracle_picked_seeds(void *p, uint32_t *out) {
+    CtxBase *c = static_cast<CtxBase *>(p);
+    if (!c || !out || c->pickedSeeds.empty()) return DRMLT_E_STATE;
+    std::memcpy(out, c->pickedSeeds.data(), c->pickedSeeds.size() * sizeof(uint32_t));
+    return 0;
+}
 int oracle_seed_pool(void *p, uint64_t seed, uint32_t first_chain, uint32_t pool_chains, double *b) { GUARD(static_cast<CtxBase *>(p)->seed(seed, first_chain, b, pool_chains)) }
 int oracle_run(void *p, uint64_t total, int nthreads) { GUARD(static_cast<CtxBase *>(p)->run(total, nthreads)) }
 int oracle_film_read(void *p, float *out) { GUARD(static_cast<CtxBase *>(p)->filmRead(out)) }

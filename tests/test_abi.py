@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol(pkg, native_lib):
     assert set(names) == set(pkg.binding.ABI_SYMBOLS)
     for n in names:
         assert hasattr(native_lib, n), n
-    assert native_lib.drmlt_abi_version() == 3   # 2: + pool seeding, RCCL exchange, drmlt_node_*; 3: + drmlt_comm_info, drmlt_film_tile
+    assert native_lib.drmlt_abi_version() == 4   # 2: + pool seeding, RCCL exchange, drmlt_node_*; 3: + drmlt_comm_info, drmlt_film_tile; 4: + seed_rule, work_units_rule (no getenv in result-affecting decisions)
 
 
 def test_struct_layouts_match_the_header(abi):

@@ -101,6 +101,23 @@ def test_area_light_on_a_mesh_becomes_one_emitter_per_triangle(pkg, harness_mock
     assert got == corners
 
 
+def test_seeding_and_work_unit_rules_are_scene_properties(pkg, harness_mock, tmp_path):
+    """The reference's two-stage seeding rule (pathsampler.cpp:901-905) and its work-unit formula (drmlt.cpp:434-444) are
+    selectable from scene XML -- properties of the plugin, fields of drmlt_config, nothing in the environment."""
+    abi = pkg.abi
+    sd = pkg.scenes.cornell_c2(16)
+    scene = str(tmp_path / "s.bin")
+    sd.save(scene)
+    prefix = str(tmp_path / "o")
+    rc, log = run(harness_mock, scene, prefix, *D(firstStageSeeding="reference", workUnitsRule="reference", **BASE))
+    assert rc == 0, log
+    cfg = abi.Config.from_buffer_copy(open(prefix + ".cfg", "rb").read())
+    assert (cfg.seed_rule, cfg.work_units_rule) == (abi.SEED_REFERENCE, abi.WORK_UNITS_REFERENCE)
+    for bad in (dict(firstStageSeeding="plain"), dict(workUnitsRule="cpu")):
+        rc, log = run(harness_mock, scene, prefix, *D(**dict(BASE, **bad)))
+        assert rc != 0 and any("Unknown " + list(bad)[0] in t for _, t in log), log
+
+
 def test_parameters_statistics_progress_and_direct_pass(pkg, harness_mock, tmp_path):
     abi = pkg.abi
     sd = pkg.scenes.cornell_c2(16)
@@ -120,6 +137,7 @@ def test_parameters_statistics_progress_and_direct_pass(pkg, harness_mock, tmp_p
     assert (cfg.timid_after_large, cfg.use_mixture, cfg.timeout_s, cfg.no_light_image, cfg.luminance_samples) == (1, 1, 7, 1, 5000)
     assert cfg.direct_samples == 16 and cfg.no_direct_sampling == 0       # reference defaults: directSamples=16, directSampling=true
     assert cfg.work_units == -1 and cfg.average_luminance == -1.0 and mask == 5 and cfg.struct_size == C.sizeof(abi.Config)
+    assert (cfg.seed_rule, cfg.work_units_rule) == (abi.SEED_TARGET, abi.WORK_UNITS_DEVICE)   # the backend's defaults
     assert open(prefix + ".seed").read().strip() == "99"
     assert os.path.getsize(prefix + ".ser") == C.sizeof(abi.Config) + 4 + 1 + 1 + 4 + 1 + 4   # Integrator::serialize round trip payload (mask, twoStage, firstStage, reduction, hasSeed, seed)
     text = [t for _, t in log]

@@ -48,8 +48,9 @@ def test_normalize_with_importance_and_develop(pkg, abi, ob):
     ref = ob.Oracle(abi, abi.make_config(max_depth=6, rr_depth=100, work_units=4, direct_samples=-1), sd, 64) \
         .render_pt(3000, seed=7, nthreads=8)
     imp = np.maximum(ob.luminance_map(ref.reshape(4, 4, 4, 4, 3).mean((1, 3)), 16, 16), 1e-3)
+    # (the reference's seeding rule: the same seeds with and without the map, so the states can be compared one to one)
     cfg = abi.make_config(technique="path", type="orbital", max_depth=6, work_units=2048, direct_samples=-1,
-                          luminance_samples=100000)
+                          luminance_samples=100000, seed_rule="reference")
     plain = ob.Oracle(abi, cfg, sd, 64)
     b0 = plain.seed(99)
     o = ob.Oracle(abi, cfg, sd, 64)
@@ -70,3 +71,55 @@ def test_normalize_with_importance_and_develop(pkg, abi, ob):
     assert f_w.std() / f_w.mean() < 0.8 * f_p.std() / f_p.mean()
     with pytest.raises(ob.OracleError, match="before seed"):
         o.set_importance_map(imp)
+
+
+def _bdpt_dims(max_depth, rr_depth=5, direct_sampling=True):
+    """[sensor S | emitter E | direct Dd] of a bdpt chain (device_bdpt.h / binding.eval_lists_bdpt)."""
+    rr = max_depth + 1 - max(rr_depth, 0)
+    S = 2 * (max_depth + 1) + max(rr, 0); S += S & 1
+    E = 2 * max_depth + max(rr - 1, 0); E += E & 1
+    return S + E + (2 * (2 * max_depth - 1) if direct_sampling else 0)
+
+
+@pytest.mark.parametrize("tech", ["path", "bdpt"])
+def test_seed_rules(pkg, abi, ob, tech):
+    """drmlt_config.seed_rule. REFERENCE: seeds in proportion to lum(f) (pathsampler.cpp:901-905, the luminance read before
+    SplatList::normalize(importanceMap)). TARGET (the product's default): in proportion to lum(f / importance), the chains' own
+    target. b is the mean of lum(f) under both; a constant map makes the two rules pick the same samples."""
+    sd = pkg.scenes.cornell_c2(16)
+    kw = dict(technique=tech, type="orbital", max_depth=5, work_units=4096, direct_samples=-1, luminance_samples=60000)
+    imp = np.tile(np.where((np.arange(16) + 0.5) / 16 < 0.5, 0.02, 1.0), (16, 1)).astype(np.float32)
+    dim = 2 if tech == "path" else _bdpt_dims(5)
+    picks, b, left = {}, {}, {}
+    for rule in ("target", "reference"):
+        o = ob.Oracle(abi, abi.make_config(seed_rule=rule, **kw), sd, 64)
+        o.set_importance_map(imp)
+        b[rule] = o.seed(5)
+        picks[rule] = o.seed_indices()
+        cur, _ = o.chain_state(dim)
+        left[rule] = float((cur["x"] < 8).mean())
+        o.close()
+    assert b["target"] == b["reference"]
+    # where do the bootstrap samples put their luminance? (the bootstrap stream's own samples, by position of their main splat)
+    o = ob.Oracle(abi, abi.make_config(seed_rule="reference", **kw), sd, 64)
+    o.seed(5)
+    cur, _ = o.chain_state(dim)       # seeds ~ f: the share of chains on the left estimates the share of f there
+    share_f = float((cur["x"] < 8).mean())
+    o.close()
+    assert abs(left["reference"] - share_f) < 1e-12                      # the map does not enter the reference's rule
+    want = share_f / 0.02 / (share_f / 0.02 + (1 - share_f))             # f / importance: the left half weighs 50 x
+    if tech == "path":                                                   # (a bdpt list spreads over pixels: only the direction is checked)
+        assert abs(left["target"] - want) < 0.03, (left, want)
+    # (bdpt: a list is drawn 50 x more often as soon as ANY of its splats -- light-image splats included -- lies on the left, wherever
+    # its main splat is; the main splat's side therefore shifts less)
+    assert left["target"] > left["reference"] + (0.2 if tech == "path" else 0.05)
+    # a constant map: the same picks under both rules
+    flat = np.full((16, 16), 0.37, dtype=np.float32)
+    got = []
+    for rule in ("target", "reference"):
+        o = ob.Oracle(abi, abi.make_config(seed_rule=rule, **kw), sd, 64)
+        o.set_importance_map(flat)
+        o.seed(5)
+        got.append(o.seed_indices())
+        o.close()
+    assert (got[0] == got[1]).mean() > 0.999                             # (a pick on a CDF step can move by one sample in floating point)
