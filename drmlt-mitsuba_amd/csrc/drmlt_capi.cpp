@@ -872,11 +872,17 @@ int drmlt_run(drmlt_ctx *ctx, uint64_t total_mutations, volatile int *stop, drml
                        !getenv("DRMLT_NO_RUN_AHEAD");
     const uint64_t call_base = ctx->mutation_base, call_end = call_base + per_chain;
     const bool regroup = (ctx->cfg.technique == DRMLT_TECH_MMLT || ctx->cfg.technique == DRMLT_TECH_BDPT) && ctx->cfg.algo != DRMLT_ALGO_PSSMLT && ctx->P.exec_order && !getenv("DRMLT_NO_REGROUP");
+    int since_regroup = 0;
     while (done < per_chain) {
         if (stop && *stop) { rc = DRMLT_E_CANCELLED; break; }
         if (timed && std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count() >= (double) ctx->cfg.timeout_s) break;
         // shorter launches when somebody is watching (cancellation / progress / deadline latency ~ tens of ms)
-        const uint64_t slice = (stop || cb || timed) ? std::min(ctx->slice, 256) : (regroup && !ctx->regrouped ? std::min<int>(ctx->slice, getenv("DRMLT_REGROUP_FIRST") ? atoi(getenv("DRMLT_REGROUP_FIRST")) : (int) std::max<uint64_t>(32, std::min<uint64_t>(256, per_chain / 8))) : ctx->slice); // (regrouping: a short first launch -- an eighth of the call, 32 to 256 mutations -- to learn which chains are parked)
+        // (regrouping: a short first launch -- an eighth of the call, 32 to 256 mutations -- to learn which chains are parked;
+        // DRMLT_REGROUP_FIRST overrides its length, clamped to [1, slice]: a launch beyond 32 768 mutations would overflow the
+        // kernels' 16-bit event counters)
+        uint64_t first_len = std::max<uint64_t>(32, std::min<uint64_t>(256, per_chain / 8));
+        if (const char *e = getenv("DRMLT_REGROUP_FIRST")) first_len = (uint64_t) std::max(1, std::min(ctx->slice, atoi(e)));
+        const uint64_t slice = (stop || cb || timed) ? std::min(ctx->slice, 256) : (regroup && !ctx->regrouped ? std::min<uint64_t>(ctx->slice, first_len) : (uint64_t) ctx->slice);
         uint32_t n = (uint32_t) std::min<uint64_t>(slice, per_chain - done);
         evs.emplace_back();
         EventPair &ev = evs.back();
@@ -908,20 +914,30 @@ int drmlt_run(drmlt_ctx *ctx, uint64_t total_mutations, volatile int *stop, drml
         ctx->mutation_base += n;
         done += n;
         ctx->launches++;
-        if (regroup) { const int rr = regroup_chains(ctx, n); if (rr != DRMLT_OK) return rr; ctx->regrouped = true; }
+        // Regrouping costs a D2H copy, a host counting sort, an H2D copy and two stream synchronisations. With somebody watching
+        // (stop / progress / deadline: launches of 256 mutations, what the Mitsuba plugin always runs) it is done after the first
+        // launch of a call and then every fourth one -- the chains' work changes slowly; unwatched calls regroup after every
+        // (1024-mutation) launch. A failure ends the loop through the normal exit below: counters and timings are kept.
+        if (regroup && (!(stop || cb || timed) || !ctx->regrouped || ++since_regroup >= 4)) {
+            rc = regroup_chains(ctx, n);
+            if (rc != DRMLT_OK) break;
+            ctx->regrouped = true;
+            since_regroup = 0;
+        }
         if (stop || cb || timed) {
-            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            const hipError_t se = hipStreamSynchronize(ctx->stream);
+            if (se != hipSuccess) { rc = ctx->fail(DRMLT_E_DEVICE, "hipStreamSynchronize: %s", hipGetErrorString(se)); break; }
             if (cb) cb(done * ctx->n_chains, per_chain * ctx->n_chains, user);
         }
     }
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    { const hipError_t se = hipStreamSynchronize(ctx->stream); if (se != hipSuccess && rc == DRMLT_OK) rc = ctx->fail(DRMLT_E_DEVICE, "hipStreamSynchronize: %s", hipGetErrorString(se)); }
     for (const EventPair &e : evs) {
         const float ms = e.elapsed_ms();
         ctx->kernel_ms += ms;
         ctx->kt_ms += ms;
         ctx->kt_launches++;
     }
-    if (ahead && done < per_chain && done > 0) {
+    if (ahead && done < per_chain && done > 0 && (rc == DRMLT_OK || rc == DRMLT_E_CANCELLED)) {
         // stopped early (cancel / timeout): chains are at the last target or up to eight launches beyond it. One catch-up launch
         // brings everybody to the most advanced chain's count, so that a stopped render, too, has run every chain equally long.
         std::vector<uint32_t> h(ctx->n_chains);
@@ -940,7 +956,7 @@ int drmlt_run(drmlt_ctx *ctx, uint64_t total_mutations, volatile int *stop, drml
             ctx->launches++;
         }
     }
-    ctx->mutations += done * ctx->n_chains;
+    ctx->mutations += done * ctx->n_chains; // whatever ended the loop: what was launched is counted
     if (rc == DRMLT_E_CANCELLED) return ctx->fail(rc, "cancelled");
     return rc;
 }

@@ -21,6 +21,7 @@
 #include <rccl/rccl.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -135,7 +136,10 @@ void tile_range(const drmlt_ctx *ctx, int rank, int world, int &lo, int &hi) {
 }
 
 // Steps 2-5 of the exchange, once the summed tile sits in comm->tile: tile luminance, scalar all-reduce, develop.
-int finish_tile(drmlt_ctx *ctx, const RcclApi *R, double *b_inout, const float *direct_tile_or_null, float *tile_host_or_null, bool want_results = true) {
+// `aborted` (node exchange only): set by a rank whose collective could not be enqueued, after it has called ncclCommAbort on every
+// communicator of the node -- checked before the RCCL call so that no rank hands an aborted communicator to the library.
+int finish_tile(drmlt_ctx *ctx, const RcclApi *R, double *b_inout, const float *direct_tile_or_null, float *tile_host_or_null, bool want_results = true,
+                const std::atomic<bool> *aborted = nullptr) {
     drmlt_comm *c = ctx->comm;
     int lo, hi;
     tile_range(ctx, c->rank, c->world, lo, hi);
@@ -145,7 +149,10 @@ int finish_tile(drmlt_ctx *ctx, const RcclApi *R, double *b_inout, const float *
     launch_set2(c->scal.as<double>(), host[0], host[1], ctx->stream); // (a kernel, not a copy from pageable memory: nothing here waits for the host)
     if (npix) launch_lum_sum(c->tile.as<float>(), imp, npix, c->scal.as<double>(), ctx->stream);
     HIP_TRY(ctx, hipGetLastError());
-    if (c->comm) NCCL_TRY(ctx, R, R->AllReduce(c->scal.p, c->scal.p, 2, ncclDouble, ncclSum, c->comm, ctx->stream));
+    if (c->comm) {
+        if (aborted && aborted->load(std::memory_order_acquire)) return ctx->fail(DRMLT_E_DEVICE, "the film exchange was aborted by another rank");
+        NCCL_TRY(ctx, R, R->AllReduce(c->scal.p, c->scal.p, 2, ncclDouble, ncclSum, c->comm, ctx->stream));
+    }
     if (!want_results) { // nobody reads the tile or the mean b now: develop with the device-resident sums, no host round trip
         if (n) launch_develop_dev(c->tile.as<float>(), imp, c->scal.as<double>(), c->comm ? 1.f / (float) c->world : 1.f,
                                   1.f / ((float) ctx->P.width * (float) ctx->P.height), ctx->cfg.acceptance_map, n, c->out.as<float>(), ctx->stream);
@@ -438,20 +445,24 @@ int drmlt_node_develop(drmlt_node *node, const float *direct_rgb_or_null, float 
         if (hipSetDevice(c->device) != hipSuccess) return node->fail(DRMLT_E_DEVICE, "device " + std::to_string(c->device) + ": hipSetDevice failed");
         if (hipStreamQuery(c->stream) == hipErrorInvalidResourceHandle) return node->fail(DRMLT_E_DEVICE, "device " + std::to_string(c->device) + ": stream is gone");
     }
+    //  abort_all runs on the failing rank's thread while its peers may be inside finish_tile: it only ABORTS the
+    // communicators (ncclCommAbort is made to be called from another thread: it releases the peers' pending operations) and
+    // raises the flag; the handles themselves are written (nulled) after every thread has joined, never under a reader.
     std::mutex abort_mutex;
-    bool aborted = false;
+    std::atomic<bool> aborted{false};
     auto abort_all = [&]() {
         std::lock_guard<std::mutex> g(abort_mutex);
-        if (aborted) return;
-        aborted = true;
+        if (aborted.load(std::memory_order_relaxed)) return;
+        aborted.store(true, std::memory_order_release);
         for (drmlt_ctx *c : node->subs)
-            if (c->comm && c->comm->comm) { (void) R->CommAbort(c->comm->comm); c->comm->comm = nullptr; }
+            if (c->comm && c->comm->comm) (void) R->CommAbort(c->comm->comm);
     };
-    return for_each_rank(node, [&](int r) {
+    const int rc_all = for_each_rank(node, [&](int r) {
         drmlt_ctx *c = node->subs[r];
         int rc = DRMLT_OK;
         if (hipSetDevice(c->device) != hipSuccess) rc = c->fail(DRMLT_E_DEVICE, "hipSetDevice failed");
         const size_t count = (size_t) c->comm->tile_rows * W * 3;
+        if (rc == DRMLT_OK && aborted.load(std::memory_order_acquire)) rc = c->fail(DRMLT_E_DEVICE, "the film exchange was aborted by another rank");
         if (rc == DRMLT_OK) {
             const ncclResult_t nr = R->ReduceScatter(c->d_film.p, c->comm->tile.p, count, ncclFloat, ncclSum, c->comm->comm, c->stream);
             if (nr != ncclSuccess) rc = c->fail(DRMLT_E_DEVICE, "ncclReduceScatter: %s", R->GetErrorString(nr));
@@ -461,11 +472,14 @@ int drmlt_node_develop(drmlt_node *node, const float *direct_rgb_or_null, float 
             tile_range(c, r, n, lo, hi);
             const size_t off = (size_t) lo * W * 3;
             double b = node->b;
-            rc = finish_tile(c, R, &b, direct_rgb_or_null ? direct_rgb_or_null + off : nullptr, out_rgb + off);
+            rc = finish_tile(c, R, &b, direct_rgb_or_null ? direct_rgb_or_null + off : nullptr, out_rgb + off, true, &aborted);
         }
         if (rc != DRMLT_OK) abort_all();
         return rc;
     });
+    if (aborted.load()) // every thread has joined: the aborted communicators are gone, forget their handles
+        for (drmlt_ctx *c : node->subs) if (c->comm) c->comm->comm = nullptr;
+    return rc_all;
 }
 
 int drmlt_node_stats_get(drmlt_node *node, drmlt_stats *out) {
