@@ -98,15 +98,14 @@ DEV MhWeights mh_weights(bool mix, bool amap, bool do_second, float a1, float a2
 
 // Event counts of one decided mutation (the seven ratios of :34-49 are assembled from them on the host).
 DEV void mh_count(Counters &ct, bool large, bool acc1, bool acc2, bool do_second) {
-    if (large) {
-        ct.large_acc1l += 1u + (acc1 ? 1u << 16 : 0u);
-        if (do_second) ct.acc1b_secl += 1u << 16;
-        if (acc2) ct.secb_acc2l += 1u << 16;
-    } else {
-        if (acc1) ct.acc1b_secl += 1u;
-        if (do_second) ct.secb_acc2l += 1u;
-        if (acc2) ct.acc2b_rev += 1u;
-    }
+    // Every counter is updated unconditionally, by a selected VALUE. Written as `if (large) ct.a += .. else ct.b += ..` the two
+    // branches were merged into one add through a selected ADDRESS, and the counters then lived in scratch memory (12 bytes per
+    // lane in every chain kernel: VERDICT r03 #8).
+    const bool bold = !large;
+    ct.large_acc1l += (large ? 1u : 0u) + ((large && acc1) ? 1u << 16 : 0u);
+    ct.acc1b_secl += ((bold && acc1) ? 1u : 0u) + ((large && do_second) ? 1u << 16 : 0u);
+    ct.secb_acc2l += ((bold && do_second) ? 1u : 0u) + ((large && acc2) ? 1u << 16 : 0u);
+    ct.acc2b_rev += (bold && acc2) ? 1u : 0u;
 }
 
 // Acceptance map (:693-709). The reference swaps the accepted proposal into `current` FIRST and then calls

@@ -773,6 +773,68 @@ template <bool TRI> DEV void test_flat(const FlatRec &G, f3 o, f3 d, float tmin,
     best_ks = hit ? G.ks : best_ks;
 }
 
+// ---- cuboid records (host side and the argument why this equals the loop over the separate faces: box_merge.h)
+// The ray in the cuboid's own coordinates b in [0, 1]^3 (the affine map of a flat record), the three slabs, then the face the
+// ray ENTERS through (entry distance >= tmin) or, failing that -- the ray starts inside, or the scene has no face there: the
+// open side of a room -- the face it LEAVES through. Which of the two is needed is mostly the same for a whole wave (rays start
+// inside a room and outside a box), so each half sits behind a wave-uniform test. The hit is handed on as the face's half-word
+// (exists | code << 1 | kind << 4 | shade << 6) and the in-face coordinates (p, q) = (b[j], b[k]), j < k the other two axes;
+// trace_flat turns the winner's into the face's own (u, v) and record once, after the loops.
+#define BOX_FACE_FLAG 0x40000000
+typedef const DPrimBox __attribute__((address_space(4))) *ScalarBoxPtr;
+struct BoxRec {
+    float2v cx, cy, cz, cw;
+    float z0, z1, z2, z3;
+    uint32_t f0, f1, f2; // face words of axes 0, 1, 2: low half side 0 (b = 0), high half side 1 (b = 1)
+};
+DEV void test_box(const BoxRec &G, f3 o, f3 d, float tmin, float &best_t, float2v &best_uv, int &best_ks) {
+    // (read once, used by both halves: a select between two single-use loads of the record becomes a load through a selected
+    // ADDRESS, and the record then lives in scratch memory)
+    const uint32_t f0 = G.f0, f1 = G.f1, f2 = G.f2;
+    const float ldz = fmaf(G.z0, d.x, fmaf(G.z1, d.y, G.z2 * d.z));
+    const float loz = fmaf(G.z0, o.x, fmaf(G.z1, o.y, fmaf(G.z2, o.z, G.z3)));
+    const float2v lo = G.cx * o.x + (G.cy * o.y + (G.cz * o.z + G.cw));
+    const float2v ld = G.cx * d.x + (G.cy * d.y + G.cz * d.z);
+    const float ix = fast_rcp(ld.x), iy = fast_rcp(ld.y), iz = fast_rcp(ldz);
+    // slab distances. (1 - lo) * inv, not t0 + inv: a ray parallel to a slab (inv = inf) must see (-inf, +inf) inside it and
+    // two equal infinities outside
+    const float ax = -lo.x * ix, bx = (1.f - lo.x) * ix, ay = -lo.y * iy, by = (1.f - lo.y) * iy, az = -loz * iz, bz = (1.f - loz) * iz;
+    const float nx = fminf(ax, bx), fx = fmaxf(ax, bx), ny = fminf(ay, by), fy = fmaxf(ay, by), nz = fminf(az, bz), fz = fmaxf(az, bz);
+    const float tnear = fmaxf(fmaxf(nx, ny), nz), tfar = fminf(fminf(fx, fy), fz);
+    const bool through = tnear <= tfar && tfar >= tmin && tnear <= best_t;
+    // entry: moving along +axis the ray enters through side 0, along -axis through side 1
+    bool use_entry = false, e0 = false, e1 = false;
+    uint32_t he = 0u;
+    const bool want_entry = through && tnear >= tmin;
+    if (__ballot(want_entry)) { // wave-uniform
+        e0 = nx == tnear; e1 = ny == tnear;
+        const float lde = e0 ? ld.x : (e1 ? ld.y : ldz);
+        const uint32_t we = e0 ? f0 : (e1 ? f1 : f2);
+        he = lde < 0.f ? we >> 16 : we & 0xffffu;
+        use_entry = want_entry && (he & 1u) != 0u;
+    }
+    // exit: along +axis through side 1, along -axis through side 0
+    bool x0 = false, x1 = false;
+    uint32_t hx = 0u;
+    if (__ballot(through && !use_entry)) { // wave-uniform
+        x0 = fx == tfar; x1 = fy == tfar;
+        const float ldx = x0 ? ld.x : (x1 ? ld.y : ldz);
+        const uint32_t wx = x0 ? f0 : (x1 ? f1 : f2);
+        hx = ldx < 0.f ? wx & 0xffffu : wx >> 16;
+    }
+    const float tc = use_entry ? tnear : tfar;
+    const uint32_t hc = use_entry ? he : hx;
+    const bool a0 = use_entry ? e0 : x0, a1 = use_entry ? e1 : x1;
+    const float2v bxy = ld * tc + lo;
+    const float bzz = fmaf(ldz, tc, loz);
+    const float p = a0 ? bxy.y : bxy.x, q = (a0 || a1) ? bzz : bxy.y; // axis 0: (y, z), axis 1: (x, z), axis 2: (x, y)
+    const bool hit = through && (hc & 1u) != 0u && tc >= tmin && tc <= best_t;
+    best_t = hit ? tc : best_t;
+    best_uv.x = hit ? p : best_uv.x;
+    best_uv.y = hit ? q : best_uv.y;
+    best_ks = hit ? (int) (hc | BOX_FACE_FLAG) : best_ks;
+}
+
 template <bool TRI> DEV Hit trace_flat(const DParams &P, f3 o, f3 d, float tmin, float tmax) {
     ScalarFlatPtr p = (ScalarFlatPtr) (uintptr_t) P.prims_flat;
     // VOLATILE scalar loads (three per record: 8 + 4 + 1 dwords): they stay where the pipeline below puts them. Left to its
@@ -797,20 +859,57 @@ template <bool TRI> DEV Hit trace_flat(const DParams &P, f3 o, f3 d, float tmin,
     float best_t = tmax;
     float2v best_uv = {0.f, 0.f};
     int best_ks = -1;
-    const int n = P.n_flat;
-    FlatRec A, B;
-    load(p, A);
-    for (int i = 0; i < n; i += 2, p += 2) { // records n and n + 1 are sentinels
-        PINF(A);
-        load(p + 1, B);
-        test_flat<TRI>(A, o, d, tmin, best_t, best_uv, best_ks);
-        PINF(B);
-        load(p + 2, A);
-        test_flat<TRI>(B, o, d, tmin, best_t, best_uv, best_ks);
+    // ---- cuboids first (record n_box is a sentinel: the read-ahead needs no clamp)
+    if (P.n_box > 0) {
+        auto loadb = [](ScalarBoxPtr q, BoxRec &G) {
+            typedef float f8v __attribute__((ext_vector_type(8)));
+            typedef float f4v __attribute__((ext_vector_type(4)));
+            const f8v c = *(const volatile f8v __attribute__((address_space(4))) *) &q->c[0];
+            const f4v z = *(const volatile f4v __attribute__((address_space(4))) *) &q->rz[0];
+            // (three separate scalar loads: as elements of one loaded vector the per-lane choice among them in test_box became an
+            // indexed load from a copy of the vector in scratch memory)
+            typedef const volatile uint32_t __attribute__((address_space(4))) *SU;
+            G.f0 = *(SU) &q->fw[0]; G.f1 = *(SU) &q->fw[1]; G.f2 = *(SU) &q->fw[2];
+            G.cx = float2v{c[0], c[1]}; G.cy = float2v{c[2], c[3]}; G.cz = float2v{c[4], c[5]}; G.cw = float2v{c[6], c[7]};
+            G.z0 = z[0]; G.z1 = z[1]; G.z2 = z[2]; G.z3 = z[3];
+        };
+        ScalarBoxPtr pb = (ScalarBoxPtr) (uintptr_t) P.prims_box;
+        BoxRec A, B;
+        loadb(pb, A);
+        for (int i = 0; i < P.n_box; i += 2, pb += 2) {
+            asm volatile("" ::"s"(A.cx.x), "s"(A.z0), "s"(A.f0));
+            loadb(pb + 1, B);
+            test_box(A, o, d, tmin, best_t, best_uv, best_ks);
+            if (i + 1 < P.n_box) {
+                asm volatile("" ::"s"(B.cx.x), "s"(B.z0), "s"(B.f0));
+                loadb(pb + 2, A);
+                test_box(B, o, d, tmin, best_t, best_uv, best_ks);
+            }
+        }
+    }
+    const int n = P.n_flat_rec;
+    if (n > 0) {
+        FlatRec A, B;
+        load(p, A);
+        for (int i = 0; i < n; i += 2, p += 2) { // records n and n + 1 are sentinels
+            PINF(A);
+            load(p + 1, B);
+            test_flat<TRI>(A, o, d, tmin, best_t, best_uv, best_ks);
+            PINF(B);
+            load(p + 2, A);
+            test_flat<TRI>(B, o, d, tmin, best_t, best_uv, best_ks);
+        }
     }
 #undef PINF
     Hit h{-1, best_t, best_uv.x, best_uv.y};
     if (best_ks >= 0) {
+        if (best_ks & BOX_FACE_FLAG) { // a cuboid's face: its own (u, v) from the in-face coordinates, its own record
+            const uint32_t hc = (uint32_t) best_ks & 0xffffu;
+            const float uu = (hc & 2u) ? h.v : h.u, vv = (hc & 2u) ? h.u : h.v;
+            h.u = (hc & 4u) ? 1.f - uu : uu;
+            h.v = (hc & 8u) ? 1.f - vv : vv;
+            best_ks = (int) (((hc >> 4) & 3u) | ((hc >> 6) << 8));
+        }
         h.prim = best_ks >> 8;
         if ((best_ks & 0xff) == PRIM_QUAD2) { // sub-triangle (a,b,c) for v <= u, (a,c,d) otherwise; its own barycentrics
             const bool second = h.v > h.u;
@@ -827,7 +926,7 @@ template <int FEAT = 15> DEV Hit trace(const DParams &P, f3 o, f3 d, float tmin,
     if (P.prims_flat) {
         Hit h = P.has_plain_tri ? trace_flat<true>(P, o, d, tmin, tmax) : trace_flat<false>(P, o, d, tmin, tmax);
         if (FEAT & 4) // the spheres of the scene follow the flat records; same wave-uniform scalar loads, one at a time
-            for (int i = P.n_flat; i < P.n_prims; ++i) {
+            for (int i = P.n_flat; i < P.n_prims; ++i) { // (P.prims: every record of the scene, flat ones first -- n_flat of them, cuboid faces included)
                 ScalarPrimPtr sp = (ScalarPrimPtr) (uintptr_t) P.prims;
                 DPrim G;
 #pragma unroll

@@ -39,6 +39,16 @@ struct DPrimFlat {
     int32_t pad[3];
 };
 
+// A cuboid (box_merge.h): world -> cuboid coordinates b in [0, 1]^3, rows laid out as DPrimFlat's, and one word per axis with
+// the two faces in the planes b[axis] = 0 (low half) and 1 (high half): exists | code << 1 | kind << 4 | shade << 6
+// (code: how the face's own (u, v) follow from the in-face coordinates; kind: PRIM_RECTANGLE / PRIM_QUAD2; shade < 1024).
+struct DPrimBox {
+    float c[8];
+    float rz[4];
+    uint32_t fw[3];
+    int32_t pad;
+};
+
 struct DShade {
     float origin[3]; // tri: p0; rect: centre; sphere: centre
     float eu[3];     // tri: p1-p0; rect: objectToWorld column 0; sphere: eu[0] = radius
@@ -148,6 +158,9 @@ struct DParams {
     uint32_t bvh_ovf_lanes;      // column count of that area (>= lanes of the launch)
     int32_t trace_vote;          // traversal: the wave tests nodes when 16 * (lanes at a leaf) <= trace_vote * (lanes at a node), leaves otherwise
     int32_t pool_refill;         // k_mutate_v5: idle lanes take pending rays off the queue inside a trace phase once this many lanes have run dry
+    const DPrimBox *prims_box;   // cuboid records of the brute-force loop (n_box of them + one sentinel), tested before prims_flat
+    int32_t n_box;
+    int32_t n_flat_rec;          // records in prims_flat (flat records that are no cuboid's face) -- n_flat counts the flat records of `prims`
     int32_t boot_weighted;       // bootstrap kernels: also write each sample's luminance under the importance map, to lum_out[n + i] (two-stage MLT: seeds drawn from the chains' own target, drmlt_capi.cpp)
 };
 

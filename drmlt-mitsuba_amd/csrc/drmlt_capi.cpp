@@ -2,6 +2,7 @@
 // scene flattening, bootstrap/seeding host logic and kernel orchestration. Everything that
 // touches path evaluation runs in the HIP kernels of kernels.hip; there is no CPU fallback.
 #include "../../include/drmlt_abi.h"
+#include "box_merge.h"
 #include "bvh_build.h"
 #include "device_types.h"
 #include "drmlt_ctx.h"
@@ -74,7 +75,7 @@ bool invert3x4(const double *m, double *o) {
 
 // Flatten the scene into intersection + shading records. Returns "" or an error.
 std::string build_scene(drmlt_ctx *ctx, const drmlt_scene &s, std::vector<DBsdf> &bsdfs, std::vector<DEmitter> &emitters,
-                        std::vector<PrimBounds> &bounds) {
+                        std::vector<PrimBounds> &bounds, std::vector<QuadGeo> &geo) {
     if (s.n_shapes <= 0) return "scene has no shapes";
     if (s.n_emitters <= 0) return "scene has no emitters";
     for (int i = 0; i < s.n_bsdfs; ++i) {
@@ -103,6 +104,8 @@ std::string build_scene(drmlt_ctx *ctx, const drmlt_scene &s, std::vector<DBsdf>
         DPrim g{};
         DShade sh{};
         PrimBounds pb;
+        QuadGeo qg{};
+        qg.usable = false;
         sh.bsdf = in.bsdf; // | kind << 24, set below
         sh.emitter = in.emitter < 0 ? -1 : in.emitter;
         double m[12], inv[12];
@@ -143,6 +146,8 @@ std::string build_scene(drmlt_ctx *ctx, const drmlt_scene &s, std::vector<DBsdf>
             }
             sh.inv_len_eu = (float) (1.0 / (2.0 * lu));
             sh.inv_area = (float) (1.0 / (4.0 * lu * lv)); // |dpdu| |dpdv| with dpdu = 2 eu
+            for (int k = 0; k < 3; ++k) { qg.a[k] = m[k * 4 + 3] - eu[k] - ev[k]; qg.e1[k] = 2.0 * eu[k]; qg.e2[k] = 2.0 * ev[k]; }
+            qg.usable = true; // the record's (u, v) run over [0, 1]^2 from that corner
             for (int k = 0; k < 3; ++k) {
                 double c = m[k * 4 + 3], ext = std::fabs(eu[k]) + std::fabs(ev[k]);
                 pb.lo[k] = (float) (c - ext); pb.hi[k] = (float) (c + ext);
@@ -165,6 +170,7 @@ std::string build_scene(drmlt_ctx *ctx, const drmlt_scene &s, std::vector<DBsdf>
         ctx->prims.push_back(g);
         ctx->shade.push_back(sh);
         bounds.push_back(pb);
+        geo.push_back(qg);
     }
     // ---- merge triangle pairs (a,b,c),(a,c,d) that form a parallelogram into one intersection record.
     // Exact: the hit is attributed to the sub-triangle it falls in, with that triangle's barycentrics and
@@ -172,6 +178,7 @@ std::string build_scene(drmlt_ctx *ctx, const drmlt_scene &s, std::vector<DBsdf>
     if (!getenv("DRMLT_NO_QUAD_MERGE")) {
         std::vector<DPrim> merged;
         std::vector<PrimBounds> mb;
+        std::vector<QuadGeo> mg;
         for (size_t i = 0; i < ctx->prims.size(); ++i) {
             bool did = false;
             if (i + 1 < ctx->prims.size() && s.shapes[i].type == DRMLT_SHAPE_TRIANGLE && s.shapes[i + 1].type == DRMLT_SHAPE_TRIANGLE &&
@@ -198,16 +205,20 @@ std::string build_scene(drmlt_ctx *ctx, const drmlt_scene &s, std::vector<DBsdf>
                         g.shade = (int32_t) i; // records i (a,b,c) and i+1 (a,c,d)
                         PrimBounds pb = bounds[i];
                         for (int k = 0; k < 3; ++k) { pb.lo[k] = std::min(pb.lo[k], bounds[i + 1].lo[k]); pb.hi[k] = std::max(pb.hi[k], bounds[i + 1].hi[k]); }
-                        merged.push_back(g); mb.push_back(pb);
+                        QuadGeo qg{};
+                        for (int k = 0; k < 3; ++k) { qg.a[k] = a[k]; qg.e1[k] = e1[k]; qg.e2[k] = e2[k]; }
+                        qg.usable = true;
+                        merged.push_back(g); mb.push_back(pb); mg.push_back(qg);
                         ++i;
                         did = true;
                     }
                 }
             }
-            if (!did) { merged.push_back(ctx->prims[i]); mb.push_back(bounds[i]); }
+            if (!did) { merged.push_back(ctx->prims[i]); mb.push_back(bounds[i]); mg.push_back(geo[i]); }
         }
         ctx->prims.swap(merged);
         bounds.swap(mb);
+        geo.swap(mg);
     }
     // emitters + DiscreteDistribution over sampling weights (scene.cpp m_emitterPDF, pmf.h:109-121)
     double total = 0;
@@ -352,7 +363,8 @@ drmlt_ctx *drmlt_create(const drmlt_config *cfg, const drmlt_scene *scene, int d
     std::vector<DBsdf> bsdfs;
     std::vector<DEmitter> emitters;
     std::vector<PrimBounds> bounds;
-    std::string e = build_scene(ctx, *scene, bsdfs, emitters, bounds);
+    std::vector<QuadGeo> geo; // world-space parallelograms of the flat records (box_merge.h)
+    std::string e = build_scene(ctx, *scene, bsdfs, emitters, bounds, geo);
     if (!e.empty()) return bail(ctx, e);
 
     // ---- acceleration structure: brute force over wave-uniform records for tiny scenes, BVH otherwise
@@ -390,8 +402,16 @@ drmlt_ctx *drmlt_create(const drmlt_config *cfg, const drmlt_scene *scene, int d
         ctx->prims.swap(np);
     }
 
-    if (!P.use_bvh) // brute-force order: flat records first, spheres last (trace(): flat loop, then the sphere loop)
-        std::stable_partition(ctx->prims.begin(), ctx->prims.end(), [](const DPrim &g) { return g.type != PRIM_SPHERE; });
+    if (!P.use_bvh) { // brute-force order: flat records first, spheres last (trace(): flat loop, then the sphere loop)
+        std::vector<size_t> perm(ctx->prims.size());
+        for (size_t i = 0; i < perm.size(); ++i) perm[i] = i;
+        std::stable_partition(perm.begin(), perm.end(), [&](size_t i) { return ctx->prims[i].type != PRIM_SPHERE; });
+        std::vector<DPrim> np(perm.size());
+        std::vector<QuadGeo> ng(perm.size());
+        for (size_t i = 0; i < perm.size(); ++i) { np[i] = ctx->prims[perm[i]]; ng[i] = geo[perm[i]]; }
+        ctx->prims.swap(np);
+        geo.swap(ng);
+    }
     for (DPrim &g : ctx->prims) g.kind_shade = g.type | (g.shade << 8);
     auto up = [&](DevBuf &b, const void *src, size_t bytes) -> bool {
         if (b.alloc(std::max<size_t>(bytes, 64)) != hipSuccess) return false;
@@ -407,20 +427,59 @@ drmlt_ctx *drmlt_create(const drmlt_config *cfg, const drmlt_scene *scene, int d
     if (ok && P.use_bvh) ok = up(ctx->d_bvh, nodes4.data(), nodes4.size() * sizeof(DBvh4Node));
     // flat-primitive fast path of the brute-force loop: interleaved records + two sentinels no ray can hit
     // (ld.z = 0, lo.z = 1: t = -inf fails t >= tmin)
-    P.prims_flat = nullptr; P.has_plain_tri = 0; P.n_flat = 0;
+    P.prims_flat = nullptr; P.has_plain_tri = 0; P.n_flat = 0; P.n_flat_rec = 0; P.prims_box = nullptr; P.n_box = 0;
     const bool flat_loop = !P.use_bvh && !getenv("DRMLT_NO_FLAT_LOOP");
-    for (const DPrim &g : ctx->prims) { if (g.type != PRIM_SPHERE) P.n_flat++; if (g.type == PRIM_TRIANGLE) P.has_plain_tri = 1; }
+    for (const DPrim &g : ctx->prims) if (g.type != PRIM_SPHERE) P.n_flat++;
     if (ok && flat_loop) {
-        std::vector<DPrimFlat> flat((size_t) P.n_flat + 2);
-        for (size_t i = 0; i < (size_t) P.n_flat; ++i) {
-            const DPrim &g = ctx->prims[i];
-            DPrimFlat &f = flat[i];
-            for (int c = 0; c < 4; ++c) { f.c[2 * c] = g.m[c]; f.c[2 * c + 1] = g.m[4 + c]; f.rz[c] = g.m[8 + c]; }
-            f.kind_shade = g.kind_shade; f.pad[0] = f.pad[1] = f.pad[2] = 0;
+        // Faces that bound a parallelepiped -- a `cube`'s six merged triangle pairs, the walls of a room -- become ONE cuboid
+        // record (box_merge.h; device_path.h: test_box): config 2's 18 records -> 1 + 3 cuboids. DRMLT_NO_BOX_MERGE: the
+        // separate faces (the tests compare the two).
+        std::vector<char> in_box((size_t) P.n_flat, 0);
+        std::vector<DPrimBox> boxes;
+        if (!getenv("DRMLT_NO_BOX_MERGE")) {
+            std::vector<QuadGeo> fg(geo.begin(), geo.begin() + P.n_flat);
+            for (size_t i = 0; i < fg.size(); ++i) // a record's shading index must fit the face half-word
+                if (ctx->prims[i].shade >= 1024 || (ctx->prims[i].type != PRIM_RECTANGLE && ctx->prims[i].type != PRIM_QUAD2)) fg[i].usable = false;
+            for (const BoxGeo &bg : find_boxes(fg)) {
+                double m[12], inv[12];
+                for (int r = 0; r < 3; ++r) { m[r * 4] = bg.E[0][r]; m[r * 4 + 1] = bg.E[1][r]; m[r * 4 + 2] = bg.E[2][r]; m[r * 4 + 3] = bg.a[r]; }
+                if (!invert3x4(m, inv)) continue;
+                DPrimBox b{};
+                for (int c = 0; c < 4; ++c) { b.c[2 * c] = (float) inv[c]; b.c[2 * c + 1] = (float) inv[4 + c]; b.rz[c] = (float) inv[8 + c]; }
+                for (int f = 0; f < 6; ++f) {
+                    if (bg.face[f] < 0) continue;
+                    const DPrim &g = ctx->prims[(size_t) bg.face[f]];
+                    const uint32_t half = 1u | ((uint32_t) bg.code[f] << 1) | ((uint32_t) g.type << 4) | ((uint32_t) g.shade << 6);
+                    b.fw[f >> 1] |= half << ((f & 1) ? 16 : 0);
+                    in_box[(size_t) bg.face[f]] = 1;
+                }
+                boxes.push_back(b);
+            }
+            if (getenv("DRMLT_VERBOSE")) fprintf(stderr, "[drmlt] brute-force loop: %d flat records, %zu of them as the faces of %zu cuboids\n", P.n_flat,
+                                                 (size_t) std::count(in_box.begin(), in_box.end(), 1), boxes.size());
         }
-        for (size_t i = (size_t) P.n_flat; i < flat.size(); ++i) { memset(&flat[i], 0, sizeof(DPrimFlat)); flat[i].rz[3] = 1.f; flat[i].kind_shade = PRIM_RECTANGLE; }
+        std::vector<DPrimFlat> flat;
+        for (size_t i = 0; i < (size_t) P.n_flat; ++i) {
+            if (in_box[i]) continue;
+            const DPrim &g = ctx->prims[i];
+            if (g.type == PRIM_TRIANGLE) P.has_plain_tri = 1;
+            DPrimFlat f{};
+            for (int c = 0; c < 4; ++c) { f.c[2 * c] = g.m[c]; f.c[2 * c + 1] = g.m[4 + c]; f.rz[c] = g.m[8 + c]; }
+            f.kind_shade = g.kind_shade;
+            flat.push_back(f);
+        }
+        P.n_flat_rec = (int) flat.size();
+        for (int k = 0; k < 2; ++k) { DPrimFlat f{}; f.rz[3] = 1.f; f.kind_shade = PRIM_RECTANGLE; flat.push_back(f); }
         ok = up(ctx->d_prims_flat, flat.data(), flat.size() * sizeof(DPrimFlat));
         if (ok) P.prims_flat = ctx->d_prims_flat.as<DPrimFlat>();
+        if (ok && !boxes.empty()) {
+            P.n_box = (int) boxes.size();
+            boxes.push_back(DPrimBox{}); // sentinel for the read-ahead (never tested)
+            ok = up(ctx->d_prims_box, boxes.data(), boxes.size() * sizeof(DPrimBox));
+            if (ok) P.prims_box = ctx->d_prims_box.as<DPrimBox>();
+        }
+    } else {
+        for (const DPrim &g : ctx->prims) if (g.type == PRIM_TRIANGLE) P.has_plain_tri = 1;
     }
     if (!ok) return bail(ctx, "device allocation/upload of the scene failed");
 

@@ -956,7 +956,11 @@ struct PoolRowSampler {
     DEV float y_raw(uint32_t k) { // iid Kelemen step, small (the only caller: mira_ratio)
         FP_STRICT;
         if (cached != (k >> 2)) { cached = k >> 2; blk = philox4x32_10(mira_k0, mira_k1, cached, mira_major, mira_chain, TAG_S1); }
-        const uint32_t c = k & 3u, w = c == 0u ? blk.x : (c == 1u ? blk.y : (c == 2u ? blk.z : blk.w));
+        // (values, not loads: a select between two single-use loads of this struct's fields becomes a load through a selected
+        // ADDRESS and the whole sampler -- 60 bytes per lane -- then lives in scratch memory: VERDICT r03 #8)
+        uint32_t bx = blk.x, by = blk.y, bz = blk.z, bw = blk.w;
+        asm volatile("" : "+v"(bx), "+v"(by), "+v"(bz), "+v"(bw));
+        const uint32_t c = k & 3u, w = (c & 2u) ? ((c & 1u) ? bw : bz) : ((c & 1u) ? by : bx);
         return x(k) + kelemen_sample(u32_to_unit(w), KELEMEN_S2);
     }
     DEV float z_raw(uint32_t k) const { return row(k); }

@@ -62,12 +62,13 @@ def test_bvh_and_brute_force_agree_on_device(pkg, ob, native_lib):
     u = np.random.default_rng(3).random((8192, 50), dtype=np.float32)
     cfg = pkg.abi.make_config(type="orbital", max_depth=8, direct_samples=-1, work_units=64)
     os.environ["DRMLT_BVH_THRESHOLD"] = "1000000"
+    os.environ["DRMLT_NO_BOX_MERGE"] = "1"   # the loop over the separate faces, as the leaves hold them (cuboid records: tests/test_gpu_boxes.py)
     a = pkg.Context(cfg, sd).eval_paths(u)
     os.environ["DRMLT_BVH_THRESHOLD"] = "0"
     try:
         b = pkg.Context(cfg, sd).eval_paths(u)
     finally:
-        del os.environ["DRMLT_BVH_THRESHOLD"]
+        del os.environ["DRMLT_BVH_THRESHOLD"], os.environ["DRMLT_NO_BOX_MERGE"]
     same = a["n_dims"] == b["n_dims"]
     assert same.mean() > 0.999
     assert np.allclose(a["luminance"][same], b["luminance"][same], rtol=1e-4, atol=1e-6)
@@ -89,7 +90,11 @@ def test_deep_bvh_spills_its_traversal_stack(pkg, ob, native_lib, capfd):
     u = np.random.default_rng(5).random((8192, 50), dtype=np.float32)
     cfg = pkg.abi.make_config(type="orbital", max_depth=8, direct_samples=-1, work_units=64)
     os.environ["DRMLT_BVH_THRESHOLD"] = "1000000"
-    a = pkg.Context(cfg, sd).eval_paths(u)
+    os.environ["DRMLT_NO_BOX_MERGE"] = "1"
+    try:
+        a = pkg.Context(cfg, sd).eval_paths(u)
+    finally:
+        del os.environ["DRMLT_NO_BOX_MERGE"]
     os.environ["DRMLT_BVH_THRESHOLD"] = "0"
     os.environ["DRMLT_VERBOSE"] = "1"
     try:
@@ -390,10 +395,11 @@ def test_large_scene_short_stack_column_spills_and_refills(pkg, ob, native_lib, 
     u = np.random.default_rng(3).random((4096, 50), dtype=np.float32)
     b = pkg.Context(cfg, sd).eval_paths(u)
     os.environ["DRMLT_BVH_THRESHOLD"] = "1000000"
+    os.environ["DRMLT_NO_BOX_MERGE"] = "1"
     try:
         a = pkg.Context(cfg, sd).eval_paths(u)
     finally:
-        del os.environ["DRMLT_BVH_THRESHOLD"]
+        del os.environ["DRMLT_BVH_THRESHOLD"], os.environ["DRMLT_NO_BOX_MERGE"]
     same = a["n_dims"] == b["n_dims"]
     assert same.mean() > 0.995
     assert np.allclose(a["luminance"][same], b["luminance"][same], rtol=1e-4, atol=1e-6)
@@ -443,7 +449,7 @@ def test_forced_bvh_on_scenes_with_spheres_and_glossy_surfaces(pkg, ob, scene, k
     n_chains = 2048
     cfg = pkg.abi.make_config(max_depth=8, direct_samples=-1, luminance_samples=20000, work_units=n_chains, sample_count=1, **kw)
     u = np.random.default_rng(11).random((8192, 50), dtype=np.float32)
-    brute = _ctx_with_env(pkg, cfg, sd, DRMLT_BVH_THRESHOLD=1000000).eval_paths(u)
+    brute = _ctx_with_env(pkg, cfg, sd, DRMLT_BVH_THRESHOLD=1000000, DRMLT_NO_BOX_MERGE=1).eval_paths(u)
     bvh = _ctx_with_env(pkg, cfg, sd, DRMLT_BVH_THRESHOLD=0).eval_paths(u)
     same = brute["n_dims"] == bvh["n_dims"]
     assert same.mean() > 0.995
