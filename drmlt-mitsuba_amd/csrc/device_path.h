@@ -787,9 +787,26 @@ struct BoxRec {
     float z0, z1, z2, z3;
     uint32_t f0, f1, f2; // face words of axes 0, 1, 2: low half side 0 (b = 0), high half side 1 (b = 1)
 };
+// ONE candidate face for a lane: the face the ray enters through (`leave` false) or leaves through. Moving along +axis a ray
+// enters through side 0 and leaves through side 1, along -axis the other way round: side = (ld[axis] < 0) != leave. Everything by
+// value (arguments and result): through references the choice among the three face words compiles to a load through a selected
+// address, and the words then live in scratch memory.
+struct BoxCand { float t, p, q; uint32_t hc; };
+DEV BoxCand box_candidate(bool leave, float nx, float ny, float fx, float fy, float tnear, float tfar, float2v lo, float2v ld, float loz, float ldz,
+                          uint32_t f0, uint32_t f1, uint32_t f2) {
+    BoxCand c;
+    c.t = leave ? tfar : tnear;
+    const float cx = leave ? fx : nx, cy = leave ? fy : ny;
+    const bool a0 = cx == c.t, a1 = cy == c.t;                        // the axis whose plane the ray crosses at t
+    const float lda = a0 ? ld.x : (a1 ? ld.y : ldz);
+    const uint32_t w = a0 ? f0 : (a1 ? f1 : f2);
+    c.hc = ((lda < 0.f) != leave) ? w >> 16 : w & 0xffffu;
+    const float2v bxy = ld * c.t + lo;
+    const float bzz = fmaf(ldz, c.t, loz);
+    c.p = a0 ? bxy.y : bxy.x; c.q = (a0 || a1) ? bzz : bxy.y;       // in-face coordinates: axis 0 (y, z), 1 (x, z), 2 (x, y)
+    return c;
+}
 DEV void test_box(const BoxRec &G, f3 o, f3 d, float tmin, float &best_t, float2v &best_uv, int &best_ks) {
-    // (read once, used by both halves: a select between two single-use loads of the record becomes a load through a selected
-    // ADDRESS, and the record then lives in scratch memory)
     const uint32_t f0 = G.f0, f1 = G.f1, f2 = G.f2;
     const float ldz = fmaf(G.z0, d.x, fmaf(G.z1, d.y, G.z2 * d.z));
     const float loz = fmaf(G.z0, o.x, fmaf(G.z1, o.y, fmaf(G.z2, o.z, G.z3)));
@@ -801,38 +818,23 @@ DEV void test_box(const BoxRec &G, f3 o, f3 d, float tmin, float &best_t, float2
     const float ax = -lo.x * ix, bx = (1.f - lo.x) * ix, ay = -lo.y * iy, by = (1.f - lo.y) * iy, az = -loz * iz, bz = (1.f - loz) * iz;
     const float nx = fminf(ax, bx), fx = fmaxf(ax, bx), ny = fminf(ay, by), fy = fmaxf(ay, by), nz = fminf(az, bz), fz = fmaxf(az, bz);
     const float tnear = fmaxf(fmaxf(nx, ny), nz), tfar = fminf(fminf(fx, fy), fz);
+    // One candidate per lane: the entry face if the ray comes from outside (entry distance >= tmin), the exit face otherwise. All
+    // selects on values (a flag that lives across a branch costs a v_cndmask and a v_cmp at every merge).
     const bool through = tnear <= tfar && tfar >= tmin && tnear <= best_t;
-    // entry: moving along +axis the ray enters through side 0, along -axis through side 1
-    bool use_entry = false, e0 = false, e1 = false;
-    uint32_t he = 0u;
-    const bool want_entry = through && tnear >= tmin;
-    if (__ballot(want_entry)) { // wave-uniform
-        e0 = nx == tnear; e1 = ny == tnear;
-        const float lde = e0 ? ld.x : (e1 ? ld.y : ldz);
-        const uint32_t we = e0 ? f0 : (e1 ? f1 : f2);
-        he = lde < 0.f ? we >> 16 : we & 0xffffu;
-        use_entry = want_entry && (he & 1u) != 0u;
+    const bool inside = !(tnear >= tmin);
+    BoxCand c = box_candidate(inside, nx, ny, fx, fy, tnear, tfar, lo, ld, loz, ldz, f0, f1, f2);
+    // the scene has no face where the ray enters (the open side of a room seen from outside): the face it leaves through. Rare, and
+    // then for many lanes at once: behind a wave-uniform test.
+    const bool hole = through && !inside && (c.hc & 1u) == 0u;
+    if (__ballot(hole)) {
+        const BoxCand c2 = box_candidate(true, nx, ny, fx, fy, tnear, tfar, lo, ld, loz, ldz, f0, f1, f2);
+        c.t = hole ? c2.t : c.t; c.p = hole ? c2.p : c.p; c.q = hole ? c2.q : c.q; c.hc = hole ? c2.hc : c.hc;
     }
-    // exit: along +axis through side 1, along -axis through side 0
-    bool x0 = false, x1 = false;
-    uint32_t hx = 0u;
-    if (__ballot(through && !use_entry)) { // wave-uniform
-        x0 = fx == tfar; x1 = fy == tfar;
-        const float ldx = x0 ? ld.x : (x1 ? ld.y : ldz);
-        const uint32_t wx = x0 ? f0 : (x1 ? f1 : f2);
-        hx = ldx < 0.f ? wx & 0xffffu : wx >> 16;
-    }
-    const float tc = use_entry ? tnear : tfar;
-    const uint32_t hc = use_entry ? he : hx;
-    const bool a0 = use_entry ? e0 : x0, a1 = use_entry ? e1 : x1;
-    const float2v bxy = ld * tc + lo;
-    const float bzz = fmaf(ldz, tc, loz);
-    const float p = a0 ? bxy.y : bxy.x, q = (a0 || a1) ? bzz : bxy.y; // axis 0: (y, z), axis 1: (x, z), axis 2: (x, y)
-    const bool hit = through && (hc & 1u) != 0u && tc >= tmin && tc <= best_t;
-    best_t = hit ? tc : best_t;
-    best_uv.x = hit ? p : best_uv.x;
-    best_uv.y = hit ? q : best_uv.y;
-    best_ks = hit ? (int) (hc | BOX_FACE_FLAG) : best_ks;
+    const bool hit = through && (c.hc & 1u) != 0u && c.t >= tmin && c.t <= best_t;
+    best_t = hit ? c.t : best_t;
+    best_uv.x = hit ? c.p : best_uv.x;
+    best_uv.y = hit ? c.q : best_uv.y;
+    best_ks = hit ? (int) (c.hc | BOX_FACE_FLAG) : best_ks;
 }
 
 template <bool TRI> DEV Hit trace_flat(const DParams &P, f3 o, f3 d, float tmin, float tmax) {
