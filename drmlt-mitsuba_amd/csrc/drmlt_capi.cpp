@@ -605,7 +605,9 @@ drmlt_ctx *drmlt_create(const drmlt_config *cfg, const drmlt_scene *scene, int d
     // SHORT phases -- chains step and refill it as soon as a few rays are done (1 000 000 triangles, 2-step calls: yield x batch
     // 20 x 16 6.9e7, 12 x 8 7.5e7, 8 x 8 7.7e7, 4 x 8 7.7e7 mutations/s; 50 000 triangles, in the L2s: 2.82e8 / 2.75e8 / 2.61e8)
     const bool beyond_l2 = P.use_bvh && (size_t) P.n_bvh_nodes * sizeof(DBvh4Node) + ctx->prims.size() * sizeof(DPrim) > (size_t) 32 << 20;
-    P.mh_batch = P.kernel_variant == 5 ? (P.use_bvh ? (beyond_l2 ? 8 : 16) : 32) : (P.kernel_variant == 4 ? (P.use_bvh ? (P.bvh_stack16 ? 6 : 4) : (P.features == 0 ? 12 : 8)) : 32); // v4 / v5: chains run free, the bookkeeping branch fires as soon as a few are parked
+    // (round 4, with the cuboid records -- a cheaper trace pass moves the balance towards larger batches: v4 on config 2 batch 8 1.99e9, 12 2.02e9,
+    // 14 2.05e9, 16 2.04e9, 20 1.94e9; v5 on the same scene at 131 072 chains 24 2.33e9, 32 2.39e9, 40 2.42e9, 48 2.36e9)
+    P.mh_batch = P.kernel_variant == 5 ? (P.use_bvh ? (beyond_l2 ? 8 : 16) : 40) : (P.kernel_variant == 4 ? (P.use_bvh ? (P.bvh_stack16 ? 6 : 4) : (P.features == 0 ? 14 : 8)) : 32); // v4 / v5: chains run free, the bookkeeping branch fires as soon as a few are parked
     if (const char *k = getenv("DRMLT_MH_BATCH")) P.mh_batch = std::max(1, std::min(64, atoi(k)));
     P.bvh_overflow = nullptr; P.bvh_ovf_lanes = 0;
     P.exec_order = nullptr;
