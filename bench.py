@@ -385,9 +385,11 @@ def main():
         bytes_per_mut += scene_bytes
         muts_per_launch = muts * per_dev / max(launches, 1)   # per device, like launch_ms
         achieved = bytes_per_mut * muts_per_launch / (launch_ms * 1e-3) / 1e9 if launch_ms > 0 else 0.0
-        traffic = valu_frac = lane_util = None
+        traffic = valu_frac = lane_util = atomics_per_mut = None
         traffic_source = None
-        pmc_name = next((n for n in (conf["pmc"].replace("r02_", "r03_"), conf["pmc"]) if os.path.exists(os.path.join(ROOT, "profiles", n))), conf["pmc"])
+        # the newest committed counter summary of this configuration (profiles/rNN_<name>_pmc.json)
+        stem = conf["pmc"].split("_", 1)[1]
+        pmc_name = next((n for n in ("r%02d_%s" % (r, stem) for r in range(9, 1, -1)) if os.path.exists(os.path.join(ROOT, "profiles", n))), conf["pmc"])
         pmc = os.path.join(ROOT, "profiles", pmc_name)
         if os.path.exists(pmc):
             try:
@@ -400,6 +402,7 @@ def main():
                 # wave-level VALU instructions per mutation (SQ_INSTS_VALU) against 1024 SIMDs x one wave64 VALU op per 2 cycles
                 valu_frac = pj["instructions_per_mutation"]["valu"] * muts_per_launch / (launch_ms * 1e-3) / (1024 * 2.4e9 / 2)
                 lane_util = pj.get("valu_lane_utilisation")
+                atomics_per_mut = pj.get("atomic_requests_per_mutation")
             except Exception:
                 traffic = None
         bvh_scene = args.config.startswith("soup")
@@ -434,12 +437,35 @@ def main():
         # The bound that actually binds: wave64 VALU instructions issued per SIMD-cycle (peak: one per 2 cycles
         # per SIMD, 1024 SIMDs at 2.4 GHz) x the fraction of lanes active in them = useful lane-operations against the VALU peak.
         roof_valu = None
+        lane_util_source = "SQ_THREAD_CYCLES_VALU / (64 SQ_ACTIVE_INST_VALU)"
+        it_node, it_leaf = st1.bvh_node_iterations - st0.bvh_node_iterations, st1.bvh_leaf_iterations - st0.bvh_leaf_iterations
+        if bvh_scene and lane_util is not None and it_node + it_leaf > 0:
+            # BVH lines: the exec mask of the straight-line traversal blocks counts lanes that compute on zeros and
+            # keep nothing. The kernel's own counters say how many lanes ADVANCE per traversal iteration; weighted by what an
+            # iteration of either kind costs (a leaf iteration ~ 0.4 node iterations, drmlt_capi.cpp: trace_vote).
+            adv = ((st1.bvh_node_visits - st0.bvh_node_visits) + 0.4 * (st1.bvh_prim_tests - st0.bvh_prim_tests)) / (64.0 * (it_node + 0.4 * it_leaf))
+            lane_util_pmc, lane_util = lane_util, min(lane_util, adv)
+            lane_util_source = ("lanes that ADVANCE per traversal iteration, counted by the kernel in this run (%.1f of 64 per node iteration, %.1f per leaf "
+                                "iteration); the counters' exec-mask figure (%.2f) includes lanes that compute on zeros" %
+                                ((st1.bvh_node_visits - st0.bvh_node_visits) / max(it_node, 1), (st1.bvh_prim_tests - st0.bvh_prim_tests) / max(it_leaf, 1), lane_util_pmc))
         if valu_frac is not None and lane_util is not None:
             roof_valu = {"bound": "valu", "achieved": valu_frac * lane_util * 1024 * 2.4e9 / 2 * 64 / 1e12, "peak": 1024 * 2.4e9 / 2 * 64 / 1e12,
                          "unit": "T lane-ops/s", "frac": valu_frac * lane_util, "valu_issue_frac_of_peak": valu_frac,
-                         "valu_lane_utilisation": lane_util, "source": traffic_source,
+                         "valu_lane_utilisation": lane_util, "valu_lane_utilisation_source": lane_util_source, "source": traffic_source,
                          "note": "frac = (SQ_INSTS_VALU per mutation x mutations/s / (1024 SIMDs x 1.2e9 wave-instructions/s)) x "
                                  "(SQ_ACTIVE_INST lanes / 64): instruction counts from the committed PMC summary, rate from this run"}
+        # The nearest MEMORY-side ceiling: the film splats are no-return float atomics executed at the memory side
+        # (MI355X_MICROARCH.md, Global float atomics). A flush instruction carries 21 splats = 21 x 3 adjacent dwords in (mostly)
+        # 21 different film rows -- the guide's scattered shape: 64 lanes in 64 rows run at ~0.08 TB/s of ADDED bytes, 256
+        # contiguous bytes at ~1.3 TB/s. Requests per mutation from the committed counter summary (TCC_EA0_ATOMIC), rate from this run.
+        roof_atomic = None
+        if atomics_per_mut is not None and launch_ms > 0:
+            req_s = atomics_per_mut * muts_per_launch / (launch_ms * 1e-3)
+            added = req_s * 12.0 / 1e9   # one request = the three channels of one splat (12 B added; 32 B written at the memory side)
+            roof_atomic = {"bound": "memory-side float atomics, scattered (3 adjacent dwords per film row)", "achieved": added, "peak": 80.0, "unit": "GB/s of added bytes",
+                           "frac": added / 80.0, "atomic_requests_per_mutation": atomics_per_mut, "atomic_requests_per_s": req_s,
+                           "peak_contiguous": 1300.0, "source": traffic_source,
+                           "note": "peak = MI355X_MICROARCH.md's rate for 64 lanes in 64 different rows (0.08 TB/s); it scales with every mutations/s gain"}
         out = {
             "metric": "mutations/sec (accepted+rejected)", "value": value, "unit": "mutations/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -451,7 +477,7 @@ def main():
                        "parallelism": ("chains partitioned x%d, one seed pool; film reduce-scatter + scalar all-reduce (RCCL from C++); " % world +
                                        ("one process drives the %d devices (drmlt_node_*, ncclCommInitAll)" % world if node_mode else "one process per GPU (drmlt_comm_*)"))
                        if multi else "1 GPU"},
-            "roofline": roof, "roofline_valu": roof_valu,
+            "roofline": roof, "roofline_valu": roof_valu, "roofline_atomic": roof_atomic,
             "rccl_nranks": rccl_nranks if multi else None, "ranks": ranks_info,
             "launch_mode": "node" if node_mode else ("process-per-gpu" if use_dist else "single"),
             "transport": None if not multi else ("loopback (test hook: ranks share a device, films summed by a device kernel)"
@@ -464,7 +490,7 @@ def main():
         }
         # the committed device-vs-oracle statistics of THIS configuration (tools/parity_protocol.py; the BVH scenes: the 300-triangle sweep run)
         pname = {"2": "parity_protocol_c2", "2x": "parity_protocol_c2", "3": "parity_protocol_c3", "5": "parity_protocol_c5", "bdpt": "parity_protocol_bdpt"}.get(args.config, "protocol_sweep_soup300_path")
-        proto = next((q for q in (os.path.join(ROOT, "profiles", n) for n in ("r03_%s.json" % pname, "r02_parity_protocol.json")) if os.path.exists(q)), "")
+        proto = next((q for q in (os.path.join(ROOT, "profiles", n) for n in ["r%02d_%s.json" % (r, pname) for r in range(9, 2, -1)] + ["r02_parity_protocol.json"]) if os.path.exists(q)), "")
         if os.path.exists(proto):
             try:
                 out["parity_protocol"] = json.load(open(proto)).get("summary")

@@ -67,7 +67,8 @@ class Stats(C.Structure):
         "second_bold_acc", "second_bold_base", "overall_acc", "overall_base",
         "mutations", "path_evals", "rays", "accepted")] + [
         ("kernel_ms", C.c_double), ("seed_ms", C.c_double), ("n_chains", C.c_uint32), ("max_dim", C.c_uint32),
-        ("launches", C.c_uint64), ("bvh_node_visits", C.c_uint64), ("bvh_prim_tests", C.c_uint64)]
+        ("launches", C.c_uint64), ("bvh_node_visits", C.c_uint64), ("bvh_prim_tests", C.c_uint64),
+        ("bvh_node_iterations", C.c_uint64), ("bvh_leaf_iterations", C.c_uint64)]
 
     RATIOS = ("first", "large", "bold", "second", "second_large", "second_bold", "overall")
 

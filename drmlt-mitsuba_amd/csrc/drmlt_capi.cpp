@@ -1111,7 +1111,7 @@ int drmlt_stats_get(drmlt_ctx *ctx, drmlt_stats *o) {
     o->n_chains = ctx->n_chains;
     o->max_dim = (uint32_t) ctx->P.max_dim;
     o->launches = ctx->launches;
-    o->bvh_node_visits = v[10]; o->bvh_prim_tests = v[11];
+    o->bvh_node_visits = v[10]; o->bvh_prim_tests = v[11]; o->bvh_node_iterations = v[12]; o->bvh_leaf_iterations = v[13];
     return DRMLT_OK;
 }
 

@@ -498,6 +498,7 @@ int drmlt_node_stats_get(drmlt_node *node, drmlt_stats *out) {
         out->max_dim = s.max_dim;
         out->launches += s.launches;
         out->bvh_node_visits += s.bvh_node_visits; out->bvh_prim_tests += s.bvh_prim_tests;
+        out->bvh_node_iterations += s.bvh_node_iterations; out->bvh_leaf_iterations += s.bvh_leaf_iterations;
     }
     return DRMLT_OK;
 }

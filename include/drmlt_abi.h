@@ -207,6 +207,10 @@ typedef struct drmlt_stats {
     uint64_t launches;           /* chain-kernel launches so far                         */
     uint64_t bvh_node_visits;    /* 4-wide BVH nodes fetched (128 B each); 0 for brute-force scenes */
     uint64_t bvh_prim_tests;     /* primitive records fetched in BVH leaves (64 B each)           */
+    uint64_t bvh_node_iterations; /* wave-level traversal iterations that advanced lanes holding a node ...       */
+    uint64_t bvh_leaf_iterations; /* ... and a leaf: bvh_node_visits / (64 x bvh_node_iterations) = share of the
+                                   * wave's lanes that ADVANCE per node iteration (the exec mask of the straight-line
+                                   * traversal blocks also counts lanes that compute on zeros and keep nothing)      */
 } drmlt_stats;
 
 /* one evaluated PSS point: SplatList of pathsampler.cpp:529-567 (one splat) */

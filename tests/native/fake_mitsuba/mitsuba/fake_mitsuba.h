@@ -99,9 +99,10 @@ struct Vector { Float x, y, z; Vector() : x(0), y(0), z(0) {} Vector(Float a, Fl
 struct Point { Float x, y, z; Point() : x(0), y(0), z(0) {} Point(Float a, Float b, Float c) : x(a), y(b), z(c) {} };
 typedef Vector Normal;
 struct Vector2i { int x, y; Vector2i() : x(0), y(0) {} Vector2i(int a, int b) : x(a), y(b) {} };
-struct AABB {
+struct AABB {              // aabb.h: TAABB<Point>
+    typedef Point PointType;
     Point min, max;
-    Point getCenter() const { return Point(0.5 * (min.x + max.x), 0.5 * (min.y + max.y), 0.5 * (min.z + max.z)); }
+    PointType getCenter() const { return Point(0.5 * (min.x + max.x), 0.5 * (min.y + max.y), 0.5 * (min.z + max.z)); }
 };
 struct Matrix4x4 {
     Float m[4][4];
@@ -124,9 +125,24 @@ private:
     Matrix4x4 m_m;
 };
 
-class InterpolatedSpectrum { // spectrum.h: a tabulated spectrum read from an .spd file
+namespace fs { // the reference's fs = boost::filesystem (fresolver.h:24): what the adaptor needs of a path -- made from a string, read back as one
+class path {
 public:
-    explicit InterpolatedSpectrum(const std::string &path) : m_path(path) {}
+    path() {}
+    path(const std::string &s) : m_s(s) {}
+    path(const char *s) : m_s(s) {}
+    const std::string &string() const { return m_s; }
+private:
+    std::string m_s;
+};
+} // namespace fs
+class ContinuousSpectrum { // spectrum.h:45-90: what Spectrum::fromContinuousSpectrum takes
+public:
+    virtual ~ContinuousSpectrum() {}
+};
+class InterpolatedSpectrum : public ContinuousSpectrum { // spectrum.h: a tabulated spectrum read from an .spd file
+public:
+    explicit InterpolatedSpectrum(const fs::path &path) : m_path(path.string()) {}
     const std::string &path() const { return m_path; }
 private:
     std::string m_path;
@@ -139,7 +155,9 @@ public:
     void toLinearRGB(Float &r, Float &g, Float &b) const { r = s[0]; g = s[1]; b = s[2]; }
     Spectrum operator/(Float f) const { return Spectrum(s[0] / f, s[1] / f, s[2] / f); }
     // the fake knows no measured spectra: a file name carries "r_g_b" so that tests can see the lookup happen
-    void fromContinuousSpectrum(const InterpolatedSpectrum &sp) {
+    enum EConversionIntent { EReflectance, EIlluminant }; // spectrum.h:343-356
+    void fromContinuousSpectrum(const ContinuousSpectrum &smooth) {
+        const InterpolatedSpectrum &sp = dynamic_cast<const InterpolatedSpectrum &>(smooth);
         double r = 0, g = 0, b = 0;
         const size_t p = sp.path().find("fake:");
         if (p == std::string::npos || sscanf(sp.path().c_str() + p + 5, "%lf_%lf_%lf", &r, &g, &b) != 3) Log(EError, "cannot read %s", sp.path().c_str());
@@ -163,11 +181,11 @@ public:
     std::string getString(const std::string &k) const { need(k, EString); return m_s.at(k); }
     std::string getString(const std::string &k, const std::string &d) const { return hasProperty(k) ? getString(k) : d; }
     int getInteger(const std::string &k) const { need(k, EInteger); return (int) m_f.at(k); }
-    int getInteger(const std::string &k, int d) const { return hasProperty(k) ? getInteger(k) : d; }
+    int getInteger(const std::string &k, const int &d) const { return hasProperty(k) ? getInteger(k) : d; }
     Float getFloat(const std::string &k) const { need(k, EFloat); return m_f.at(k); }
-    Float getFloat(const std::string &k, Float d) const { return hasProperty(k) ? getFloat(k) : d; }
+    Float getFloat(const std::string &k, const Float &d) const { return hasProperty(k) ? getFloat(k) : d; }
     bool getBoolean(const std::string &k) const { need(k, EBoolean); return m_f.at(k) != 0; }
-    bool getBoolean(const std::string &k, bool d) const { return hasProperty(k) ? getBoolean(k) : d; }
+    bool getBoolean(const std::string &k, const bool &d) const { return hasProperty(k) ? getBoolean(k) : d; }
     Transform getTransform(const std::string &k) const { need(k, ETransform); return m_t.at(k); }
     Transform getTransform(const std::string &k, const Transform &d) const { return hasProperty(k) ? getTransform(k) : d; }
     Spectrum getSpectrum(const std::string &k) const { need(k, ESpectrum); return m_sp.at(k); }
@@ -231,7 +249,7 @@ public:
     float *getFloat32Data() { return m_data.data(); }             // bitmap.h:1216
     const float *getFloat32Data() const { return m_data.data(); }
     // bitmap.h:685-687 (not a const member in the reference either)
-    ref<Bitmap> convert(EPixelFormat, EComponentFormat, Float gamma = 1.0f, Float multiplier = 1.0f, int intent = 0) {
+    ref<Bitmap> convert(EPixelFormat, EComponentFormat, Float gamma = 1.0f, Float multiplier = 1.0f, Spectrum::EConversionIntent intent = Spectrum::EReflectance) {
         (void) gamma; (void) multiplier; (void) intent;
         Bitmap *b = new Bitmap(m_pf, m_cf, m_size); b->m_data = m_data; return b;
     }
@@ -370,7 +388,7 @@ private:
 
 class FileResolver : public Object {
 public:
-    std::string resolve(const std::string &p) const { return prefix() + p; }
+    fs::path resolve(const fs::path &path) const { return fs::path(prefix() + path.string()); }
     static std::string &prefix() { static std::string s; return s; }
 };
 class Thread {

@@ -93,8 +93,29 @@ def split_args(args):
     return [p.strip() for p in parts if p.strip() and p.strip() != "void"]
 
 
-def methods(body):
-    """{name: set of (n_params, n_defaults, is_const, is_static)} of the declarations at class scope."""
+BUILTIN = {"int", "char", "long", "short", "float", "double", "bool", "unsigned", "signed", "void", "Float", "size_t", "uint32_t", "int32_t",
+           "uint64_t", "int64_t", "uint8_t", "uint16_t"}
+
+
+def norm_type(t, is_param):
+    """Canonical token string of a parameter or return type: no parameter name, no default value, no storage / linkage words,
+    no namespace qualifiers, `T const` -> `const T`, single spaces. The SAME function reads both sides, so only equality matters."""
+    t = re.sub(r"[^=!<>]=[^=].*$", lambda m: m.group(0)[0], t) if is_param else t          # default value
+    t = re.sub(r"\b(virtual|inline|static|explicit|MTS_EXPORT_\w+|FINLINE)\b", " ", t)
+    t = re.sub(r"\b(?:mitsuba|std)::", "", t)
+    t = re.sub(r"\s+", " ", t).strip()
+    if is_param:
+        m = re.match(r"^(.*[\s\*&])([A-Za-z_]\w*)$", t)
+        if m and m.group(2) not in BUILTIN and m.group(1).strip() not in ("const", "unsigned", "signed", "struct", "class"):
+            t = m.group(1)
+    t = re.sub(r"\s*([\*&<>,])\s*", r"\1", t).strip()
+    t = re.sub(r"^(\w+) const\b", r"const \1", t)
+    return t
+
+
+def methods(body, with_types=False):
+    """{name: set of (n_params, n_defaults, is_const, is_static)} of the declarations at class scope
+    (with_types: (n_params, n_defaults, is_const, is_static, return type, (parameter types ...)))."""
     out = {}
     flat = flatten(body)
     flat = re.sub(r"\b(public|protected|private)\s*:", ";", flat)
@@ -113,7 +134,10 @@ def methods(body):
         is_const = bool(re.match(r"\s*const\b", tail))
         is_static = bool(re.search(r"\bstatic\b", stmt[:m.start()]))
         n_def = sum(1 for a in args if re.search(r"[^=!<>]=[^=]", a))
-        out.setdefault(m.group(1), set()).add((len(args), n_def, is_const, is_static))
+        sig = (len(args), n_def, is_const, is_static)
+        if with_types:
+            sig += (norm_type(stmt[:m.start()], False), tuple(norm_type(a, True) for a in args))
+        out.setdefault(m.group(1), set()).add(sig)
     return out
 
 
@@ -132,7 +156,7 @@ def ref_sources():
     return _ref_cache["src"]
 
 
-def ref_class_methods(name, seen=None):
+def ref_class_methods(name, seen=None, with_types=False):
     """methods of reference class `name` including its bases; (methods, header) or (None, None)."""
     seen = seen or set()
     if name in seen:
@@ -143,9 +167,9 @@ def ref_class_methods(name, seen=None):
         if not found:
             continue
         bases, body = found
-        ms = methods(body)
+        ms = methods(body, with_types)
         for b in bases:
-            bm, _ = ref_class_methods(b, seen)
+            bm, _ = ref_class_methods(b, seen, with_types)
             for k, v in (bm or {}).items():
                 ms.setdefault(k, set()).update(v)
         return ms, hdr
@@ -164,7 +188,7 @@ TEST_ONLY = {"FakeLog", "InterpolatedSpectrum"}       # InterpolatedSpectrum: on
 STD_LIKE = {"size", "data", "c_str", "push_back", "begin", "end", "empty", "resize", "assign", "get", "count", "at", "find", "insert"}
 
 
-def fake_classes():
+def fake_classes(with_types=False):
     src = strip_comments(open(FAKE).read())
     names = re.findall(r"\b(?:class|struct)\s+(\w+)\s*(?::[^{;]*)?\{", src)
     out = {}
@@ -172,8 +196,34 @@ def fake_classes():
         if n in TEST_ONLY:
             continue
         bases, body = find_class(src, n)
-        out[n] = (bases, methods(body))
+        out[n] = (bases, methods(body, with_types))
     return out
+
+
+def test_parameter_and_return_types_match_the_reference_header():
+    """beyond name / arity / const / static, the TYPES -- return type and every parameter type, compared as
+    normalised token strings (parameter names, default values, `virtual` / `inline` / export macros and namespace qualifiers
+    removed) -- of every method the adaptor calls or overrides."""
+    calls = adaptor_calls() - STD_LIKE
+    problems, checked = [], 0
+    for cls, (bases, ms) in sorted(fake_classes(with_types=True).items()):
+        wanted = {m: sigs for m, sigs in ms.items() if m in calls and m != cls}
+        if not wanted:
+            continue
+        ref_ms, hdr = ref_class_methods(cls, with_types=True)
+        if ref_ms is None:
+            continue            # reported by the test above
+        for m, sigs in sorted(wanted.items()):
+            for sig in sorted(sigs):
+                same_shape = [r for r in ref_ms.get(m, ()) if r[:4] == sig[:4]]
+                if not same_shape:
+                    continue    # reported by the test above
+                if any(r[4:] == sig[4:] for r in same_shape):
+                    checked += 1
+                else:
+                    problems.append("%s::%s: fake %s %s, reference (%s) %s" % (cls, m, sig[4], list(sig[5]), hdr, [(r[4], list(r[5])) for r in same_shape]))
+    assert not problems, "\n".join(problems)
+    assert checked >= 45, checked
 
 
 def test_every_called_method_matches_the_reference_header():
@@ -248,7 +298,7 @@ def test_exported_xml_property_names_round_trip(pkg, tmp_path):
     # the adaptor reads every property the reference's constructor reads, with the same getter (`devices` / `device` / `seed` are its backend additions)
     for name, getter in reference.items():
         assert adaptor.get(name) == getter or (getter == "getSize" and adaptor.get(name) == "getInteger"), (name, getter, adaptor.get(name))
-    assert set(adaptor) - set(reference) <= {"devices", "device", "seed"}, set(adaptor) - set(reference)   # backend parameters
+    assert set(adaptor) - set(reference) <= {"devices", "device", "seed", "firstStageSeeding", "workUnitsRule"}, set(adaptor) - set(reference)   # backend parameters
     for cname, conf in cb.CONFIGS.items():
         if conf["mitsuba"]["integrator"] != "drmlt":
             continue

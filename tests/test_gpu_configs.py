@@ -108,3 +108,73 @@ def test_config5_caustic_mmlt_full_size(pkg, native_lib):
     b = ctx2.seed(0x5EED)
     ctx2.run(512 * 512 * 16)
     check_invariants(ctx2, 512 * 512 * 16, b)
+
+
+# ---- the same properties at the settings bench.py TIMES: its chain counts pick other kernels --
+# k_mutate_v5 from 98 304 chains up (config 3: the conductor-only flat build <1>), the regrouped execution order of the
+# bidirectional kernels (several launches per call), cuboid records in the ray loop.
+def _bench_conf(name):
+    import bench
+    return bench.CONFIGS[name]
+
+
+def _run_like_bench(pkg, name, spp, launches, capfd=None):
+    conf = _bench_conf(name)
+    sd = pkg.scenes.SCENES[conf["scene"][0]](res=conf["res"], **conf["scene"][1])
+    n = conf.get("chains", 65536)
+    cfg = pkg.abi.make_config(work_units=n, luminance_samples=100000, direct_samples=-1, sample_count=spp, **conf["cfg"])
+    ctx = pkg.Context(cfg, sd)
+    b = ctx.seed(0x5EED)
+    M = conf["res"] * conf["res"] * spp
+    assert M % n == 0 and M // n == launches * 1024 or launches is None
+    ctx.run(M)
+    return ctx, b, M, n
+
+
+def test_bench_config_2x_full_size(pkg, native_lib):
+    """`bench.py --config 2x`: Cornell 512^2, 131 072 chains -> k_mutate_v5's flat build with cuboid records."""
+    ctx, b, M, n = _run_like_bench(pkg, "2x", 512, None)
+    st, _ = check_invariants(ctx, M, b)
+    assert st.n_chains == 131072 and st.launches == 1 and st.bvh_node_visits == 0
+    cur, u = ctx.chain_state(34)
+    assert np.all((u >= 0) & (u <= 1)) and np.all(cur["luminance"] > 0)
+
+
+def test_bench_config_3_full_size(pkg, native_lib):
+    """`bench.py --config 3`: door scene, type=green, 131 072 chains -> k_mutate_v5<1> (Green's reverse moves recomputed from the
+    state in device memory), two launches with run-ahead between them."""
+    ctx, b, M, n = _run_like_bench(pkg, "3", 512, None)
+    st, _ = check_invariants(ctx, M, b)
+    assert st.n_chains == 131072 and st.launches == 1
+    assert M + st.second_base <= st.path_evals <= M + 2 * st.second_base
+    ctx.run(M)                                                                  # a second call continues every chain from its counter
+    st2 = ctx.stats()
+    assert st2.mutations == 2 * M and st2.launches == 2
+    cur, u = ctx.chain_state(34)
+    assert np.all((u >= 0) & (u <= 1)) and np.all(cur["luminance"] > 0)
+
+
+def test_bench_config_5_full_size_regrouped(pkg, native_lib):
+    """`bench.py --config 5`: caustic, mmlt / orbital / fixEmitterPath / acceptanceMap, 262 144 chains run in depth order and
+    regrouped by work between the launches of a call (a short first launch, then 1024-mutation launches)."""
+    ctx, _, M, n = _run_like_bench(pkg, "5", 1024, None)
+    st, film = check_invariants(ctx, M, 1.0, amap=True)
+    assert st.n_chains == 262144 and st.launches >= 2                           # the first launch of a regrouping call is short
+    f = film.astype(np.float64)
+    assert f[..., 0].sum() == pytest.approx(st.bold_acc, rel=1e-3) and f[..., 1].sum() == pytest.approx(st.second_acc, rel=1e-3)
+    cur, u = ctx.chain_state(27)
+    assert set(np.unique(cur["n_dims"])) <= set(range(1, 7)) and np.all((u >= 0) & (u <= 1))
+
+
+def test_bench_config_bdpt_full_size(pkg, native_lib):
+    """`bench.py --config bdpt`: Cornell, bdpt / orbital, maxDepth 8, directSampling, 131 072 chains -> the two-waves-per-SIMD build."""
+    ctx, b, M, n = _run_like_bench(pkg, "bdpt", 256, None)
+    st = ctx.stats()
+    assert st.mutations == M and st.n_chains == 131072 and st.first_base == M and st.large_base + st.bold_base == M
+    assert st.second_base == st.bold_base - st.bold_acc and st.overall_acc == st.first_acc + st.second_acc == st.accepted
+    film = ctx.film()
+    assert np.all(np.isfinite(film)) and film.min() >= 0
+    # a list's splats carry unit luminance in total: the film holds one unit per mutation (up to the splats that leave the film)
+    assert lum(film.astype(np.float64)).sum() == pytest.approx(M, rel=2e-2)
+    img = ctx.develop()
+    assert lum(img.astype(np.float64)).mean() == pytest.approx(b, rel=2e-3)

@@ -36,6 +36,10 @@ def main():
     only_o = only_g = 0.0
     n_only_o = n_only_g = 0
     orcs = [ob.Oracle(abi, cfg, sd, precision=a.precision, native=True) for _ in range(a.threads)]
+    LW = np.array([0.212671, 0.715160, 0.072169])
+    cls = {"main": [0.0, 0.0], "light": [0.0, 0.0]}                     # [device, oracle] luminance by splat class
+    img = {"main": np.zeros((2, 16, 16)), "light": np.zeros((2, 16, 16))}   # the same, by 4 x 4 pixel block of the 64 x 64 film
+    by_n = np.zeros((2, 16))                                            # list luminance by number of light-image splats
     for c0 in range(0, a.n, chunk):
         us, ue, ud = (rng.random((chunk, 24), dtype=np.float32) for _ in range(3))
         gl = ctx.eval_lists_bdpt(us, ue, ud) if a.direct else ctx.eval_lists_bdpt(us, ue)
@@ -49,6 +53,18 @@ def main():
         [t.start() for t in th]; [t.join() for t in th]
         lg, lo = gl[:, 0].astype(np.float64), ol[:, 0].astype(np.float64)
         tot_g += lg.sum(); tot_o += lo.sum()
+        for side, L in enumerate((gl.astype(np.float64), ol.astype(np.float64))):
+            ml = (L[:, 4:7] @ LW) * (L[:, 1] > 0)
+            cls["main"][side] += ml.sum()
+            bx, by = np.clip((L[:, 2] / 4).astype(int), 0, 15), np.clip((L[:, 3] / 4).astype(int), 0, 15)
+            np.add.at(img["main"][side], (by, bx), ml)
+            more = L[:, 10:].reshape(len(L), -1, 5)
+            valid = np.arange(more.shape[1])[None, :] < L[:, 7:8]
+            ll = (more[:, :, 2:5] @ LW) * valid
+            cls["light"][side] += ll.sum()
+            bx, by = np.clip((more[:, :, 0] / 4).astype(int), 0, 15), np.clip((more[:, :, 1] / 4).astype(int), 0, 15)
+            np.add.at(img["light"][side], (by[valid], bx[valid]), ll[valid])
+            np.add.at(by_n[side], np.clip(L[:, 7].astype(int), 0, 15), L[:, 0])
         m = (lg == 0) & (lo > 0); only_o += lo[m].sum(); n_only_o += int(m.sum())
         m = (lo == 0) & (lg > 0); only_g += lg[m].sum(); n_only_g += int(m.sum())
         d = lg - lo
@@ -56,6 +72,13 @@ def main():
             worst.append((float(d[i]), float(lg[i]), float(lo[i]), gl[i, 1:10].tolist(), ol[i, 1:10].tolist(), us[i].tolist(), ue[i].tolist(), ud[i].tolist()))
         print("%d points: sum device %.6g oracle %.6g ratio %.5f | oracle-only %d pts %.4g (%.3f%%), device-only %d pts %.4g (%.3f%%)" %
               (c0 + chunk, tot_g, tot_o, tot_g / tot_o, n_only_o, only_o, 100 * only_o / tot_o, n_only_g, only_g, 100 * only_g / tot_o), flush=True)
+    for k in ("main", "light"):
+        g_, o_ = cls[k]
+        d = img[k][0] - img[k][1]
+        print("%s splats: device %.6g oracle %.6g ratio %.5f | 4 x 4 blocks: max |device - oracle| / block mean %.4g, rms %.4g" %
+              (k, g_, o_, g_ / max(o_, 1e-30), np.abs(d).max() / max(img[k][1].mean(), 1e-30), np.sqrt((d ** 2).mean()) / max(img[k][1].mean(), 1e-30)))
+    print("list luminance by number of light-image splats (device / oracle): " +
+          " ".join("%d: %.5f" % (i, by_n[0, i] / by_n[1, i]) for i in range(16) if by_n[1, i] > 0))
     worst.sort(key=lambda w: -abs(w[0]))
     print("largest differences (device - oracle, device, oracle, [hasMain px py r g b nMore nDims nRays] x 2):")
     for w in worst[:15]:
