@@ -140,9 +140,15 @@ DEV void eval_bdpt(const DParams &P, const TablesT &T, MSampler &smp, bool activ
     const BdptStore W{P.bd_verts, NVS, n};
     auto mis = [&](int group, int slot) -> float & { return lds_x[(mis_row + (uint32_t) group * NVS + (uint32_t) slot) * 64u + lane]; };
     auto lrow = [&](int r) -> float & { return list[(size_t) r * n]; };
-    static_assert(2 * (2 * BDPT_MAX_DEPTH + 1) <= 64, "two flag bits per vertex slot in one 64-bit register");
-    unsigned long long flagbits = 0ull; // two bits per vertex slot: BF_CONN, BF_DEGEN (drmlt_create refuses maxDepth > BDPT_MAX_DEPTH)
-    auto set_flags = [&](int slot, unsigned v) { flagbits = (flagbits & ~(3ull << (2 * slot))) | ((unsigned long long) v << (2 * slot)); };
+    // two flags per vertex slot (BF_CONN, BF_DEGEN), ONE BIT PER SLOT IN EACH OF TWO 64-bit words (round 4: one word of bit
+    // pairs held 2 maxDepth + 1 <= 32 slots, i.e. maxDepth <= 15)
+    static_assert(2 * BDPT_MAX_DEPTH + 1 <= 64, "one flag bit per vertex slot in a 64-bit register");
+    unsigned long long connbits = 0ull, degenbits = 0ull;
+    auto set_flags = [&](int slot, unsigned v) {
+        const unsigned long long bit = 1ull << slot;
+        connbits = (v & BF_CONN) ? connbits | bit : connbits & ~bit;
+        degenbits = (v & BF_DEGEN) ? degenbits | bit : degenbits & ~bit;
+    };
 
     R.lum = 0.f; R.nrays = 0u; R.n_sensor = R.n_emitter = R.n_direct = 0u; R.n_more = 0; R.has_main = false;
     smp.reset_caches();
@@ -349,7 +355,7 @@ DEV void eval_bdpt(const DParams &P, const TablesT &T, MSampler &smp, bool activ
     // instead of a sweep over the whole path.
     if (active) {
         double *const tails = W.tails(chain);
-        auto fl = [&](int slot) -> bool { return ((unsigned) (flagbits >> (2 * slot)) & BF_CONN) != 0u; };
+        auto fl = [&](int slot) -> bool { return ((connbits >> slot) & 1ull) != 0ull; };
         const float re_e = (direct && fl(1)) ? re_walk : 0.f; // the sampleDirect ratio of the s >= 4 strategies, at position 1
         double acc = 0.0;
         for (int m = 1; m <= nE - 3; ++m) { // emitter vertex m = position m: pdfRad[m] / pdfImp[m] (path.cpp:868-898 for the specular neighbours)
@@ -383,7 +389,7 @@ DEV void eval_bdpt(const DParams &P, const TablesT &T, MSampler &smp, bool activ
     // in a cell, the sampler -- every mode and kernel of it -- ran for a few lanes in nearly every round).
     uint32_t kd_total = 0u;
     if (active && direct && nE >= 2) {
-        auto degen = [&](int slot) -> bool { return ((unsigned) (flagbits >> (2 * slot)) & BF_DEGEN) != 0u; };
+        auto degen = [&](int slot) -> bool { return ((degenbits >> slot) & 1ull) != 0ull; };
         int mt;
         for (int s = nE - 1; s >= 2; --s) // t = 1 is the last cell of a row that reaches it (light image)
             if (P.light_image && bdpt_row_cells(P, s, nS, mt) > 0 && !degen(s - 1)) kd_total += 2u;
@@ -456,11 +462,11 @@ DEV void eval_bdpt(const DParams &P, const TablesT &T, MSampler &smp, bool activ
         const uint32_t nEnS = (uint32_t) __shfl((int) ((uint32_t) nE | ((uint32_t) nS << 8)), (int) c, 64);
         const int nEc = (int) (nEnS & 255u), nSc = (int) (nEnS >> 8);
         const uint32_t emit_c = (uint32_t) __shfl((int) emit_bits, (int) c, 64);
-        const unsigned long long fb = shfl_u64(flagbits, c);
+        const unsigned long long fbc = shfl_u64(connbits, c), fbd = shfl_u64(degenbits, c);
         const float em0_c = __shfl(em0_fwd, (int) c, 64), re_walk_c = __shfl(re_walk, (int) c, 64);
         float *const list_c = reinterpret_cast<float *>(shfl_u64((unsigned long long) list, c));
         const uint32_t prog_c = (uint32_t) __shfl((int) progress, (int) c, 64);
-        auto flags = [&](int slot) -> unsigned { return (unsigned) (fb >> (2 * slot)) & 3u; };
+        auto flags = [&](int slot) -> unsigned { return ((unsigned) (fbc >> slot) & 1u) | (((unsigned) (fbd >> slot) & 1u) << 1); };
         auto misc = [&](int group, int slot) -> float { return lds_x[(mis_row + (uint32_t) group * NVS + (uint32_t) slot) * 64u + c]; };
 
         int s = 0, t = 0;

@@ -91,6 +91,9 @@ struct MSampler {
         return (k & 1u) ? pair_y1 : pair_y0;
     }
     DEV float z_raw(uint32_t k) {
+        // second stage of a rejected LARGE step (timidAfterLarge; technique=bdpt only -- mmlt refuses it): fillSpace takes its uniform
+        // branch again, before it looks at the kernel (drmlt_sampler.cpp:319-321 behind a debug-only assertion: DESIGN deviation 2)
+        if (large) return u_s2(draw_base + k);
         if (ident2()) return x(k);
         if (type != 2) return x(k) + gaussian_sample(u_s2(draw_base + 2u * k), u_s2(draw_base + 2u * k + 1u), sigma2);
         ensure_pair(k & ~1u, true);

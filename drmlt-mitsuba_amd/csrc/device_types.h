@@ -12,7 +12,7 @@
 #include <stdint.h>
 
 #define DRMLT_MAX_LDS_PRIMS 96
-#define BDPT_MAX_DEPTH 15 // technique=bdpt: 2 maxDepth + 1 stored vertices x 2 flag bits must fit a 64-bit register (device_bdpt.h)
+#define BDPT_MAX_DEPTH 24 // technique=bdpt: one wave's LDS rows (samplers + densities, device_bdpt.h) reach the 64 KB a workgroup may have at maxDepth 26; the flag words would hold 31
 
 // PRIM_QUAD2: two triangles (a,b,c), (a,c,d) that form a parallelogram, intersected once; the hit is
 // attributed to the sub-triangle it falls in (two consecutive shading records), so f(u) is unchanged

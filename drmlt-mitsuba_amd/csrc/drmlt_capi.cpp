@@ -331,9 +331,10 @@ drmlt_ctx *drmlt_create(const drmlt_config *cfg, const drmlt_scene *scene, int d
     if (cfg->seed_rule != DRMLT_SEED_TARGET && cfg->seed_rule != DRMLT_SEED_REFERENCE) return bail(nullptr, "Unknown seeding rule (firstStageSeeding: target | reference)");
     if (cfg->work_units_rule != DRMLT_WORK_UNITS_DEVICE && cfg->work_units_rule != DRMLT_WORK_UNITS_REFERENCE) return bail(nullptr, "Unknown work-unit rule (workUnitsRule: device | reference)");
     const bool mmlt = cfg->technique == DRMLT_TECH_MMLT, bdpt = cfg->technique == DRMLT_TECH_BDPT;
-    if (bdpt && cfg->timid_after_large) return bail(nullptr, "timidAfterLarge is not supported for technique=bdpt");
-    // device_bdpt.h keeps two flag bits per stored vertex in ONE 64-bit register: 2 maxDepth + 1 slots fit up to maxDepth 15
-    if (bdpt && cfg->max_depth > BDPT_MAX_DEPTH) return bail(nullptr, "technique=bdpt: maxDepth above 15 is not supported on the device");
+    // (timidAfterLarge under bdpt: the reference's code path with its debug assertions compiled out -- a rejected large step's second
+    // stage draws uniforms again for all three samplers, drmlt_sampler.cpp:319-321 -- as for technique=path, DESIGN deviation 2)
+    // a wave's sampler and density rows (device_bdpt.h) take 60.7 KB of LDS at maxDepth 24 and pass the 64 KB of a workgroup at 26
+    if (bdpt && cfg->max_depth > BDPT_MAX_DEPTH) return bail(nullptr, "technique=bdpt: maxDepth above 24 is not supported on the device");
     // ... and a vertex record packs its bsdf and emitter numbers into one word (device_bdpt.h: BR_IDS)
     if (bdpt && (scene->n_bsdfs > 4096 || scene->n_emitters > 65534)) return bail(nullptr, "technique=bdpt: more than 4096 bsdfs or 65534 emitters are not supported on the device");
     if (cfg->max_depth <= 0) return bail(nullptr, "technique=path needs a finite maxDepth (pssmlt_utils.h:63)");

@@ -198,7 +198,7 @@ template <int FEAT, int OCC> __global__ void __launch_bounds__(CHAIN_BLOCK, OCC)
                 bool doSecond = false;
                 y_lum = lum; ns1 = R.n_sensor; ne1 = R.n_emitter; nd1 = R.n_direct;
                 z_lum = 0.f; ns2 = ne2 = nd2 = 0u;
-                mh_first(mix, false, large, y_lum, cur_lum, u32_to_unit(coins.y), u32_to_unit(coins.w), a1, acc1, doSecond); // timidAfterLarge is refused for bdpt
+                mh_first(mix, P.timid_after_large != 0, large, y_lum, cur_lum, u32_to_unit(coins.y), u32_to_unit(coins.w), a1, acc1, doSecond);
                 if (doSecond) { stage = 1; decided = false; }
             } else if (stage == 1) {
                 z_lum = lum; ns2 = R.n_sensor; ne2 = R.n_emitter; nd2 = R.n_direct;
@@ -212,7 +212,7 @@ template <int FEAT, int OCC> __global__ void __launch_bounds__(CHAIN_BLOCK, OCC)
                     stage = 2; decided = false;
                 } else if (P.type == 1) {
                     float ratio = 1.f;
-                    if (!(fminf(1.f, y_lum / z_lum) >= 1.f)) { // (a large step never gets here: no second stage after it)
+                    if (!large && !(fminf(1.f, y_lum / z_lum) >= 1.f)) { // (a large step -- here only with timidAfterLarge -- has no kernel ratio: uniform proposals both times)
                         float num = 0.f, den = 0.f;
                         for (int sg = 0; sg < 3; ++sg) {
                             const uint32_t nmax = sg == 0 ? max(ns1, ns2) : (sg == 1 ? max(ne1, ne2) : max(nd1, nd2));

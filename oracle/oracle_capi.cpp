@@ -69,7 +69,6 @@ template <typename F> struct Ctx : CtxBase {
         mmlt = in.technique == DRMLT_TECH_MMLT;
         bdpt = in.technique == DRMLT_TECH_BDPT;
         if (bdpt && in.algo == DRMLT_ALGO_PSSMLT) return "oracle: pssmlt over technique=bdpt is not restated";
-        if (bdpt && in.timid_after_large) return "timidAfterLarge is not restated for technique=bdpt";
         if (mmlt && in.max_depth <= 0) return "Impossible to use MMLT with no max depth"; // drmlt.cpp:213-215
         if (mmlt && in.algo == DRMLT_ALGO_PSSMLT) return "oracle: pssmlt over technique=mmlt is not restated";
         // A rejected large step re-draws the strategy; its second stage (and Green's reverse path) then reads an

@@ -79,10 +79,10 @@ def test_create_validates_like_the_reference_ctor(pkg, abi, native_lib):
         (dict(type="orbital", max_depth=-1), "maxDepth"),
         (dict(type=7, max_depth=8), "implementation type"),
         (dict(type="orbital", technique="mmlt", max_depth=8, algo=1), "pssmlt"),
-        (dict(type="orbital", technique="bdpt", max_depth=8, timid_after_large=1), "timidAfterLarge"),
         (dict(type="orbital", technique="mmlt", max_depth=8, timid_after_large=1), "timidAfterLarge"),
-        # device_bdpt.h keeps two flag bits per stored vertex in one 64-bit register: 2 * 16 + 1 slots would need 66
-        (dict(type="orbital", technique="bdpt", max_depth=16), "maxDepth above 15"),
+        # a wave's sampler and density rows pass the 64 KB of a workgroup at maxDepth 26 (round 4: the flag words hold 2 * 24 + 1 slots)
+        (dict(type="orbital", technique="bdpt", max_depth=25), "maxDepth above 24"),
+        (dict(type="orbital", technique="mmlt", max_depth=25), "maxDepth above 24"),
     ]
     for kw, needle in bad:
         with pytest.raises(pkg.DrmltError) as e:

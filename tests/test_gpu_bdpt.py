@@ -69,6 +69,30 @@ def test_lists_of_deep_paths(pkg, ob, direct, native_lib):
     np.testing.assert_allclose(mg[:, :, 2:], mo[:, :, 2:], rtol=5e-2, atol=5e-4)
 
 
+@pytest.mark.parametrize("direct", [0, 1], ids=["nodirect", "direct"])
+def test_lists_at_max_depth_20(pkg, ob, direct, native_lib):
+    """maxDepth 20 (round 3 refused more than 15: two flag bits per stored vertex in one 64-bit word; now one bit per vertex in
+    each of two words, up to maxDepth 24): 41 stored vertices, 60 KB of sampler and density rows per wave. Same lists as the oracle,
+    and a short chain run stays finite."""
+    sd = pkg.scenes.cornell_c2(64)
+    cfg, ctx, orc = make(pkg, ob, sd, type="orbital", work_units=256, max_depth=20, rr_depth=-1, no_direct_sampling=0 if direct else 1)
+    rng = np.random.default_rng(4)
+    n, w = 1500, 80
+    us, ue, ud = (rng.random((n, w), dtype=np.float32) for _ in range(3))
+    g, o = (ctx.eval_lists_bdpt(us, ue, ud), orc.bdpt_eval(us, ue, ud)) if direct else (ctx.eval_lists_bdpt(us, ue), orc.bdpt_eval(us, ue))
+    same = (g[:, 1] == o[:, 1]) & (g[:, 7] == o[:, 7]) & (g[:, 8] == o[:, 8]) & (g[:, 9] == o[:, 9])
+    assert same.mean() > 0.97, same.mean()
+    assert (o[:, 9] >= 150).sum() >= 20                                         # paths that do use the depth
+    rel = np.abs(g[:, 0] - o[:, 0])[same] / np.maximum(o[:, 0][same], 1e-3)
+    assert np.quantile(rel, 0.99) < 4e-3, np.quantile(rel, 0.99)
+    assert g[:, 0].sum() == pytest.approx(o[:, 0].sum(), rel=3e-3)
+    b = ctx.seed(5)
+    ctx.run(256 * 32)
+    st = ctx.stats()
+    img = ctx.develop()
+    assert st.mutations == 256 * 32 and np.isfinite(img).all() and lum(img).mean() == pytest.approx(b, rel=1e-3)
+
+
 def rel_full(g, o):
     return np.abs(g[:, 0] - o[:, 0]) / np.maximum(o[:, 0], 1e-3)
 
@@ -76,7 +100,11 @@ def rel_full(g, o):
 VARIANTS = [dict(type="orbital"), dict(type="green"), dict(type="mira"), dict(type="orbital", use_mixture=1),
             dict(type="orbital", no_light_image=1), dict(type="green", direct_samples=16),
             dict(type="orbital", no_direct_sampling=0), dict(type="green", no_direct_sampling=0), dict(type="mira", no_direct_sampling=0),
-            dict(type="orbital", no_direct_sampling=0, use_mixture=1), dict(type="orbital", no_direct_sampling=0, no_light_image=1)]
+            dict(type="orbital", no_direct_sampling=0, use_mixture=1), dict(type="orbital", no_direct_sampling=0, no_light_image=1),
+            # timidAfterLarge under bdpt (round 3 refused it; the reference gates the second stage on it for every technique,
+            # drmlt_proc.cpp:553-558): a rejected large step's second stage is another uniform proposal of all three samplers
+            dict(type="orbital", no_direct_sampling=0, timid_after_large=1), dict(type="green", no_direct_sampling=0, timid_after_large=1),
+            dict(type="mira", timid_after_large=1)]
 
 
 @pytest.mark.parametrize("kw", VARIANTS, ids=lambda k: "-".join("%s=%s" % i for i in k.items()))
@@ -96,6 +124,9 @@ def test_chains_track_the_oracle(pkg, ob, kw, native_lib):
     assert tracked.sum() / same0.sum() > 0.93, tracked.sum() / same0.sum()
     sg, so = ctx.stats(), orc.stats()
     assert sg.mutations == so.mutations == n_chains * n_mut
+    if kw.get("timid_after_large"):
+        assert sg.second_large_base > 0.1 * sg.large_base and so.second_large_base > 0          # second stages after rejected large steps do happen
+        assert abs(sg.second_large_base - so.second_large_base) <= 0.03 * so.second_large_base + 20
     for k in ("first", "large", "bold", "second", "overall"):
         bg_, bo_ = getattr(sg, k + "_base"), getattr(so, k + "_base")
         assert abs(bg_ - bo_) <= 0.02 * max(bo_, 1) + 20, (k, bg_, bo_)
