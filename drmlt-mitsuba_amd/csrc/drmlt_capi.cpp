@@ -30,6 +30,8 @@ void launch_bootstrap_mmlt(const DParams &P, uint32_t n, float *lum_out, hipStre
 void launch_init_chains_mmlt(const DParams &P, const uint32_t *seed_index, const float *seed_lum, hipStream_t st);
 void launch_mutate_mmlt(const DParams &P, uint32_t n_mut, uint32_t mut_base, hipStream_t st);
 void launch_eval_paths_mmlt(const DParams &P, const float *u, uint32_t n, uint32_t dim, float *out8, hipStream_t st);
+void launch_regroup(const uint32_t *work, const int32_t *depth_or_null, uint32_t n, uint32_t n_mut, uint32_t md, uint32_t *order, uint32_t padded, uint32_t *scratch, hipStream_t st);
+size_t regroup_scratch_words(uint32_t n, uint32_t md);
 // technique=bdpt (kernels_bdpt.hip)
 void launch_bootstrap_bdpt(const DParams &P, uint32_t n, float *lum_out, hipStream_t st);
 void launch_init_chains_bdpt(const DParams &P, const uint32_t *seed_index, const float *seed_lum, hipStream_t st);
@@ -892,7 +894,34 @@ int drmlt_set_luminance(drmlt_ctx *ctx, double b) {
 // sixty-three finished lanes each (config 5 with the E S* L paths counted: 2.33e9 -> see DESIGN 7a). Chain ids, states and
 // streams are untouched: the same chains bit for bit, in other lanes. Counting sort, stable: deterministic.
 static int regroup_chains(drmlt_ctx *ctx, uint32_t n_mut) {
-    const uint32_t n = ctx->n_chains, padded = (n + 63u) / 64u * 64u, md = ctx->cfg.technique == DRMLT_TECH_MMLT ? (uint32_t) ctx->cfg.max_depth : 1u, B = 16u; // (bdpt: no depth classes)
+    const uint32_t n = ctx->n_chains, padded = (n + 63u) / 64u * 64u, md = ctx->cfg.technique == DRMLT_TECH_MMLT ? (uint32_t) ctx->cfg.max_depth : 1u; // (bdpt: no depth classes)
+    if (!getenv("DRMLT_REGROUP_ON_HOST")) {
+        // on the device, enqueued behind the launch whose counts it reads (kernels_mmlt.hip: launch_regroup): no copy, no synchronisation
+        const size_t words = regroup_scratch_words(n, md);
+        if (ctx->d_regroup.bytes < words * sizeof(uint32_t)) HIP_TRY(ctx, ctx->d_regroup.alloc(words * sizeof(uint32_t)));
+        launch_regroup(ctx->d_done.as<uint32_t>(), ctx->cfg.technique == DRMLT_TECH_MMLT ? ctx->P.chain_depth : nullptr, n, n_mut, md, ctx->d_order.as<uint32_t>(), padded,
+                       ctx->d_regroup.as<uint32_t>(), ctx->stream);
+        HIP_TRY(ctx, hipGetLastError());
+        if (!getenv("DRMLT_REGROUP_CHECK")) return DRMLT_OK;
+        // test hook: the device's permutation against the host's stable counting sort of the same counts
+        std::vector<uint32_t> got(padded), work(n);
+        HIP_TRY(ctx, hipMemcpyAsync(got.data(), ctx->d_order.p, (size_t) padded * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(work.data(), ctx->d_done.p, (size_t) n * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        std::vector<uint32_t> want(n);
+        for (uint32_t j = 0; j < n; ++j) want[j] = j;
+        auto key = [&](uint32_t j) {
+            const uint32_t d = ctx->seed_indices[j] % md, extra = work[j] > n_mut ? work[j] - n_mut : 0u;
+            return (md - 1u - d) * 16u + (15u - std::min<uint32_t>(15u, (uint32_t) ((uint64_t) extra * 16u / std::max(1u, n_mut))));
+        };
+        std::stable_sort(want.begin(), want.end(), [&](uint32_t a, uint32_t b) { return key(a) < key(b); });
+        for (uint32_t j = 0; j < padded; ++j)
+            if (got[j] != (j < n ? want[j] : n)) return ctx->fail(DRMLT_E_DEVICE, "regroup: the device's order differs from the host's stable sort at slot %u (%u instead of %u)", j, got[j], j < n ? want[j] : n);
+        ctx->regroup_checks++;
+        return DRMLT_OK;
+    }
+    // the same permutation on the host (round 3's path, kept as the cross-check: tests/test_gpu_node.py compares the two)
+    const uint32_t B = 16u;
     std::vector<uint32_t> work(n);
     HIP_TRY(ctx, hipMemcpyAsync(work.data(), ctx->d_done.p, (size_t) n * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -976,11 +1005,11 @@ int drmlt_run(drmlt_ctx *ctx, uint64_t total_mutations, volatile int *stop, drml
         ctx->mutation_base += n;
         done += n;
         ctx->launches++;
-        // Regrouping costs a D2H copy, a host counting sort, an H2D copy and two stream synchronisations. With somebody watching
-        // (stop / progress / deadline: launches of 256 mutations, what the Mitsuba plugin always runs) it is done after the first
-        // launch of a call and then every fourth one -- the chains' work changes slowly; unwatched calls regroup after every
-        // (1024-mutation) launch. A failure ends the loop through the normal exit below: counters and timings are kept.
-        if (regroup && (!(stop || cb || timed) || !ctx->regrouped || ++since_regroup >= 4)) {
+        // Regrouping is three small kernels on the chains' stream (kernels_mmlt.hip: launch_regroup), after every launch. (Round 3
+        // sorted on the host -- a D2H copy, an H2D copy and two stream synchronisations per launch; that path survives behind
+        // DRMLT_REGROUP_ON_HOST as the cross-check and is thinned to every fourth launch when somebody is watching.) A failure
+        // ends the loop through the normal exit below: counters and timings are kept.
+        if (regroup && (!(stop || cb || timed) || !ctx->regrouped || !getenv("DRMLT_REGROUP_ON_HOST") || ++since_regroup >= 4)) {
             rc = regroup_chains(ctx, n);
             if (rc != DRMLT_OK) break;
             ctx->regrouped = true;

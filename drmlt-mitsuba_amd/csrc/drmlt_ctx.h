@@ -62,7 +62,7 @@ struct drmlt_ctx {
     int bvh_depth = 0;
     int ovf_entries = 0;   // capacity per lane of the traversal stacks' overflow area (0: every stack fits its LDS column)
     size_t ovf_lanes = 0;  // columns allocated in d_ovf
-    DevBuf d_prims, d_shade, d_bsdfs, d_emitters, d_bvh, d_lut, d_film, d_x, d_cur, d_stats, d_err, d_scratch, d_chain_i, d_importance, d_bd_verts, d_bd_lists, d_prims_flat, d_prims_box, d_ovf, d_order, d_done;
+    DevBuf d_prims, d_shade, d_bsdfs, d_emitters, d_bvh, d_lut, d_film, d_x, d_cur, d_stats, d_err, d_scratch, d_chain_i, d_importance, d_bd_verts, d_bd_lists, d_prims_flat, d_prims_box, d_regroup, d_ovf, d_order, d_done;
     std::vector<DPrim> prims;
     std::vector<DShade> shade;
     std::vector<uint32_t> seed_indices; // bootstrap sample index of every chain's seed (last drmlt_seed)
@@ -76,6 +76,7 @@ struct drmlt_ctx {
     double kernel_ms = 0.0, seed_ms = 0.0;
     double kt_ms = 0.0; uint64_t kt_launches = 0; // drmlt_kernel_time window
     uint64_t host_counters[9] = {0};
+    unsigned regroup_checks = 0; // DRMLT_REGROUP_CHECK (test hook): device permutations compared with the host's so far
     bool regrouped = false; // the bidirectional kernels' execution order has been regrouped by work at least once since the last seed (drmlt_capi.cpp: regroup_chains)
     int slice = 1024; // mutations per chain per launch (<= 32768: the per-lane event counters are 16 bit)
     drmlt_comm *comm = nullptr; // set by drmlt_comm_init / drmlt_node_create

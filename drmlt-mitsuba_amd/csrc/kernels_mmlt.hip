@@ -247,3 +247,81 @@ void launch_mutate_mmlt(const DParams &P, uint32_t n_mut, uint32_t mut_base, hip
 void launch_eval_paths_mmlt(const DParams &P, const float *u, uint32_t n, uint32_t dim, float *out8, hipStream_t st) {
     hipLaunchKernelGGL(k_eval_paths_mmlt, dim3((n + CHAIN_BLOCK - 1) / CHAIN_BLOCK), dim3(CHAIN_BLOCK), mmlt_lds_bytes(P), st, P, u, n, dim, out8);
 }
+
+
+// ------------------------------------------------------------------------------------------ regrouping on the device
+// The execution order of the bidirectional chain kernels between the launches of a call (drmlt_capi.cpp: regroup): chains sorted
+// by (path depth, deepest first; evaluations of the launch just done, most first), stable in the chain id -- the counting sort the
+// host did in round 3 behind a device-to-host copy, two stream synchronisations and a host-to-device copy per launch (VERDICT r03
+// #14). Three small kernels on the chains' stream, nothing waits for the host:
+//   k_regroup_hist     one wave per segment of RG_SEG chains: key of every chain, histogram of the segment (LDS atomics) -> hist[key][seg]
+//   k_regroup_scan     one wave: hist[key][seg] := number of chains that come BEFORE the first chain of that key in that segment
+//   k_regroup_scatter  one wave per segment, its chains in id order, 64 at a time; lanes with equal keys are numbered by ballot +
+//                      prefix count, so equal keys keep their id order: the same permutation as the host's stable sort.
+#define RG_SEG 1024u
+#define RG_BUCKETS 16u
+DEV uint32_t regroup_key(const uint32_t *work, const int32_t *depth, uint32_t j, uint32_t n_mut, uint32_t md) {
+    const uint32_t d = depth ? (uint32_t) (depth[j] - 1) : 0u;                       // (seed index % maxDepth: pathsampler.cpp:889)
+    const uint32_t w = work[j], extra = w > n_mut ? w - n_mut : 0u;                   // second stages and reverse moves
+    const uint32_t b = min(RG_BUCKETS - 1u, (uint32_t) ((unsigned long long) extra * RG_BUCKETS / max(1u, n_mut)));
+    return (md - 1u - min(d, md - 1u)) * RG_BUCKETS + (RG_BUCKETS - 1u - b);
+}
+__global__ void __launch_bounds__(64) k_regroup_hist(const uint32_t *work, const int32_t *depth, uint32_t n, uint32_t n_mut, uint32_t md, uint32_t nseg, uint32_t *hist) {
+    __shared__ uint32_t cnt[24u * RG_BUCKETS];
+    const uint32_t lane = threadIdx.x, seg = blockIdx.x, nkeys = md * RG_BUCKETS;
+    for (uint32_t k = lane; k < nkeys; k += 64u) cnt[k] = 0u;
+    __syncthreads();
+    for (uint32_t i = 0; i < RG_SEG; i += 64u) {
+        const uint32_t j = seg * RG_SEG + i + lane;
+        if (j < n) atomicAdd(&cnt[regroup_key(work, depth, j, n_mut, md)], 1u);
+    }
+    __syncthreads();
+    for (uint32_t k = lane; k < nkeys; k += 64u) hist[(size_t) k * nseg + seg] = cnt[k];
+}
+__global__ void __launch_bounds__(64) k_regroup_scan(uint32_t nkeys, uint32_t nseg, uint32_t *hist) {
+    const uint32_t lane = threadIdx.x;
+    uint32_t running = 0u; // wave-uniform: chains before the current (key, first segment of this pass)
+    for (uint32_t k = 0; k < nkeys; ++k)
+        for (uint32_t s0 = 0; s0 < nseg; s0 += 64u) {
+            const uint32_t s = s0 + lane;
+            const uint32_t v = s < nseg ? hist[(size_t) k * nseg + s] : 0u;
+            uint32_t incl = v; // inclusive prefix sum over the wave
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const uint32_t up = (uint32_t) __shfl_up((int) incl, off, 64);
+                if ((int) lane >= off) incl += up;
+            }
+            if (s < nseg) hist[(size_t) k * nseg + s] = running + incl - v;
+            running += (uint32_t) __shfl((int) incl, 63, 64);
+        }
+}
+__global__ void __launch_bounds__(64) k_regroup_scatter(const uint32_t *work, const int32_t *depth, uint32_t n, uint32_t n_mut, uint32_t md, uint32_t nseg, const uint32_t *offs,
+                                                        uint32_t *order, uint32_t padded) {
+    __shared__ uint32_t cur[24u * RG_BUCKETS];
+    const uint32_t lane = threadIdx.x, seg = blockIdx.x, nkeys = md * RG_BUCKETS;
+    for (uint32_t k = lane; k < nkeys; k += 64u) cur[k] = offs[(size_t) k * nseg + seg];
+    __syncthreads();
+    for (uint32_t i = 0; i < RG_SEG; i += 64u) {
+        const uint32_t j = seg * RG_SEG + i + lane;
+        const bool have = j < n;
+        const uint32_t key = have ? regroup_key(work, depth, j, n_mut, md) : 0xffffffffu;
+        unsigned long long todo = __ballot(have);
+        while (todo) { // one distinct key per round, lowest pending lane first: every lane of the wave reaches the end
+            const uint32_t k = (uint32_t) __shfl((int) key, __builtin_ctzll(todo), 64);
+            const unsigned long long m = __ballot(have && key == k);
+            if (have && key == k) order[cur[k] + __builtin_amdgcn_mbcnt_hi((uint32_t) (m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) m, 0u))] = j;
+            __syncthreads();
+            if (lane == 0) cur[k] += (uint32_t) __popcll(m);
+            __syncthreads();
+            todo &= ~m;
+        }
+    }
+    if (seg == 0) for (uint32_t j = n + lane; j < padded; j += 64u) order[j] = n; // whole waves: the tail runs no chain
+}
+void launch_regroup(const uint32_t *work, const int32_t *depth_or_null, uint32_t n, uint32_t n_mut, uint32_t md, uint32_t *order, uint32_t padded, uint32_t *scratch, hipStream_t st) {
+    const uint32_t nseg = (n + RG_SEG - 1u) / RG_SEG, nkeys = md * RG_BUCKETS;
+    hipLaunchKernelGGL(k_regroup_hist, dim3(nseg), dim3(64), 0, st, work, depth_or_null, n, n_mut, md, nseg, scratch);
+    hipLaunchKernelGGL(k_regroup_scan, dim3(1), dim3(64), 0, st, nkeys, nseg, scratch);
+    hipLaunchKernelGGL(k_regroup_scatter, dim3(nseg), dim3(64), 0, st, work, depth_or_null, n, n_mut, md, nseg, scratch, order, padded);
+}
+size_t regroup_scratch_words(uint32_t n, uint32_t md) { return (size_t) md * RG_BUCKETS * ((n + RG_SEG - 1u) / RG_SEG); }

@@ -105,6 +105,31 @@ def test_regrouping_the_waves_by_work_changes_no_chain(pkg, kw, native_lib, monk
     assert (fa @ LUMW).sum() == pytest.approx((fb @ LUMW).sum(), rel=1e-5)
 
 
+@pytest.mark.parametrize("kw,n", [(dict(technique="mmlt", max_depth=6), 5000), (dict(technique="bdpt", max_depth=6, no_direct_sampling=0), 3000),
+                                  (dict(technique="mmlt", max_depth=11), 1030)], ids=["mmlt", "bdpt", "mmlt-deep"])
+def test_the_device_regroups_as_the_host_sort_would(pkg, kw, n, native_lib, monkeypatch):
+    """Round 4: the regrouping permutation is made on the device (histogram, scan, stable scatter: kernels_mmlt.hip) behind the launch
+    whose counts it reads -- no host round trip between the launches of a call. DRMLT_REGROUP_CHECK compares every one of them with
+    the host's stable sort of the same counts (the library fails the call on a difference); the host path (round 3's,
+    DRMLT_REGROUP_ON_HOST) ends in the same states. Chain counts that are no multiple of the 1024-chain segments or of a wave."""
+    sd = pkg.scenes.caustic_c5(32)
+    per_chain = 80
+    res = []
+    for mode in ("device+check", "host"):
+        monkeypatch.setenv("DRMLT_SLICE", "16")                      # five launches, a regrouping after each
+        monkeypatch.delenv("DRMLT_REGROUP_CHECK", raising=False); monkeypatch.delenv("DRMLT_REGROUP_ON_HOST", raising=False)
+        monkeypatch.setenv("DRMLT_REGROUP_CHECK" if mode == "device+check" else "DRMLT_REGROUP_ON_HOST", "1")
+        ctx = pkg.Context(_cfg(pkg, n, **kw), sd)
+        ctx.seed(0xFEED)
+        ctx.run(n * per_chain)                                       # raises if a device permutation differs from the host's
+        st = ctx.stats()
+        res.append((ctx.chain_state(st.max_dim if kw["technique"] == "bdpt" else 2 * (kw["max_depth"] + 1) + 2 * kw["max_depth"] + 1), st))
+        ctx.close()
+    ((ca, ua), sa), ((cb, ub), sb) = res
+    assert sa.launches == sb.launches == 5
+    assert np.array_equal(ua, ub) and np.array_equal(ca["luminance"], cb["luminance"]) and sa.accepted == sb.accepted and sa.rays == sb.rays
+
+
 def test_node_with_two_ranks_on_one_gpu_equals_single_context(pkg, native_lib, monkeypatch):
     """drmlt_node_* with two ranks (both on GPU 0: loopback transport for the reduce-scatter arithmetic): seed pool,
     threaded run, tiled develop, summed stats == one context with twice the chains."""
