@@ -187,6 +187,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-quality", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--with-progress", action="store_true", help="run with a progress callback, as the Mitsuba plugin does: the library then cuts "
+                    "the call into launches of 256 mutations per chain and synchronises after each (ADVICE r03: the plugin path's own line)")
     args = ap.parse_args()
     conf = CONFIGS[args.config]
     res = args.res or conf["res"]
@@ -288,6 +290,7 @@ def main():
             torch.cuda.synchronize()
 
     last = {}
+    progress = (lambda done, total: None) if args.with_progress else None
 
     def steps(k):
         """k steps of the render = ONE call into the library, which cuts it into launches of 1024 mutations per chain (one per
@@ -297,15 +300,15 @@ def main():
         reduce-scatter + scalar all-reduce + tile develop, all in C++ -- enqueued behind the chain kernels (one process per GPU),
         or drmlt_node_develop, which also brings the stitched image to the host (one process, N devices)."""
         if node_mode:
-            node.run(k * step_mutations * world)   # the node's total: an N-th of it per device
+            node.run(k * step_mutations * world, progress=progress)   # the node's total: an N-th of it per device
             if not os.environ.get("BENCH_SKIP_EXCHANGE"):
                 last["image"] = node.develop()
             return
         if os.environ.get("BENCH_CALL_PER_STEP"):
             for _ in range(k):
-                ctx.run(step_mutations)
+                ctx.run(step_mutations, progress=progress)
         else:
-            ctx.run(k * step_mutations)
+            ctx.run(k * step_mutations, progress=progress)
         if use_dist and not os.environ.get("BENCH_SKIP_EXCHANGE"):
             ctx.exchange_tiled(b, want_tile=False, wait=False)
 
@@ -473,7 +476,7 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": conf["what"] % dict(res=res, chains=args.chains, spp=spp), "name": args.config,
                        "max_depth": cfg_kw["max_depth"], "rr_depth": cfg_kw.get("rr_depth", 5), "p_large": 0.3, "filter": "box",
-                       "mutations_per_step_per_gpu": step_mutations,
+                       "mutations_per_step_per_gpu": step_mutations, "progress_callback": bool(args.with_progress),
                        "parallelism": ("chains partitioned x%d, one seed pool; film reduce-scatter + scalar all-reduce (RCCL from C++); " % world +
                                        ("one process drives the %d devices (drmlt_node_*, ncclCommInitAll)" % world if node_mode else "one process per GPU (drmlt_comm_*)"))
                        if multi else "1 GPU"},

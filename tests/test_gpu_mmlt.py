@@ -211,8 +211,7 @@ def test_refused_configurations(pkg, native_lib):
     sd = pkg.scenes.cornell_c2(16)
     for kw, msg in ((dict(technique="mmlt", max_depth=-1), "no max depth"),
                     (dict(technique="path", max_depth=5, fix_emitter_path=1), "fixEmitterPath without MMLT"),
-                    (dict(technique="mmlt", max_depth=5, timid_after_large=1), "timidAfterLarge"),
-                    (dict(technique="bdpt", max_depth=5, timid_after_large=1), "bdpt")):
+                    (dict(technique="mmlt", max_depth=5, timid_after_large=1), "timidAfterLarge")):   # (bdpt takes timidAfterLarge since round 4)
         with pytest.raises(pkg.DrmltError, match=msg):
             pkg.Context(pkg.abi.make_config(work_units=64, **kw), sd)
 

@@ -25,13 +25,16 @@ for f in glob.glob(os.path.join(root, "pmc_%s_*" % tag, "**", "*counter_collecti
             n[r["Counter_Name"]] += 1
 if not acc:
     raise SystemExit("no k_mutate rows under gpurun_out/pmc_%s_*" % tag)
-c = {k: acc[k] / n[k] for k in acc}
+# per CALL (the profiled command is one drmlt_run call of `muts` mutations): a call of the bidirectional kernels is cut into a short first
+# launch and the rest (regrouping), so the launches are SUMMED, not averaged -- round 4; with one launch per call the two are the same
+launches_per_call = max(n.values())
+c = {k: acc[k] for k in acc}
 rd = 2.0 * c.get("FETCH_SIZE", 0.0) * 1024.0
 wr_atomic = c.get("TCC_EA0_ATOMIC_sum", 0.0) * 32.0
 wr = max(c.get("WRITE_SIZE", 0.0) * 1024.0, wr_atomic)
 s = {
     "command": cmd or "rocprofv3 --pmc <group> --kernel-trace --output-format csv -- python3 bench.py ... (tools/pmc_run.sh %s, one pass per counter group; FETCH_SIZE and WRITE_SIZE in separate passes)" % tag,
-    "kernel": kernel, "mutations_per_launch": muts, "counters_per_launch": c,
+    "kernel": kernel, "mutations_per_launch": muts, "launches_per_call": launches_per_call, "counters_per_launch": c,
     "corrections": "FETCH_SIZE/WRITE_SIZE in KB; FETCH_SIZE doubled (gfx950 reports half of coalesced reads); write side = max(WRITE_SIZE x 1024, TCC_EA0_ATOMIC_sum x 32 B)",
     "hbm_read_bytes_per_launch": rd, "hbm_write_bytes_per_launch": wr, "hbm_bytes_per_launch": rd + wr,
     "hbm_bytes_per_mutation": (rd + wr) / muts,
