@@ -893,13 +893,15 @@ template <bool TRI> DEV Hit trace_flat(const DParams &P, f3 o, f3 d, float tmin,
     if (n > 0) {
         FlatRec A, B;
         load(p, A);
-        for (int i = 0; i < n; i += 2, p += 2) { // records n and n + 1 are sentinels
+        for (int i = 0; i < n; i += 2, p += 2) { // records n and n + 1 are sentinels: the read-ahead needs no clamp
             PINF(A);
             load(p + 1, B);
             test_flat<TRI>(A, o, d, tmin, best_t, best_uv, best_ks);
-            PINF(B);
-            load(p + 2, A);
-            test_flat<TRI>(B, o, d, tmin, best_t, best_uv, best_ks);
+            if (i + 1 < n) { // (with the cuboids most flat scenes keep one or two flat records -- the light: an odd count no longer pays for testing a sentinel)
+                PINF(B);
+                load(p + 2, A);
+                test_flat<TRI>(B, o, d, tmin, best_t, best_uv, best_ks);
+            }
         }
     }
 #undef PINF
