@@ -463,12 +463,16 @@ def main():
         # contiguous bytes at ~1.3 TB/s. Requests per mutation from the committed counter summary (TCC_EA0_ATOMIC), rate from this run.
         roof_atomic = None
         if atomics_per_mut is not None and launch_ms > 0:
+            # The guide's scattered figure is 64 lanes adding one dword each to 64 different rows: 0.08 TB/s of added bytes = 2.0e10
+            # row REQUESTS per second (each leaves L2 as its own memory-side atomic). A splat is one such request carrying three dwords,
+            # so the ceiling is priced in requests, not in bytes.
             req_s = atomics_per_mut * muts_per_launch / (launch_ms * 1e-3)
-            added = req_s * 12.0 / 1e9   # one request = the three channels of one splat (12 B added; 32 B written at the memory side)
-            roof_atomic = {"bound": "memory-side float atomics, scattered (3 adjacent dwords per film row)", "achieved": added, "peak": 80.0, "unit": "GB/s of added bytes",
-                           "frac": added / 80.0, "atomic_requests_per_mutation": atomics_per_mut, "atomic_requests_per_s": req_s,
-                           "peak_contiguous": 1300.0, "source": traffic_source,
-                           "note": "peak = MI355X_MICROARCH.md's rate for 64 lanes in 64 different rows (0.08 TB/s); it scales with every mutations/s gain"}
+            peak_req = 0.08e12 / 4.0
+            roof_atomic = {"bound": "memory-side float atomics, scattered (one request per splat: 3 adjacent dwords of one film row)",
+                           "achieved": req_s / 1e9, "peak": peak_req / 1e9, "unit": "G atomic requests/s", "frac": req_s / peak_req,
+                           "atomic_requests_per_mutation": atomics_per_mut, "added_gbs": req_s * 12.0 / 1e9, "source": traffic_source,
+                           "note": "peak = MI355X_MICROARCH.md (Global float atomics): 64 lanes in 64 different rows run at ~0.08 TB/s of added bytes = 2.0e10 "
+                                   "requests/s (256 contiguous bytes per instruction: 1.3 TB/s); scales with every mutations/s gain"}
         out = {
             "metric": "mutations/sec (accepted+rejected)", "value": value, "unit": "mutations/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

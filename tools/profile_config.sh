@@ -8,11 +8,15 @@ set -e
 R=$GRAFT_REPO_ROOT
 rt=$1; shift
 for cfg in "$@"; do
+  spp=64
   case $cfg in
-    2|3|5) muts=$((512*512*64)); name=c$cfg;;
-    *) muts=$((512*512*64)); name=$cfg;;
+    2|3) name=c$cfg;;
+    5) name=c5; spp=256;;   # the bidirectional kernels cut a call into a short first launch and the rest (regrouping): a call long
+    bdpt) name=bdpt; spp=256;; # enough that the chain state's load / store per launch is amortised as in a render
+    *) name=$cfg;;
   esac
-  cmd="python3 $R/bench.py --config $cfg --steps 1 --warmup 0 --spp 64 --no-cpu-baseline --no-quality"
+  muts=$((512*512*spp))
+  cmd="python3 $R/bench.py --config $cfg --steps 1 --warmup 0 --spp $spp --no-cpu-baseline --no-quality"
   echo "== $cfg: kernel trace" >> $R/gpurun_out/profile_progress.txt
   ( cd /tmp && export TMPDIR=/tmp && timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/kt_${rt}_$cfg -- python3 $R/bench.py --config $cfg --steps 5 --warmup 0 --no-cpu-baseline --no-quality > $R/gpurun_out/kt_${rt}_${cfg}_bench.json 2> $R/gpurun_out/kt_${rt}_$cfg.log )
   f=$(find $R/gpurun_out/kt_${rt}_$cfg -name '*kernel_stats.csv' | head -1)
