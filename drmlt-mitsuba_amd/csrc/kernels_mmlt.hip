@@ -69,8 +69,16 @@ __global__ void __launch_bounds__(CHAIN_BLOCK) k_init_chains_mmlt(DParams P, con
 
 // Two waves per SIMD is what this kernel lives on (7.3e8 -> 1.3e9 mutations/s at 131 072 chains): the launch bounds keep it
 // at 256 registers whatever else the translation unit grows, and flat scenes run the build without any BVH code (FEAT 7).
-template <int FEAT> __global__ void __launch_bounds__(CHAIN_BLOCK, 2) k_mutate_mmlt(DParams P, uint32_t n_mut, uint32_t mut_base) {
+// LDS_TABLES (round 4): the scene's shading / BSDF / emitter records staged in LDS behind the kernel's own rows, as the path kernels have
+// them -- every walk step gathers two or three of them per lane, and from device memory each gather is a dependent round trip through the
+// vector cache that the wave parks on (35 % of its time on config 5). Small scenes only (P.tables_in_lds and the rows still fit eight waves).
+template <int FEAT, bool LDS_TABLES = false> __global__ void __launch_bounds__(CHAIN_BLOCK, 2) k_mutate_mmlt(DParams P, uint32_t n_mut, uint32_t mut_base) {
     const uint32_t lane = threadIdx.x;
+    LdsTables LT;
+    LT.shade_off = ((uint32_t) P.mmlt_S + (uint32_t) P.mmlt_E + 1u + 3u * ((uint32_t) P.max_depth + 3u)) * 64u;
+    LT.bsdf_off = LT.shade_off + (uint32_t) P.n_shade * 16u;
+    LT.emit_off = LT.bsdf_off + (uint32_t) P.n_bsdfs * 12u;
+    if (LDS_TABLES) stage_tables(P, LT, lane);
     // Execution order: a wave's work is its DEEPEST chain's (every lane walks in lock step), so waves are made of chains of
     // one depth, deepest first. With more waves than the device holds (262 144 chains = two rounds) the slots that shallow
     // waves free early are taken by the next ones -- depths 6 5 4 | 3 2 1 pair up to equal sums -- and the kernel costs the
@@ -124,7 +132,8 @@ template <int FEAT> __global__ void __launch_bounds__(CHAIN_BLOCK, 2) k_mutate_m
         {
             smp.mode = stage == 0 ? SM_STAGE1 : (stage == 1 ? SM_STAGE2 : SM_REVERSE);
             MmltResult R;
-            eval_mmlt<FEAT>(P, T, smp, depth, NX, R);
+            if (LDS_TABLES) eval_mmlt<FEAT>(P, LT, smp, depth, NX, R);
+            else eval_mmlt<FEAT>(P, T, smp, depth, NX, R);
             ++work;
             ct.rays += R.nrays;
             DSplat res = R.splat;
@@ -240,7 +249,11 @@ void launch_init_chains_mmlt(const DParams &P, const uint32_t *seed_index, const
                        seed_index, seed_lum);
 }
 void launch_mutate_mmlt(const DParams &P, uint32_t n_mut, uint32_t mut_base, hipStream_t st) {
-    if (P.use_bvh) hipLaunchKernelGGL(k_mutate_mmlt<15>, dim3((P.n_chains + CHAIN_BLOCK - 1) / CHAIN_BLOCK), dim3(CHAIN_BLOCK), mmlt_lds_bytes(P), st, P, n_mut, mut_base);
+    const size_t table_bytes = ((size_t) P.n_shade * 16 + (size_t) P.n_bsdfs * 12 + (size_t) P.n_emitters * 8) * sizeof(float);
+    static const bool no_lds_tables = getenv("DRMLT_MMLT_TABLES_GLOBAL") != nullptr; // A/B
+    if (!P.use_bvh && P.tables_in_lds && !no_lds_tables && mmlt_lds_bytes(P) + table_bytes <= 20480)
+        hipLaunchKernelGGL((k_mutate_mmlt<7, true>), dim3((P.n_chains + CHAIN_BLOCK - 1) / CHAIN_BLOCK), dim3(CHAIN_BLOCK), mmlt_lds_bytes(P) + table_bytes, st, P, n_mut, mut_base);
+    else if (P.use_bvh) hipLaunchKernelGGL(k_mutate_mmlt<15>, dim3((P.n_chains + CHAIN_BLOCK - 1) / CHAIN_BLOCK), dim3(CHAIN_BLOCK), mmlt_lds_bytes(P), st, P, n_mut, mut_base);
     else hipLaunchKernelGGL(k_mutate_mmlt<7>, dim3((P.n_chains + CHAIN_BLOCK - 1) / CHAIN_BLOCK), dim3(CHAIN_BLOCK), mmlt_lds_bytes(P), st, P, n_mut,
                        mut_base);
 }
