@@ -988,6 +988,23 @@ struct LdsTables {
     }
     DEV float emitter_cdf_lo(int i) const { return lds_x[emit_off + (uint32_t) i * 8u + 4u]; }
 };
+// BSDF and emitter records in LDS, shading records in device memory: for kernels whose own rows leave less LDS than the shading table
+// needs (k_mutate_bdpt at two waves per SIMD: 19.25 KB of rows; the Cornell scene's 30 shading records are 1.9 KB, its four BSDFs and one
+// emitter 224 bytes)
+struct MixedTables {
+    const DShade *sh;
+    LdsTables L;
+    DEV DShade shade(int i) const { return load_global16(sh + i); }
+    DEV DBsdf bsdf(int i) const { return L.bsdf(i); }
+    DEV DEmitter emitter(int i) const { return L.emitter(i); }
+    DEV float emitter_cdf_lo(int i) const { return L.emitter_cdf_lo(i); }
+};
+DEV void stage_bsdfs_emitters(const DParams &P, const LdsTables &T, uint32_t lane) {
+    const float *src = reinterpret_cast<const float *>(P.bsdfs);
+    for (uint32_t i = lane; i < (uint32_t) P.n_bsdfs * 12u; i += 64u) lds_x[T.bsdf_off + i] = src[i];
+    src = reinterpret_cast<const float *>(P.emitters);
+    for (uint32_t i = lane; i < (uint32_t) P.n_emitters * 8u; i += 64u) lds_x[T.emit_off + i] = src[i];
+}
 // cooperative copy of the three tables into LDS by one wave
 DEV void stage_tables(const DParams &P, const LdsTables &T, uint32_t lane) {
     const float *src = reinterpret_cast<const float *>(P.shade);

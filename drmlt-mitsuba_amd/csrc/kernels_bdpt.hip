@@ -134,8 +134,16 @@ __global__ void __launch_bounds__(CHAIN_BLOCK) k_init_chains_bdpt(DParams P, con
 // OCC 2: registers capped at 256 (the rest spills to scratch) so that two waves share a SIMD -- chosen by the launcher when
 // there are waves to fill them (more than 65 536 chains): a single wave64 issues a vector instruction every 4 cycles at
 // best, the SIMD one every 2.
-template <int FEAT, int OCC> __global__ void __launch_bounds__(CHAIN_BLOCK, OCC) k_mutate_bdpt(DParams P, uint32_t n_mut, uint32_t mut_base) {
+// LDS_BSDFS (round 4): BSDF and emitter records staged in LDS behind the kernel's rows (device_path.h: MixedTables) -- every walk step and
+// every connection cell gathers one or two BSDF records per lane; the shading table does not fit beside 19.25 KB of rows at two waves per SIMD.
+template <int FEAT, int OCC, bool LDS_BSDFS = false> __global__ void __launch_bounds__(CHAIN_BLOCK, OCC) k_mutate_bdpt(DParams P, uint32_t n_mut, uint32_t mut_base) {
     const uint32_t lane = threadIdx.x;
+    MixedTables MT;
+    MT.sh = P.shade;
+    MT.L.shade_off = 0u;
+    MT.L.bsdf_off = ((uint32_t) P.mmlt_S + (uint32_t) P.mmlt_E) * 64u + (uint32_t) bdpt_eval_lds_floats(P.max_depth);
+    MT.L.emit_off = MT.L.bsdf_off + (uint32_t) P.n_bsdfs * 12u;
+    if (LDS_BSDFS) stage_bsdfs_emitters(P, MT.L, lane);
     // Execution order (drmlt_capi.cpp: regroup_chains): which chain a lane runs. Between the launches of a call the host groups the
     // chains by the evaluations they needed in the launch just done, so that chains parked on a glint (two evaluations per mutation,
     // launch after launch) share waves instead of holding sixty-three finished lanes each. Chain ids -- state, streams, workspace
@@ -188,7 +196,8 @@ template <int FEAT, int OCC> __global__ void __launch_bounds__(CHAIN_BLOCK, OCC)
         // Green's reverse path only needs its luminance; it is written over the first-stage list, which is rejected
         // for good by then (acc1 = false) and has already been splatted (see below)
         float *target = stage == 1 ? L2 : L1;
-        eval_bdpt<FEAT>(P, T, smp, run, cc, NX, target, R); // the whole wave: the connections of all chains go to all lanes
+        if (LDS_BSDFS) eval_bdpt<FEAT>(P, MT, smp, run, cc, NX, target, R); // the whole wave: the connections of all chains go to all lanes
+        else eval_bdpt<FEAT>(P, T, smp, run, cc, NX, target, R);
         if (!run) continue;
         ++work;
         {
@@ -334,7 +343,10 @@ void launch_mutate_bdpt(const DParams &P, uint32_t n_mut, uint32_t mut_base, hip
     const dim3 grid((P.n_chains + CHAIN_BLOCK - 1) / CHAIN_BLOCK), block(CHAIN_BLOCK);
     static const int force_occ = getenv("DRMLT_BDPT_OCC") ? atoi(getenv("DRMLT_BDPT_OCC")) : 0; // diagnostic
     const bool two = force_occ ? force_occ == 2 : (!P.use_bvh && grid.x > 1024u + 256u && bdpt_lds_bytes(P) <= 20480);
+    const size_t tb = ((size_t) P.n_bsdfs * 12 + (size_t) P.n_emitters * 8) * sizeof(float);
+    static const bool global_tables = getenv("DRMLT_BDPT_TABLES_GLOBAL") != nullptr; // A/B
     if (P.use_bvh) hipLaunchKernelGGL((k_mutate_bdpt<15, 1>), grid, block, bdpt_lds_bytes(P), st, P, n_mut, mut_base);
+    else if (two && !global_tables && bdpt_lds_bytes(P) + tb <= 20480) hipLaunchKernelGGL((k_mutate_bdpt<7, 2, true>), grid, block, bdpt_lds_bytes(P) + tb, st, P, n_mut, mut_base);
     else if (two) hipLaunchKernelGGL((k_mutate_bdpt<7, 2>), grid, block, bdpt_lds_bytes(P), st, P, n_mut, mut_base);
     else hipLaunchKernelGGL((k_mutate_bdpt<7, 1>), grid, block, bdpt_lds_bytes(P), st, P, n_mut, mut_base);
 }
