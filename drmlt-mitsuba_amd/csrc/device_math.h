@@ -42,12 +42,6 @@ struct u4 {
     uint32_t x, y, z, w;
 };
 DEV u4 philox4x32_10(uint32_t k0, uint32_t k1, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3) {
-#ifdef DRMLT_PHILOX_OPAQUE_KEYS
-    // The key is wave-uniform, so the compiler computes the twenty round keys once per kernel and keeps them in scalar registers for good --
-    // in kernels that call the generator from dozens of inlined sites (the bidirectional samplers) those registers spill into vector lanes and
-    // every call reads them back (840 v_readlane in k_mutate_mmlt). Opaque at the call: the round keys are scalar adds here, live nowhere else.
-    asm volatile("" : "+s"(k0), "+s"(k1));
-#endif
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
         // one 32 x 32 -> 64 multiply per product (v_mad_u64_u32) instead of a quarter-rate mul_hi / mul_lo pair
