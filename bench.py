@@ -74,16 +74,19 @@ CONFIGS = {
                  pmc="r02_soup_pmc.json", ref_spp=2048,
                  what="closed room with 2000 random triangles (BVH in HBM) %(res)dx%(res)d, drmlt technique=path type=orbital, "
                       "%(chains)d chains/GPU, sampleCount %(spp)d"),
-    "soup50k": dict(scene=("triangle_soup", dict(n_tris=50000)), res=512, chains=131072,
-                    cfg=dict(technique="path", type="orbital", max_depth=8, rr_depth=5), spp=256, kernel="k_mutate_v5",
+    # 50 000 / 1 000 000 triangles: the waves are parked on node fetches more than half of their time, and what covers a fetch is
+    # another wave. From 163 840 chains up k_mutate_v5 keeps its proposal rows in device memory and is built for THREE waves per
+    # SIMD (kernels.hip: ROWS_MEM): 196 608 chains fill them (sampleCount 240 / 60: a whole number of mutations per chain).
+    "soup50k": dict(scene=("triangle_soup", dict(n_tris=50000)), res=512, chains=196608,
+                    cfg=dict(technique="path", type="orbital", max_depth=8, rr_depth=5), spp=240, kernel="k_mutate_v5",
                     pmc="r02_soup50k_pmc.json", ref_spp=512,
                     what="closed room with 50000 random triangles (BVH, primitive and shading records: 9.6 MB in HBM / L2; "
                          "32-bit traversal stacks) %(res)dx%(res)d, drmlt technique=path type=orbital, %(chains)d chains/GPU, "
                          "sampleCount %(spp)d"),
     # a scene whose node / primitive / shading records (188 MB) exceed the L2 caches: the regime SURVEY 8(d) names as the one
-    # where memory, not instruction issue, would bound the path. 64 mutations/pixel per step (the scene is slow to traverse).
-    "soup1m": dict(scene=("triangle_soup", dict(n_tris=1000000)), res=512, chains=131072,
-                   cfg=dict(technique="path", type="orbital", max_depth=8, rr_depth=5), spp=64, kernel="k_mutate_v5",
+    # where memory, not instruction issue, would bound the path. 60 mutations/pixel per step (the scene is slow to traverse).
+    "soup1m": dict(scene=("triangle_soup", dict(n_tris=1000000)), res=512, chains=196608,
+                   cfg=dict(technique="path", type="orbital", max_depth=8, rr_depth=5), spp=60, kernel="k_mutate_v5",
                    pmc="r02_soup1m_pmc.json", no_cpu_baseline="the CPU restatement has no acceleration structure: brute force over "
                    "1e6 triangles per ray is not a baseline (soup50k already runs 3e3 mutations/s on 16 threads)", no_quality=True,
                    what="closed room with 1000000 random triangles (BVH, primitive and shading records: 188 MB, beyond L2, inside "

@@ -612,6 +612,20 @@ drmlt_ctx *drmlt_create(const drmlt_config *cfg, const drmlt_scene *scene, int d
     // 14 2.05e9, 16 2.04e9, 20 1.94e9; v5 on the same scene at 131 072 chains 24 2.33e9, 32 2.39e9, 40 2.42e9, 48 2.36e9)
     P.mh_batch = P.kernel_variant == 5 ? (P.use_bvh ? (beyond_l2 ? 8 : 16) : 40) : (P.kernel_variant == 4 ? (P.use_bvh ? (P.bvh_stack16 ? 6 : 4) : (P.features == 0 ? 14 : 8)) : 32); // v4 / v5: chains run free, the bookkeeping branch fires as soon as a few are parked
     if (const char *k = getenv("DRMLT_MH_BATCH")) P.mh_batch = std::max(1, std::min(64, atoi(k)));
+    // k_mutate_v5 on traversed scenes with chains for more than two 64-chain waves per SIMD (from 163 840 per GPU): the proposal
+    // rows move from LDS to device memory and the kernel is built for three waves per SIMD (kernels.hip: ROWS_MEM)
+    P.rows = nullptr;
+    {
+        int cus = 256;
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, ctx->device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
+        bool rows_mem = P.kernel_variant == 5 && P.use_bvh && !mmlt && !bdpt && cfg->algo != DRMLT_ALGO_PSSMLT && (uint64_t) ctx->n_chains * 2u >= (uint64_t) cus * 4u * 64u * 5u;
+        if (const char *e = getenv("DRMLT_ROWS_MEM")) rows_mem = atoi(e) != 0 && P.kernel_variant == 5 && P.use_bvh && !mmlt && !bdpt && cfg->algo != DRMLT_ALGO_PSSMLT;
+        if (rows_mem) {
+            if (ctx->d_rows.alloc((size_t) P.eff_dim * ctx->n_chains * sizeof(float)) != hipSuccess) return bail(ctx, "device allocation of the proposal rows failed");
+            P.rows = ctx->d_rows.as<float>();
+        }
+    }
     P.bvh_overflow = nullptr; P.bvh_ovf_lanes = 0;
     P.exec_order = nullptr;
     // measured (5-launch calls) on the 2000-triangle soup: 16 3.69e8, 20 3.80e8, 24 3.84e8, 28 3.84e8 mutations/s; on 50 000 triangles (32-bit

@@ -62,7 +62,7 @@ struct drmlt_ctx {
     int bvh_depth = 0;
     int ovf_entries = 0;   // capacity per lane of the traversal stacks' overflow area (0: every stack fits its LDS column)
     size_t ovf_lanes = 0;  // columns allocated in d_ovf
-    DevBuf d_prims, d_shade, d_bsdfs, d_emitters, d_bvh, d_lut, d_film, d_x, d_cur, d_stats, d_err, d_scratch, d_chain_i, d_importance, d_bd_verts, d_bd_lists, d_prims_flat, d_prims_box, d_regroup, d_ovf, d_order, d_done;
+    DevBuf d_prims, d_shade, d_bsdfs, d_emitters, d_bvh, d_lut, d_film, d_x, d_cur, d_stats, d_err, d_scratch, d_chain_i, d_importance, d_bd_verts, d_bd_lists, d_prims_flat, d_prims_box, d_regroup, d_ovf, d_order, d_done, d_rows;
     std::vector<DPrim> prims;
     std::vector<DShade> shade;
     std::vector<uint32_t> seed_indices; // bootstrap sample index of every chain's seed (last drmlt_seed)

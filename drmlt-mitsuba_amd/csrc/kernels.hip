@@ -919,6 +919,12 @@ __global__ void __launch_bounds__(CHAIN_BLOCK) k_mutate_v4(DParams P, uint32_t n
 #define V5_STACK32_CAP 25 // (no splat queue, coins drawn per lane instead of kept in four rows: 28 rows of 256 B for the column; measured on 50 000 /
                           // 1 000 000 triangles: 11 entries 2.23e8 / 5.65e7, 16 2.48e8 / 7.03e7, 20 2.69e8 / 7.62e7)
 #define V5_SLOTS 128u
+#ifndef V5_ROWS_MEM_WAVES
+#define V5_ROWS_MEM_WAVES 3 // waves per SIMD the ROWS_MEM builds are compiled for (registers) and sized for (LDS)
+#endif
+#ifndef V5_ROWS_MEM_STACK32_CAP
+#define V5_ROWS_MEM_STACK32_CAP 25 // as the rows-in-LDS build (larger columns cost the twelfth wave: LDS is granted in steps)
+#endif
 enum { RS_IDLE = 0, RS_BUSY = 1, RS_DONE = 2 };
 
 struct V5Lds {
@@ -940,9 +946,29 @@ DEV V5Lds v5_layout(uint32_t D, uint32_t qcap, bool coin_rows) {
 }
 static size_t v5_lds_bytes(uint32_t D, uint32_t qcap, bool coin_rows) { return ((size_t) D * 64u + (coin_rows ? 4u * 64u : 0u) + 64u + 5u * qcap + 8u * V5_SLOTS + 2u * (V5_SLOTS / 4u)) * sizeof(float); } // (+ the scene tables, when they are staged)
 
+// Where a wave's proposal rows live. RowsLds: 64 columns of lds_x (one per chain of the wave). RowsMem: device memory, [dim][chain]
+// beside the state -- the builds that give the rows' 8.7 KB of LDS (and a few registers) for a THIRD wave per SIMD on scenes that
+// are traversed: there the wave is parked on node fetches more than half of its time, and what covers a fetch is another wave
+// (1 -> 2 waves per SIMD: x 1.69 on 1 000 000 triangles, x 1.58 on 50 000). A path step reads its handful of components
+// through the L2s instead of LDS: one more fetch beside the ~60 node fetches of the ray it follows.
+struct RowsLds {
+    DEV float get(uint32_t k, uint32_t col) const { return lds_x[k * 64u + col]; }
+    DEV void put(uint32_t k, uint32_t col, float v) const { lds_x[k * 64u + col] = v; }
+};
+struct RowsMem {
+    typedef float __attribute__((address_space(1))) *GPtr;
+    GPtr base;       // column 0 of this wave: P.rows + wave_base
+    uint32_t stride; // P.n_chains
+    // (plain loads and stores: with the streaming hint -- nt, to keep the L2 lines for the BVH -- the row reads themselves miss:
+    // 50 000 triangles 3.13e8 -> 2.79e8, 1 000 000 9.16e7 -> 8.52e7)
+    DEV float get(uint32_t k, uint32_t col) const { return base[(size_t) k * stride + col]; }
+    DEV void put(uint32_t k, uint32_t col, float v) const { base[(size_t) k * stride + col] = v; }
+};
+
 // the proposal rows as the path step sees them: whatever stage is being evaluated sits in the one row group
-struct PoolRowSampler {
+template <class Rows> struct PoolRowSampler {
     uint32_t lane;
+    Rows rows;
     // Mira's ratio alone looks behind the rows (they hold z by then): the state in device memory and the first-stage draws,
     // set by the kernel before a decision (mira_*), block cache of the TAG_S1 stream
     const float *mira_x = nullptr;
@@ -950,7 +976,7 @@ struct PoolRowSampler {
     uint32_t mira_k0 = 0u, mira_k1 = 0u, mira_major = 0u, mira_chain = 0u, cached = 0xffffffffu;
     u4 blk = {0u, 0u, 0u, 0u};
     DEV void reset_caches() { cached = 0xffffffffu; }
-    DEV float row(uint32_t k) const { return lds_x[k * 64u + lane]; }
+    DEV float row(uint32_t k) const { return rows.get(k, lane); }
     DEV float next(uint32_t k) const { return wrap01(row(k)); }
     DEV float x(uint32_t k) const { return load_global_f32(mira_x + (size_t) k * mira_stride); }
     DEV float y_raw(uint32_t k) { // iid Kelemen step, small (the only caller: mira_ratio)
@@ -967,7 +993,7 @@ struct PoolRowSampler {
 };
 
 // first-stage proposal of the chain in column `col` (state column `xcol` of P.x), dimensions 4b .. 4b+3, from Philox block b
-DEV void v5_fill_first(const DParams &P, uint32_t D, uint32_t col, size_t xcol, uint32_t b, uint32_t major, uint32_t chain, bool large) {
+template <class Rows> DEV void v5_fill_first(const DParams &P, const Rows &rows, uint32_t D, uint32_t col, size_t xcol, uint32_t b, uint32_t major, uint32_t chain, bool large) {
     FP_STRICT;
     const u4 r = philox4x32_10(P.key0, P.key1, b, major, chain, TAG_S1);
     const float u0 = u32_to_unit(r.x), u1 = u32_to_unit(r.y), u2 = u32_to_unit(r.z), u3 = u32_to_unit(r.w);
@@ -984,28 +1010,27 @@ DEV void v5_fill_first(const DParams &P, uint32_t D, uint32_t col, size_t xcol, 
         y0 = x0 + kelemen_sample(u0, KELEMEN_S2); y1 = x1 + kelemen_sample(u1, KELEMEN_S2);
         y2 = x2 + kelemen_sample(u2, KELEMEN_S2); y3 = x3 + kelemen_sample(u3, KELEMEN_S2);
     }
-    float *ys = &lds_x[4u * b * 64u + col];
-    ys[0] = large ? u0 : y0; ys[64] = large ? u1 : y1;
-    if (hi) { ys[128] = large ? u2 : y2; ys[192] = large ? u3 : y3; }
+    rows.put(4u * b, col, large ? u0 : y0); rows.put(4u * b + 1u, col, large ? u1 : y1);
+    if (hi) { rows.put(4u * b + 2u, col, large ? u2 : y2); rows.put(4u * b + 3u, col, large ? u3 : y3); }
 }
 // second-stage proposal from Philox block b of the TAG_S2 stream, written OVER the first-stage rows: a large step
 // (timidAfterLarge) -> dims 4b .. 4b+3 (uniforms); orbital -> the angles of pairs 4b .. 4b+3 = dims 8b .. 8b+7 (reads the y rows
 // it replaces); iid kernels -> the Gaussian perturbations of dims 2b, 2b+1 (draws 2k, 2k+1 belong to dim k)
-DEV void v5_fill_second(const DParams &P, uint32_t D, uint32_t col, size_t xcol, uint32_t b, uint32_t major, uint32_t chain, bool large) {
+template <class Rows> DEV void v5_fill_second(const DParams &P, const Rows &rows, uint32_t D, uint32_t col, size_t xcol, uint32_t b, uint32_t major, uint32_t chain, bool large) {
     FP_STRICT;
     const u4 r = philox4x32_10(P.key0, P.key1, b, major, chain, TAG_S2);
     const float u[4] = {u32_to_unit(r.x), u32_to_unit(r.y), u32_to_unit(r.z), u32_to_unit(r.w)};
     if (large) {
 #pragma unroll
         for (uint32_t i = 0; i < 4u; ++i)
-            if (4u * b + i < D) lds_x[(4u * b + i) * 64u + col] = u[i];
+            if (4u * b + i < D) rows.put(4u * b + i, col, u[i]);
         return;
     }
     if (P.type != 2) {
         const uint32_t k = 2u * b; // (k + 1 < D: the caller's block count)
         const float x0 = load_global_f32(P.x + (size_t) k * P.n_chains + xcol), x1 = load_global_f32(P.x + (size_t) (k + 1u) * P.n_chains + xcol);
-        lds_x[k * 64u + col] = x0 + gaussian_sample(u[0], u[1], P.sigma2);
-        lds_x[(k + 1u) * 64u + col] = x1 + gaussian_sample(u[2], u[3], P.sigma2);
+        rows.put(k, col, x0 + gaussian_sample(u[0], u[1], P.sigma2));
+        rows.put(k + 1u, col, x1 + gaussian_sample(u[2], u[3], P.sigma2));
         return;
     }
 #pragma unroll
@@ -1013,7 +1038,7 @@ DEV void v5_fill_second(const DParams &P, uint32_t D, uint32_t col, size_t xcol,
         const uint32_t k0 = 2u * (4u * b + i);
         if (k0 + 1u < D) {
             const float x0 = load_global_f32(P.x + (size_t) k0 * P.n_chains + xcol), x1 = load_global_f32(P.x + (size_t) (k0 + 1u) * P.n_chains + xcol);
-            const float y0 = lds_x[k0 * 64u + col], y1 = lds_x[(k0 + 1u) * 64u + col];
+            const float y0 = rows.get(k0, col), y1 = rows.get(k0 + 1u, col);
             // theta ~ wrapped Cauchy by inverse CDF (transition.h:157-173); z = y + R(theta)(x - y) (drmlt_sampler.cpp:374-391)
             float xi = u[i], sign = 1.f;
             if (xi < 0.5f) { xi *= 2.f; } else { sign = -1.f; xi = 2.f * (xi - 0.5f); }
@@ -1021,8 +1046,8 @@ DEV void v5_fill_second(const DParams &P, uint32_t D, uint32_t col, size_t xcol,
             const float A = fminf(1.f, fmaxf(-1.f, (V + WC_DISPERSION) / (1.f + WC_DISPERSION * V)));
             const float ct = A, st = sign * sqrtf(fmaxf(0.f, 1.f - A * A));
             const float dx0 = x0 - y0, dx1 = x1 - y1;
-            lds_x[k0 * 64u + col] = y0 + (ct * dx0 - st * dx1);
-            lds_x[(k0 + 1u) * 64u + col] = y1 + (st * dx0 + ct * dx1);
+            rows.put(k0, col, y0 + (ct * dx0 - st * dx1));
+            rows.put(k0 + 1u, col, y1 + (st * dx0 + ct * dx1));
         }
     }
 }
@@ -1031,7 +1056,7 @@ DEV void v5_fill_second(const DParams &P, uint32_t D, uint32_t col, size_t xcol,
 //   reverse:  rows := y* = z - (y - x)   (drmlt_proc.cpp:588-598; the rows held z, which is recomputed, not read)
 //   !reverse: state := wrap(z)            (the rows hold y* by then: DRMLTSampler::accept(second), drmlt_sampler.cpp:189-199)
 // A large step (timidAfterLarge): y and z are the uniforms themselves, dims 4b .. 4b+3 of block b of either stream.
-DEV void v5_iid_second_again(const DParams &P, uint32_t D, uint32_t col, size_t xcol, uint32_t b, uint32_t major, uint32_t chain, bool large, bool reverse) {
+template <class Rows> DEV void v5_iid_second_again(const DParams &P, const Rows &rows, uint32_t D, uint32_t col, size_t xcol, uint32_t b, uint32_t major, uint32_t chain, bool large, bool reverse) {
     FP_STRICT;
     const u4 r2 = philox4x32_10(P.key0, P.key1, b, major, chain, TAG_S2);
     const float u2[4] = {u32_to_unit(r2.x), u32_to_unit(r2.y), u32_to_unit(r2.z), u32_to_unit(r2.w)};
@@ -1044,7 +1069,7 @@ DEV void v5_iid_second_again(const DParams &P, uint32_t D, uint32_t col, size_t 
             const uint32_t k = 4u * b + i;
             if (k < D) {
                 float *xg = P.x + (size_t) k * P.n_chains + xcol;
-                if (reverse) lds_x[k * 64u + col] = u2[i] - (u1[i] - load_global_f32(xg));
+                if (reverse) rows.put(k, col, u2[i] - (u1[i] - load_global_f32(xg)));
                 else *xg = wrap01(u2[i]);
             }
         }
@@ -1058,17 +1083,21 @@ DEV void v5_iid_second_again(const DParams &P, uint32_t D, uint32_t col, size_t 
     const u4 r1 = philox4x32_10(P.key0, P.key1, k >> 2, major, chain, TAG_S1);
     const float ua = (k & 2u) ? u32_to_unit(r1.z) : u32_to_unit(r1.x), ub = (k & 2u) ? u32_to_unit(r1.w) : u32_to_unit(r1.y);
     const float y0 = x0 + kelemen_sample(ua, KELEMEN_S2), y1 = x1 + kelemen_sample(ub, KELEMEN_S2);
-    lds_x[k * 64u + col] = z0 - (y0 - x0);
-    lds_x[(k + 1u) * 64u + col] = z1 - (y1 - x1);
+    rows.put(k, col, z0 - (y0 - x0));
+    rows.put(k + 1u, col, z1 - (y1 - x1));
 }
 
 // FEAT & 8 (BVH scenes): the traversal loop described above. Flat scenes (FEAT without bit 3; LDS_TABLES: their shading /
 // BSDF / emitter tables staged in LDS) run the same kernel with the wave-uniform brute-force loop as their "trace phase":
 // up to 64 rays off the queue per pass, every one of them done when the pass ends -- so nearly all 64 chains step together
 // (k_mutate_v4 steps at most its 32 chain lanes; the helper lanes idle through the path step).
-template <int FEAT, bool STACK16, bool OVF, bool STAMPS = false, bool LDS_TABLES = false>
-__global__ void __launch_bounds__(CHAIN_BLOCK, 2) k_mutate_v5(DParams P, uint32_t n_mut, uint32_t mut_base) {
+// ROWS_MEM (BVH scenes with chains for more than two waves per SIMD): proposal rows in device memory (RowsMem), registers for three waves.
+template <int FEAT, bool STACK16, bool OVF, bool STAMPS = false, bool LDS_TABLES = false, bool ROWS_MEM = false>
+__global__ void __launch_bounds__(CHAIN_BLOCK, ROWS_MEM ? V5_ROWS_MEM_WAVES : 2) k_mutate_v5(DParams P, uint32_t n_mut, uint32_t mut_base) {
     constexpr bool FLAT = (FEAT & 8) == 0;
+    static_assert(!ROWS_MEM || !FLAT, "the flat builds keep their rows in LDS");
+    typedef typename std::conditional<ROWS_MEM, RowsMem, RowsLds>::type RowsT;
+    typedef PoolRowSampler<RowsT> SamplerT;
     constexpr uint32_t QCAP = (FLAT || STACK16) ? V5_QCAP : V5_QCAP_STACK32;
     constexpr bool COIN_ROWS = FLAT || STACK16; // coins drawn one mutation ahead by the flattened proposal pass (else: per lane, when a mutation starts)
     // per-section copies of the parameter block, read through a kernarg pointer the compiler cannot see through (see k_mutate_v4):
@@ -1087,7 +1116,7 @@ __global__ void __launch_bounds__(CHAIN_BLOCK, 2) k_mutate_v5(DParams P, uint32_
     const bool live = c < P0.n_chains;
     const uint32_t cc = live ? c : P0.n_chains - 1;
     const uint32_t D = (uint32_t) P0.eff_dim, nb1 = (D + 3u) / 4u;
-    const V5Lds L = v5_layout(D, QCAP, COIN_ROWS);
+    const V5Lds L = v5_layout(ROWS_MEM ? 0u : D, QCAP, COIN_ROWS);
     const V4Lds Lq{0u, 0u, L.q_off, QCAP};
     unsigned char *const ring = reinterpret_cast<unsigned char *>(&lds_x[L.ring_off]);
     unsigned char *const status = reinterpret_cast<unsigned char *>(&lds_x[L.status_off]);
@@ -1109,7 +1138,9 @@ __global__ void __launch_bounds__(CHAIN_BLOCK, 2) k_mutate_v5(DParams P, uint32_
     float cum = 0.f; // weight of the current state since it was adopted (one splat per residence, as k_mutate_v4)
     uint32_t qn = 0u;
     Counters ct = {0u, 0u, 0u, 0u, 0u};
-    PoolRowSampler smp{lane};
+    RowsT rows;
+    if constexpr (ROWS_MEM) { rows.base = (RowsMem::GPtr) (uintptr_t) (P0.rows + wave_base); rows.stride = P0.n_chains; }
+    SamplerT smp{lane, rows};
 
     PathState ps;
     path_init(P0, ps);
@@ -1129,7 +1160,7 @@ __global__ void __launch_bounds__(CHAIN_BLOCK, 2) k_mutate_v5(DParams P, uint32_
 
     // traversal: this lane's column of the stack, the ray it is working on (`slot`), the FIFO of pending slots
     typedef typename std::conditional<STACK16, short, int>::type StackT;
-    constexpr int CAP = STACK16 ? BVH_STACK : V5_STACK32_CAP;
+    constexpr int CAP = STACK16 ? BVH_STACK : (ROWS_MEM ? V5_ROWS_MEM_STACK32_CAP : V5_STACK32_CAP);
     __shared__ StackT v5_stack[FLAT ? 1 : (CAP + 3) * 64];
     StackT *const my_stack = v5_stack + (FLAT ? 0u : lane);
     Trav T;
@@ -1191,8 +1222,8 @@ __global__ void __launch_bounds__(CHAIN_BLOCK, 2) k_mutate_v5(DParams P, uint32_
                     }
                     const bool shadow_clear = st_s == RS_DONE ? pool[64u + lane] == 0.f : true;
                     status[lane] = RS_IDLE; status[64u + lane] = RS_IDLE;
-                    if (LDS_TABLES) path_step<true, FEAT, PoolRowSampler, LdsTables, false>(Ps, LT, ps, smp, h, shadow_clear, sr);
-                    else path_step<true, FEAT, PoolRowSampler, GlobalTables, false>(Ps, GlobalTables{Ps.shade, Ps.bsdfs, Ps.emitters}, ps, smp, h, shadow_clear, sr);
+                    if (LDS_TABLES) path_step<true, FEAT, SamplerT, LdsTables, false>(Ps, LT, ps, smp, h, shadow_clear, sr);
+                    else path_step<true, FEAT, SamplerT, GlobalTables, false>(Ps, GlobalTables{Ps.shade, Ps.bsdfs, Ps.emitters}, ps, smp, h, shadow_clear, sr);
                     push_c = ps.phase == PH_CLOSEST;
                     push_s = sr.valid;
                 }
@@ -1283,11 +1314,10 @@ __global__ void __launch_bounds__(CHAIN_BLOCK, 2) k_mutate_v5(DParams P, uint32_
                         const uint32_t q = (uint32_t) (((float) ii + 0.5f) * rcp_n), j = ii - q * n;
                         const uint32_t cj = (uint32_t) lds_list[j];
                         if (valid) {
-                            const float *src = &lds_x[4u * q * 64u + cj];
                             float *dst = Pm.x + (size_t) (4u * q) * Pm.n_chains + wave_base + cj;
 #pragma unroll
                             for (uint32_t r = 0; r < 4u; ++r)
-                                if (4u * q + r < D) dst[(size_t) r * Pm.n_chains] = wrap01(src[r * 64u]);
+                                if (4u * q + r < D) dst[(size_t) r * Pm.n_chains] = wrap01(rows.get(4u * q + r, cj));
                         }
                     }
                 }
@@ -1308,7 +1338,7 @@ __global__ void __launch_bounds__(CHAIN_BLOCK, 2) k_mutate_v5(DParams P, uint32_
                         const uint32_t cj = (uint32_t) lds_list[j];
                         const uint32_t mj = (uint32_t) __shfl((int) maj_done, (int) cj, 64);
                         const unsigned lg = (unsigned) __shfl((int) large_done, (int) cj, 64);
-                        if (valid && bq < (lg ? nb1 : D / 2u)) v5_iid_second_again(Pm, D, cj, (size_t) wave_base + cj, bq, mj, chain_base + cj, lg != 0u, false);
+                        if (valid && bq < (lg ? nb1 : D / 2u)) v5_iid_second_again(Pm, rows, D, cj, (size_t) wave_base + cj, bq, mj, chain_base + cj, lg != 0u, false);
                     }
                 }
                 // this wave's own stores to the state rows must have landed before the proposals below read them back (same CU: the
@@ -1348,7 +1378,7 @@ __global__ void __launch_bounds__(CHAIN_BLOCK, 2) k_mutate_v5(DParams P, uint32_
                         const uint32_t mj = (uint32_t) __shfl((int) maj_mine, (int) cj, 64);
                         const unsigned inf = (unsigned) __shfl((int) info, (int) cj, 64);
                         if (valid) {
-                            if (b < nb1) v5_fill_first(Pm, D, cj, (size_t) wave_base + cj, b, mj, chain_base + cj, inf != 0u);
+                            if (b < nb1) v5_fill_first(Pm, rows, D, cj, (size_t) wave_base + cj, b, mj, chain_base + cj, inf != 0u);
                             else {
                                 const u4 coins = philox4x32_10(Pm.key0, Pm.key1, 0u, mj + 1u, chain_base + cj, TAG_COIN);
                                 float *dst = &lds_x[L.coin_off + cj];
@@ -1373,7 +1403,7 @@ __global__ void __launch_bounds__(CHAIN_BLOCK, 2) k_mutate_v5(DParams P, uint32_
                         const uint32_t cj = (uint32_t) lds_list[j];
                         const uint32_t mj = (uint32_t) __shfl((int) maj_mine, (int) cj, 64);
                         const unsigned inf = (unsigned) __shfl((int) info, (int) cj, 64);
-                        if (valid && b < (inf ? nb1 : nbs)) v5_fill_second(Pm, D, cj, (size_t) wave_base + cj, b, mj, chain_base + cj, inf != 0u);
+                        if (valid && b < (inf ? nb1 : nbs)) v5_fill_second(Pm, rows, D, cj, (size_t) wave_base + cj, b, mj, chain_base + cj, inf != 0u);
                     }
                 }
                 const unsigned long long f3mask = __ballot(kind == 3);
@@ -1390,9 +1420,11 @@ __global__ void __launch_bounds__(CHAIN_BLOCK, 2) k_mutate_v5(DParams P, uint32_
                         const uint32_t cj = (uint32_t) lds_list[j];
                         const uint32_t mj = (uint32_t) __shfl((int) maj_mine, (int) cj, 64);
                         const unsigned inf = (unsigned) __shfl((int) info, (int) cj, 64);
-                        if (valid && b < (inf ? nb1 : D / 2u)) v5_iid_second_again(Pm, D, cj, (size_t) wave_base + cj, b, mj, chain_base + cj, inf != 0u, true);
+                        if (valid && b < (inf ? nb1 : D / 2u)) v5_iid_second_again(Pm, rows, D, cj, (size_t) wave_base + cj, b, mj, chain_base + cj, inf != 0u, true);
                     }
                 }
+                // (rows in device memory: the flattened stores above land before their chains' lanes read them -- same CU, as for the state)
+                if (ROWS_MEM && (f1mask | f2mask | f3mask)) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
                 // ---- begin the evaluation: film position and camera ray from the first two components; the ray goes into the pool
                 if (parked) {
                     if (kind == 0) ps.phase = PH_IDLE;
@@ -1608,9 +1640,10 @@ void launch_mutate(const DParams &P, uint32_t n_mut, uint32_t mut_base, hipStrea
     const dim3 block(CHAIN_BLOCK);
     if (P.kernel_variant == 5) { // ray pool, 64 chains per wave
         const bool flat = (P.features & 8) == 0;
-        size_t lds = v5_lds_bytes((uint32_t) D, (flat || P.bvh_stack16) ? V5_QCAP : V5_QCAP_STACK32, flat || P.bvh_stack16);
+        const bool rows_mem = !flat && P.rows != nullptr; // (drmlt_capi.cpp: chains for more than two waves per SIMD)
+        size_t lds = v5_lds_bytes(rows_mem ? 0u : (uint32_t) D, (flat || P.bvh_stack16) ? V5_QCAP : V5_QCAP_STACK32, flat || P.bvh_stack16);
         if (flat && P.tables_in_lds) lds += (size_t) P.n_shade * 64 + (size_t) P.n_bsdfs * 48 + (size_t) P.n_emitters * 32;
-        if (getenv("DRMLT_VERBOSE")) fprintf(stderr, "[drmlt] k_mutate_v5: %zu B of LDS per wave%s\n", lds, flat ? "" : " (+ the traversal stack)");
+        if (getenv("DRMLT_VERBOSE")) fprintf(stderr, "[drmlt] k_mutate_v5: %zu B of LDS per wave%s%s\n", lds, flat ? "" : " (+ the traversal stack)", rows_mem ? "; proposal rows in device memory, three waves per SIMD" : "");
         const dim3 g5((P.n_chains + 63) / 64);
         const bool diffuse = P.features == 8;
         if (flat) { // brute-force loop as the trace phase; tables in LDS when they are small (they are, for scenes this small)
@@ -1620,6 +1653,12 @@ void launch_mutate(const DParams &P, uint32_t n_mut, uint32_t mut_base, hipStrea
             else if (P.features == 1) hipLaunchKernelGGL((k_mutate_v5<1, true, false, false, true>), g5, block, lds, st, P, n_mut, mut_base); // rough conductors, no dielectric (config 3)
             else if ((P.features & ~3) == 0) hipLaunchKernelGGL((k_mutate_v5<3, true, false, false, true>), g5, block, lds, st, P, n_mut, mut_base);
             else hipLaunchKernelGGL((k_mutate_v5<7, true, false, false, true>), g5, block, lds, st, P, n_mut, mut_base);
+        }
+        else if (rows_mem) {
+            if (!P.bvh_stack16) { if (diffuse) hipLaunchKernelGGL((k_mutate_v5<8, false, true, false, false, true>), g5, block, lds, st, P, n_mut, mut_base); else hipLaunchKernelGGL((k_mutate_v5<15, false, true, false, false, true>), g5, block, lds, st, P, n_mut, mut_base); }
+            else if (P.bvh_overflow) { if (diffuse) hipLaunchKernelGGL((k_mutate_v5<8, true, true, false, false, true>), g5, block, lds, st, P, n_mut, mut_base); else hipLaunchKernelGGL((k_mutate_v5<15, true, true, false, false, true>), g5, block, lds, st, P, n_mut, mut_base); }
+            else if (diffuse) hipLaunchKernelGGL((k_mutate_v5<8, true, false, false, false, true>), g5, block, lds, st, P, n_mut, mut_base);
+            else hipLaunchKernelGGL((k_mutate_v5<15, true, false, false, false, true>), g5, block, lds, st, P, n_mut, mut_base);
         }
         else if (!P.bvh_stack16) { if (diffuse) hipLaunchKernelGGL((k_mutate_v5<8, false, true>), g5, block, lds, st, P, n_mut, mut_base); else hipLaunchKernelGGL((k_mutate_v5<15, false, true>), g5, block, lds, st, P, n_mut, mut_base); }
         else if (P.bvh_overflow) { if (diffuse) hipLaunchKernelGGL((k_mutate_v5<8, true, true>), g5, block, lds, st, P, n_mut, mut_base); else hipLaunchKernelGGL((k_mutate_v5<15, true, true>), g5, block, lds, st, P, n_mut, mut_base); }

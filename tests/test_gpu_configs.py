@@ -178,3 +178,15 @@ def test_bench_config_bdpt_full_size(pkg, native_lib):
     assert lum(film.astype(np.float64)).sum() == pytest.approx(M, rel=2e-2)
     img = ctx.develop()
     assert lum(img.astype(np.float64)).mean() == pytest.approx(b, rel=2e-3)
+
+
+def test_bench_config_soup50k_full_size_three_waves_per_simd(pkg, native_lib, capfd, monkeypatch):
+    """`bench.py --config soup50k`: 50 000 triangles, 196 608 chains -> k_mutate_v5 with its proposal rows in device memory, built for
+    three waves per SIMD (picked by the chain count, no environment variable)."""
+    monkeypatch.setenv("DRMLT_VERBOSE", "1")
+    ctx, b, M, n = _run_like_bench(pkg, "soup50k", 60, None)
+    assert "proposal rows in device memory" in capfd.readouterr().err
+    st, _ = check_invariants(ctx, M, b)
+    assert st.n_chains == 196608 and st.bvh_node_visits > 50 * M
+    cur, u = ctx.chain_state(34)
+    assert np.all((u >= 0) & (u <= 1)) and np.all(cur["luminance"] > 0)

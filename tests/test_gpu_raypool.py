@@ -85,6 +85,36 @@ def test_ray_pool_kernel_runs_the_same_chains(pkg, native_lib, scene, skw, kw, e
     assert np.abs(lum(f5) - lum(f4)).sum() / lum(f4).sum() < 1e-4
 
 
+BVH_CASES = [(c, i) for c, i in zip(CASES, ["soup-orbital", "soup-timid", "soup-mixture", "soup-short", "soup40k", "caustic-bvh", "door-bvh", "", "", "", "",
+                                            "soup-green", "soup-green-timid", "soup-green-mixture", "", "", "soup-mira", "soup-mira-timid", "", ""]) if i]
+
+
+@pytest.mark.parametrize("scene,skw,kw,env", [c for c, _ in BVH_CASES], ids=[i for _, i in BVH_CASES])
+def test_rows_in_device_memory_run_the_same_chains(pkg, native_lib, scene, skw, kw, env):
+    """From 163 840 chains per GPU up, k_mutate_v5 on traversed scenes keeps its proposal rows in device memory and is built for
+    three waves per SIMD (ROWS_MEM). Forced here at 1000 chains: the chains of the rows-in-LDS build, bit for bit."""
+    sd = pkg.scenes.SCENES[scene](res=32, **skw)
+    n_chains, n_mut = 1000, 60
+    base = dict(max_depth=8, direct_samples=-1, luminance_samples=20000, work_units=n_chains, sample_count=1)
+    base.update(kw)
+    cfg = pkg.abi.make_config(**base)
+    res = []
+    for rows_mem in (0, 1):
+        ctx = ctx_with_env(pkg, cfg, sd, DRMLT_KERNEL=5, DRMLT_ROWS_MEM=rows_mem, **env)
+        ctx.seed(0x5005)
+        ctx.run(n_chains * n_mut)
+        res.append((ctx.chain_state(34), ctx.stats(), ctx.film()))
+        ctx.close()
+    ((c0, u0), s0, f0), ((c1, u1), s1, f1) = res
+    assert s1.mutations == s0.mutations == n_chains * n_mut
+    assert np.array_equal(u1, u0) and np.array_equal(c1["luminance"], c0["luminance"])
+    for k in ("first", "large", "bold", "second", "second_large", "second_bold", "overall"):
+        assert getattr(s1, k + "_base") == getattr(s0, k + "_base") and getattr(s1, k + "_acc") == getattr(s0, k + "_acc"), k
+    assert s1.accepted == s0.accepted and s1.rays == s0.rays and s1.path_evals == s0.path_evals and s1.bvh_node_visits == s0.bvh_node_visits > 0
+    assert lum(f1).sum() == pytest.approx(lum(f0).sum(), rel=1e-5)
+    assert np.abs(lum(f1) - lum(f0)).sum() / lum(f0).sum() < 1e-4
+
+
 def test_ray_pool_kernel_with_run_ahead_and_acceptance_map(pkg, native_lib):
     sd = pkg.scenes.triangle_soup(2000, 32)
     n_chains, per_chain = 1536, 300
