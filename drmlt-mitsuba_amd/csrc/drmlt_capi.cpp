@@ -502,7 +502,10 @@ drmlt_ctx *drmlt_create(const drmlt_config *cfg, const drmlt_scene *scene, int d
             // (k_mutate_v5, the ray-pool kernel, carries 64 chains per wave: 131 072 fill the device; it is the path technique's kernel
             // for all three types -- flat scenes included: 2.15e9 at 131 072 chains against k_mutate_v4's 1.79e9 at 65 536)
             const bool pool_kernel = !mmlt && !bdpt && cfg->algo != DRMLT_ALGO_PSSMLT && !getenv("DRMLT_KERNEL");
-            const uint64_t fill = mmlt ? 262144 : ((bdpt || pool_kernel) ? 131072 : 65536); // mmlt: two rounds of waves, run in depth order
+            // (traversed scenes with 32-bit stack entries -- tens of thousands of primitives and more: the pool kernel hides their node
+            // fetches behind a THIRD wave per SIMD, its proposal rows in device memory: 196 608 chains, kernels.hip: ROWS_MEM)
+            const bool three_waves = pool_kernel && P.use_bvh && !P.bvh_stack16;
+            const uint64_t fill = mmlt ? 262144 : (three_waves ? 196608 : ((bdpt || pool_kernel) ? 131072 : 65536)); // mmlt: two rounds of waves, run in depth order
             work_units = (int) std::min<uint64_t>(fill, std::max<uint64_t>(64, budget / 64 / 64 * 64));
         }
     }

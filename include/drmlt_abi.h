@@ -80,7 +80,7 @@ enum { DRMLT_FILTER_BOX = 0, DRMLT_FILTER_GAUSSIAN = 1 };
 enum { DRMLT_SEED_TARGET = 0, DRMLT_SEED_REFERENCE = 1 };
 
 /* workUnits = -1 ("derived", drmlt_config.work_units_rule; adaptor property "workUnitsRule" = "device" | "reference").
- *   DEVICE    (default) a device-filling chain count: 131 072 (path, bdpt), 262 144 (mmlt), pssmlt 65 536; at least 64
+ *   DEVICE    (default) a device-filling chain count: 131 072 (path, bdpt; path on large traversed scenes 196 608), 262 144 (mmlt), pssmlt 65 536; at least 64
  *             mutations per chain.
  *   REFERENCE ceil(budget / 200 000) (path) or / 100 000 (bdpt, mmlt): drmlt.cpp:434-444 -- sized for a CPU scheduler. */
 enum { DRMLT_WORK_UNITS_DEVICE = 0, DRMLT_WORK_UNITS_REFERENCE = 1 };
@@ -108,8 +108,8 @@ typedef struct drmlt_config {
     int32_t  rr_depth;           /* "rrDepth"          default 5                   */
     int32_t  direct_samples;     /* "directSamples"    default 16; <0: MLT does it */
     int32_t  luminance_samples;  /* "luminanceSamples" default 100000              */
-    int32_t  work_units;         /* "workUnits"        default -1: derived -- a device-filling chain count (65 536; 131 072 for
-                                  * bdpt, 262 144 for mmlt), at least 64 mutations per chain; the reference derives ~budget / 200 000 */
+    int32_t  work_units;         /* "workUnits"        default -1: derived -- a device-filling chain count (see DRMLT_WORK_UNITS_DEVICE),
+                                  * at least 64 mutations per chain; the reference derives ~budget / 200 000 */
     int32_t  sample_count;       /* sensor sampler's sampleCount = mutations/pixel */
     float    p_large;            /* "pLarge"           default 0.3                 */
     float    sigma;              /* "sigma"            default 1/64                */
