@@ -45,14 +45,16 @@ CONFIGS = {
               spp=256, kernel="k_mutate_v4", pmc="r02_c2_pmc.json",   # (BASELINE fixes 65 536 chains: k_mutate_v4's ground)
               what="Cornell box %(res)dx%(res)d, integrator=drmlt technique=path type=orbital, %(chains)d chains/GPU, "
                    "sampleCount %(spp)d (BASELINE.json configs[1])"),
-    # the same render with the chain count left to the library (workUnits = -1 -> 131 072 chains, k_mutate_v5): NOT the headline
-    "2x": dict(scene=("cornell_c2", {}), res=512, chains=131072, cfg=dict(technique="path", type="orbital", max_depth=8, rr_depth=5),
-               spp=256, kernel="k_mutate_v5", pmc="r03_2x_pmc.json",
+    # the same render with the chain count left to the library (workUnits = -1 -> 196 608 chains, k_mutate_v5 with its proposal rows in
+    # device memory and three waves per SIMD; sampleCount 240: a whole number of mutations per chain): NOT the headline
+    "2x": dict(scene=("cornell_c2", {}), res=512, chains=196608, cfg=dict(technique="path", type="orbital", max_depth=8, rr_depth=5),
+               spp=240, kernel="k_mutate_v5", pmc="r03_2x_pmc.json",
                what="Cornell box %(res)dx%(res)d, integrator=drmlt technique=path type=orbital, %(chains)d chains/GPU (the library's own "
                     "choice for workUnits = -1; BASELINE.json configs[1] fixes 65 536: see config 2), sampleCount %(spp)d"),
-    # BASELINE's config 3 does not fix the chain count: 131 072 chains run k_mutate_v5 (64 chains per wave, two waves per SIMD)
-    "3": dict(scene=("door_c3", {}), res=512, chains=131072, cfg=dict(technique="path", type="green", max_depth=8, rr_depth=5),
-              spp=256, kernel="k_mutate_v5", pmc="r02_c3_pmc.json",
+    # BASELINE's config 3 does not fix the chain count: 196 608 chains (what workUnits = -1 derives) run k_mutate_v5 -- 64 chains per
+    # wave, three waves per SIMD, proposal rows in device memory; sampleCount 240: a whole number of mutations per chain
+    "3": dict(scene=("door_c3", {}), res=512, chains=196608, cfg=dict(technique="path", type="green", max_depth=8, rr_depth=5),
+              spp=240, kernel="k_mutate_v5", pmc="r02_c3_pmc.json",
               what="door scene (occluded area light, rough-conductor floor) %(res)dx%(res)d, drmlt technique=path type=green, "
                    "%(chains)d chains/GPU, sampleCount %(spp)d (BASELINE.json configs[2])"),
     # 262 144 chains: k_mutate_mmlt runs one chain per lane at 256 VGPRs, so 65 536 chains are 1024 waves = one per SIMD

@@ -492,8 +492,8 @@ drmlt_ctx *drmlt_create(const drmlt_config *cfg, const drmlt_scene *scene, int d
     if (work_units <= 0) {
         // "derived" (workUnits = -1, the default). The reference sizes work units for its CPU scheduler -- 200 000 (path) or
         // 100 000 (mmlt, bdpt) mutations each, drmlt.cpp:434-444: a few hundred chains for a whole image. A device wants the
-        // count that fills it: 65 536 chains for the path kernels (32 per wave, two waves per SIMD), 131 072 for bdpt's
-        // one-chain-per-lane kernel, 262 144 for mmlt's (two rounds, so that shallow waves make room for the next), but never chains shorter than 64 mutations. An explicit workUnits is
+        // count that fills it: 196 608 or 131 072 chains for the path technique's pool kernel (64 per wave, three or two waves per SIMD:
+        // below), 131 072 for bdpt's one-chain-per-lane kernel, 262 144 for mmlt's (two rounds, so that shallow waves make room for the next), but never chains shorter than 64 mutations. An explicit workUnits is
         // taken as given; drmlt_config.work_units_rule = DRMLT_WORK_UNITS_REFERENCE (adaptor: workUnitsRule=reference) restores the reference's formula.
         if (cfg->work_units_rule == DRMLT_WORK_UNITS_REFERENCE) {
             const uint64_t per_unit = (mmlt || bdpt) ? 100000 : 200000;
@@ -502,9 +502,11 @@ drmlt_ctx *drmlt_create(const drmlt_config *cfg, const drmlt_scene *scene, int d
             // (k_mutate_v5, the ray-pool kernel, carries 64 chains per wave: 131 072 fill the device; it is the path technique's kernel
             // for all three types -- flat scenes included: 2.15e9 at 131 072 chains against k_mutate_v4's 1.79e9 at 65 536)
             const bool pool_kernel = !mmlt && !bdpt && cfg->algo != DRMLT_ALGO_PSSMLT && !getenv("DRMLT_KERNEL");
-            // (traversed scenes with 32-bit stack entries -- tens of thousands of primitives and more: the pool kernel hides their node
-            // fetches behind a THIRD wave per SIMD, its proposal rows in device memory: 196 608 chains, kernels.hip: ROWS_MEM)
-            const bool three_waves = pool_kernel && P.use_bvh && !P.bvh_stack16;
+            // (with its proposal rows in device memory the pool kernel runs a THIRD wave per SIMD, kernels.hip: ROWS_MEM -- 196 608 chains.
+            // It pays on traversed scenes with 32-bit stack entries, tens of thousands of primitives and more, whose node fetches the
+            // extra wave covers, + 10 ... 14 %, and on flat scenes, + 4 ... 12 %; not on small trees -- 2000 triangles: - 5 %)
+            const bool small_tables = ctx->shade.size() * 64 + bsdfs.size() * 48 + emitters.size() * 32 <= 16384; // (= P.tables_in_lds, below)
+            const bool three_waves = pool_kernel && (P.use_bvh ? !P.bvh_stack16 : small_tables);
             const uint64_t fill = mmlt ? 262144 : (three_waves ? 196608 : ((bdpt || pool_kernel) ? 131072 : 65536)); // mmlt: two rounds of waves, run in depth order
             work_units = (int) std::min<uint64_t>(fill, std::max<uint64_t>(64, budget / 64 / 64 * 64));
         }
@@ -622,8 +624,9 @@ drmlt_ctx *drmlt_create(const drmlt_config *cfg, const drmlt_scene *scene, int d
         int cus = 256;
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, ctx->device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
-        bool rows_mem = P.kernel_variant == 5 && P.use_bvh && !mmlt && !bdpt && cfg->algo != DRMLT_ALGO_PSSMLT && (uint64_t) ctx->n_chains * 2u >= (uint64_t) cus * 4u * 64u * 5u;
-        if (const char *e = getenv("DRMLT_ROWS_MEM")) rows_mem = atoi(e) != 0 && P.kernel_variant == 5 && P.use_bvh && !mmlt && !bdpt && cfg->algo != DRMLT_ALGO_PSSMLT;
+        const bool can = P.kernel_variant == 5 && (P.use_bvh || P.tables_in_lds) && !mmlt && !bdpt && cfg->algo != DRMLT_ALGO_PSSMLT;
+        bool rows_mem = can && (uint64_t) ctx->n_chains * 2u >= (uint64_t) cus * 4u * 64u * 5u;
+        if (const char *e = getenv("DRMLT_ROWS_MEM")) rows_mem = atoi(e) != 0 && can;
         if (rows_mem) {
             if (ctx->d_rows.alloc((size_t) P.eff_dim * ctx->n_chains * sizeof(float)) != hipSuccess) return bail(ctx, "device allocation of the proposal rows failed");
             P.rows = ctx->d_rows.as<float>();

@@ -960,7 +960,9 @@ struct RowsMem {
     GPtr base;       // column 0 of this wave: P.rows + wave_base
     uint32_t stride; // P.n_chains
     // (plain loads and stores: with the streaming hint -- nt, to keep the L2 lines for the BVH -- the row reads themselves miss:
-    // 50 000 triangles 3.13e8 -> 2.79e8, 1 000 000 9.16e7 -> 8.52e7)
+    // 50 000 triangles 3.13e8 -> 2.79e8, 1 000 000 9.16e7 -> 8.52e7. The same hint on the STATE instead -- read once per mutation,
+    // a whole mutation of every wave of the XCD apart: it does not survive in the L2 anyway -- loses as well: Cornell at 196 608
+    // chains 2.54e9 -> 2.18e9, door 1.09e9 -> 1.05e9, 50 000 triangles 3.45e8 -> 3.26e8. nt bypasses more than the L2.)
     DEV float get(uint32_t k, uint32_t col) const { return base[(size_t) k * stride + col]; }
     DEV void put(uint32_t k, uint32_t col, float v) const { base[(size_t) k * stride + col] = v; }
 };
@@ -1091,11 +1093,11 @@ template <class Rows> DEV void v5_iid_second_again(const DParams &P, const Rows 
 // BSDF / emitter tables staged in LDS) run the same kernel with the wave-uniform brute-force loop as their "trace phase":
 // up to 64 rays off the queue per pass, every one of them done when the pass ends -- so nearly all 64 chains step together
 // (k_mutate_v4 steps at most its 32 chain lanes; the helper lanes idle through the path step).
-// ROWS_MEM (BVH scenes with chains for more than two waves per SIMD): proposal rows in device memory (RowsMem), registers for three waves.
+// ROWS_MEM (chains for more than two waves per SIMD; traversed scenes and flat ones with their tables in LDS): proposal rows in device
+// memory (RowsMem), registers for three waves (the flat builds need 169 - 179 as they are: 0 - 4 spilled).
 template <int FEAT, bool STACK16, bool OVF, bool STAMPS = false, bool LDS_TABLES = false, bool ROWS_MEM = false>
 __global__ void __launch_bounds__(CHAIN_BLOCK, ROWS_MEM ? V5_ROWS_MEM_WAVES : 2) k_mutate_v5(DParams P, uint32_t n_mut, uint32_t mut_base) {
     constexpr bool FLAT = (FEAT & 8) == 0;
-    static_assert(!ROWS_MEM || !FLAT, "the flat builds keep their rows in LDS");
     typedef typename std::conditional<ROWS_MEM, RowsMem, RowsLds>::type RowsT;
     typedef PoolRowSampler<RowsT> SamplerT;
     constexpr uint32_t QCAP = (FLAT || STACK16) ? V5_QCAP : V5_QCAP_STACK32;
@@ -1640,13 +1642,19 @@ void launch_mutate(const DParams &P, uint32_t n_mut, uint32_t mut_base, hipStrea
     const dim3 block(CHAIN_BLOCK);
     if (P.kernel_variant == 5) { // ray pool, 64 chains per wave
         const bool flat = (P.features & 8) == 0;
-        const bool rows_mem = !flat && P.rows != nullptr; // (drmlt_capi.cpp: chains for more than two waves per SIMD)
+        const bool rows_mem = P.rows != nullptr && (!flat || P.tables_in_lds); // (drmlt_capi.cpp: chains for more than two waves per SIMD)
         size_t lds = v5_lds_bytes(rows_mem ? 0u : (uint32_t) D, (flat || P.bvh_stack16) ? V5_QCAP : V5_QCAP_STACK32, flat || P.bvh_stack16);
         if (flat && P.tables_in_lds) lds += (size_t) P.n_shade * 64 + (size_t) P.n_bsdfs * 48 + (size_t) P.n_emitters * 32;
         if (getenv("DRMLT_VERBOSE")) fprintf(stderr, "[drmlt] k_mutate_v5: %zu B of LDS per wave%s%s\n", lds, flat ? "" : " (+ the traversal stack)", rows_mem ? "; proposal rows in device memory, three waves per SIMD" : "");
         const dim3 g5((P.n_chains + 63) / 64);
         const bool diffuse = P.features == 8;
-        if (flat) { // brute-force loop as the trace phase; tables in LDS when they are small (they are, for scenes this small)
+        if (flat && rows_mem) { // three waves per SIMD, as on traversed scenes
+            if (P.features == 0) hipLaunchKernelGGL((k_mutate_v5<0, true, false, false, true, true>), g5, block, lds, st, P, n_mut, mut_base);
+            else if (P.features == 1) hipLaunchKernelGGL((k_mutate_v5<1, true, false, false, true, true>), g5, block, lds, st, P, n_mut, mut_base);
+            else if ((P.features & ~3) == 0) hipLaunchKernelGGL((k_mutate_v5<3, true, false, false, true, true>), g5, block, lds, st, P, n_mut, mut_base);
+            else hipLaunchKernelGGL((k_mutate_v5<7, true, false, false, true, true>), g5, block, lds, st, P, n_mut, mut_base);
+        }
+        else if (flat) { // brute-force loop as the trace phase; tables in LDS when they are small (they are, for scenes this small)
             if (!P.tables_in_lds) hipLaunchKernelGGL((k_mutate_v5<7, true, false, false, false>), g5, block, lds, st, P, n_mut, mut_base);
             else if (P.features == 0 && (P.debug & 128)) hipLaunchKernelGGL((k_mutate_v5<0, true, false, true, true>), g5, block, lds, st, P, n_mut, mut_base); // diagnostic stamps
             else if (P.features == 0) hipLaunchKernelGGL((k_mutate_v5<0, true, false, false, true>), g5, block, lds, st, P, n_mut, mut_base);

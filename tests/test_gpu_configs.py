@@ -132,20 +132,21 @@ def _run_like_bench(pkg, name, spp, launches, capfd=None):
 
 
 def test_bench_config_2x_full_size(pkg, native_lib):
-    """`bench.py --config 2x`: Cornell 512^2, 131 072 chains -> k_mutate_v5's flat build with cuboid records."""
-    ctx, b, M, n = _run_like_bench(pkg, "2x", 512, None)
+    """`bench.py --config 2x`: Cornell 512^2, 196 608 chains -> k_mutate_v5's flat build with cuboid records, proposal rows in device
+    memory, three waves per SIMD."""
+    ctx, b, M, n = _run_like_bench(pkg, "2x", 480, None)
     st, _ = check_invariants(ctx, M, b)
-    assert st.n_chains == 131072 and st.launches == 1 and st.bvh_node_visits == 0
+    assert st.n_chains == 196608 and st.launches == 1 and st.bvh_node_visits == 0
     cur, u = ctx.chain_state(34)
     assert np.all((u >= 0) & (u <= 1)) and np.all(cur["luminance"] > 0)
 
 
 def test_bench_config_3_full_size(pkg, native_lib):
-    """`bench.py --config 3`: door scene, type=green, 131 072 chains -> k_mutate_v5<1> (Green's reverse moves recomputed from the
-    state in device memory), two launches with run-ahead between them."""
-    ctx, b, M, n = _run_like_bench(pkg, "3", 512, None)
+    """`bench.py --config 3`: door scene, type=green, 196 608 chains -> k_mutate_v5<1> with three waves per SIMD (Green's reverse moves
+    recomputed from the state in device memory, proposal rows in device memory too), two launches with run-ahead between them."""
+    ctx, b, M, n = _run_like_bench(pkg, "3", 480, None)
     st, _ = check_invariants(ctx, M, b)
-    assert st.n_chains == 131072 and st.launches == 1
+    assert st.n_chains == 196608 and st.launches == 1
     assert M + st.second_base <= st.path_evals <= M + 2 * st.second_base
     ctx.run(M)                                                                  # a second call continues every chain from its counter
     st2 = ctx.stats()

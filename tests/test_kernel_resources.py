@@ -47,3 +47,7 @@ def test_chain_kernels_keep_their_occupancy(native_lib):
         # 16-bit stacks: twelve waves per CU
         stack16 = re.match(r"_Z11k_mutate_v5ILi\d+ELb1E", n) is not None
         assert r["LDS"] + 4608 + (2944 if stack16 else 0) <= 160 * 1024 // 12, (n, r)
+    flat3 = {n: r for n, r in k.items() if n.startswith("_Z11k_mutate_v5") and n.endswith("ELb0ELb1ELb1EEv7DParamsjj")}   # flat scenes, tables in LDS, ROWS_MEM
+    assert len(flat3) == 4, sorted(flat3)
+    for n, r in flat3.items():
+        assert r["Occupancy"] >= 3 and r["VGPRs"] + r["AGPRs"] <= 168 and r["ScratchSize"] <= 16, (n, r)

@@ -10,7 +10,9 @@ rt=$1; shift
 for cfg in "$@"; do
   spp=64
   case $cfg in
-    2|3) name=c$cfg;;
+    2) name=c2;;
+    3) name=c3; spp=60;;    # 196 608 chains: a whole number of mutations per chain
+    2x) name=2x; spp=60;;
     5) name=c5; spp=256;;   # the bidirectional kernels cut a call into a short first launch and the rest (regrouping): a call long
     bdpt) name=bdpt; spp=256;; # enough that the chain state's load / store per launch is amortised as in a render
     soup50k|soup1m) name=$cfg; spp=60;; # 196 608 chains: a whole number of mutations per chain
