@@ -397,6 +397,9 @@ template <class T> DEV T load_global16(const T *p) {
     for (unsigned i = 0; i < sizeof(T) / 16u; ++i) u.w[i] = q[i];
     return u.v;
 }
+// samplers that want the draws of a path step requested together (PoolRowSampler over rows in device memory, kernels.hip)
+template <class S, class = void> struct draws_batched : std::false_type {};
+template <class S> struct draws_batched<S, std::void_t<decltype(S::batch_draws)>> : std::integral_constant<bool, S::batch_draws> {};
 DEV float load_global_f32(const float *p) { return *(const float __attribute__((address_space(1))) *) (uintptr_t) p; }
 DEV void atomic_add_global_f32(float *p, float v) { // no-return float add on device memory (global_atomic_add_f32)
     (void) __hip_atomic_fetch_add((float __attribute__((address_space(1))) *) (uintptr_t) p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1261,10 +1264,18 @@ DEV void path_step(const DParams &P, const TablesT &T, PathState &ps, SamplerT &
 
     // ---------------- part 2: the one place PSS components are drawn
     float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f, v4 = 0.f;
+    if constexpr (draws_batched<SamplerT>::value) {
+        // a sampler whose rows live in device memory: all five loads in flight together instead of `need` round trips one after the other
+        // (the ones beyond `need` read component k again -- the same line -- and are not used)
+        const uint32_t k = ps.k;
+        v0 = smp.next(k); v1 = smp.next(need > 1 ? k + 1u : k); v2 = smp.next(need > 2 ? k + 2u : k);
+        v3 = smp.next(need > 3 ? k + 3u : k); v4 = smp.next(need > 4 ? k + 4u : k);
+    } else {
 #pragma nounroll
-    for (int j = 0; j < need; ++j) {
-        float v = smp.next(ps.k + (uint32_t) j);
-        if (j == 0) v0 = v; else if (j == 1) v1 = v; else if (j == 2) v2 = v; else if (j == 3) v3 = v; else v4 = v;
+        for (int j = 0; j < need; ++j) {
+            float v = smp.next(ps.k + (uint32_t) j);
+            if (j == 0) v0 = v; else if (j == 1) v1 = v; else if (j == 2) v2 = v; else if (j == 3) v3 = v; else v4 = v;
+        }
     }
 
     // ---------------- part 3: use them

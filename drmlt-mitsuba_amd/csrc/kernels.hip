@@ -969,6 +969,7 @@ struct RowsMem {
 
 // the proposal rows as the path step sees them: whatever stage is being evaluated sits in the one row group
 template <class Rows> struct PoolRowSampler {
+    static constexpr bool batch_draws = std::is_same<Rows, RowsMem>::value; // (device_path.h: path_step, part 2)
     uint32_t lane;
     Rows rows;
     // Mira's ratio alone looks behind the rows (they hold z by then): the state in device memory and the first-stage draws,
@@ -1035,12 +1036,21 @@ template <class Rows> DEV void v5_fill_second(const DParams &P, const Rows &rows
         rows.put(k + 1u, col, x1 + gaussian_sample(u[2], u[3], P.sigma2));
         return;
     }
+    // (all loads first: the stores below may alias them for the compiler, and with the rows in device memory every pair would
+    // otherwise wait for its own round trip behind the previous pair's stores)
+    float xa[4], xb[4], ya[4], yb[4];
+#pragma unroll
+    for (uint32_t i = 0; i < 4u; ++i) {
+        const uint32_t k0 = 2u * (4u * b + i);
+        const uint32_t kk = k0 + 1u < D ? k0 : 0u;
+        xa[i] = load_global_f32(P.x + (size_t) kk * P.n_chains + xcol); xb[i] = load_global_f32(P.x + (size_t) (kk + 1u) * P.n_chains + xcol);
+        ya[i] = rows.get(kk, col); yb[i] = rows.get(kk + 1u, col);
+    }
 #pragma unroll
     for (uint32_t i = 0; i < 4u; ++i) {
         const uint32_t k0 = 2u * (4u * b + i);
         if (k0 + 1u < D) {
-            const float x0 = load_global_f32(P.x + (size_t) k0 * P.n_chains + xcol), x1 = load_global_f32(P.x + (size_t) (k0 + 1u) * P.n_chains + xcol);
-            const float y0 = rows.get(k0, col), y1 = rows.get(k0 + 1u, col);
+            const float x0 = xa[i], x1 = xb[i], y0 = ya[i], y1 = yb[i];
             // theta ~ wrapped Cauchy by inverse CDF (transition.h:157-173); z = y + R(theta)(x - y) (drmlt_sampler.cpp:374-391)
             float xi = u[i], sign = 1.f;
             if (xi < 0.5f) { xi *= 2.f; } else { sign = -1.f; xi = 2.f * (xi - 0.5f); }
@@ -1317,9 +1327,12 @@ __global__ void __launch_bounds__(CHAIN_BLOCK, ROWS_MEM ? V5_ROWS_MEM_WAVES : 2)
                         const uint32_t cj = (uint32_t) lds_list[j];
                         if (valid) {
                             float *dst = Pm.x + (size_t) (4u * q) * Pm.n_chains + wave_base + cj;
+                            float v[4]; // (loads first: see v5_fill_second)
+#pragma unroll
+                            for (uint32_t r = 0; r < 4u; ++r) v[r] = rows.get(4u * q + r < D ? 4u * q + r : 4u * q, cj);
 #pragma unroll
                             for (uint32_t r = 0; r < 4u; ++r)
-                                if (4u * q + r < D) dst[(size_t) r * Pm.n_chains] = wrap01(rows.get(4u * q + r, cj));
+                                if (4u * q + r < D) dst[(size_t) r * Pm.n_chains] = wrap01(v[r]);
                         }
                     }
                 }
