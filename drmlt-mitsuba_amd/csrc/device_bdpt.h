@@ -99,7 +99,7 @@ struct BdptStore {
 template <class TablesT>
 DEV float emitter_direct_pdf_area(const TablesT &T, f3 ref_p, f3 ref_n, bool refn_zero, f3 sp, f3 sn, int emitter) {
     const DEmitter E = T.emitter(emitter);
-    const DShade L = T.shade(E.prim);
+    const DShade L = T.emitter_shade(emitter, E);
     f3 d = sp - ref_p;
     const float dist2 = dot3(d, d);
     d = d * rsqrtf(dist2);
@@ -200,7 +200,7 @@ DEV void eval_bdpt(const DParams &P, const TablesT &T, MSampler &smp, bool activ
                 const DEmitter E = T.emitter(ei);
                 const float emPdf = E.cdf_hi - E.cdf_lo;
                 sx = (sx - E.cdf_lo) / emPdf;
-                const DShade L = T.shade(E.prim);
+                const DShade L = T.emitter_shade(ei, E);
                 f3 lp;
                 if ((L.bsdf >> 24) == PRIM_RECTANGLE) lp = fma3(ld3(L.eu), sx, fma3(ld3(L.ev), u1, ld3(L.origin)));
                 else if ((L.bsdf >> 24) == PRIM_SPHERE) { // sphere.cpp:257-268: uniform on the sphere
@@ -532,7 +532,7 @@ DEV void eval_bdpt(const DParams &P, const TablesT &T, MSampler &smp, bool activ
                     const DEmitter E = T.emitter(ei);
                     const float emPdf = E.cdf_hi - E.cdf_lo;
                     sx = (sx - E.cdf_lo) / emPdf;
-                    const DShade L = T.shade(E.prim);
+                    const DShade L = T.emitter_shade(ei, E);
                     f3 ln = ld3(L.n), dd;
                     float dist, pdf;
                     if ((L.bsdf >> 24) == PRIM_SPHERE) {

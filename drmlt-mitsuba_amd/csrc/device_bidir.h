@@ -330,7 +330,7 @@ DEV void eval_mmlt(const DParams &P, const TablesT &T, MSampler &smp, int depth,
             const DEmitter E = T.emitter(ei);
             const float emPdf = E.cdf_hi - E.cdf_lo;
             sx = (sx - E.cdf_lo) / emPdf;
-            const DShade L = T.shade(E.prim);
+            const DShade L = T.emitter_shade(ei, E);
             f3 lp;
             if ((L.bsdf >> 24) == PRIM_RECTANGLE) lp = fma3(ld3(L.eu), sx, fma3(ld3(L.ev), u1, ld3(L.origin)));
             else if ((L.bsdf >> 24) == PRIM_SPHERE) { // sphere.cpp:257-268: uniform on the sphere

@@ -957,6 +957,7 @@ struct GlobalTables {
     DEV DBsdf bsdf(int i) const { return load_global16(bs + i); }
     DEV DEmitter emitter(int i) const { return load_global16(em + i); }
     DEV float emitter_cdf_lo(int i) const { return load_global_f32(&em[i].cdf_lo); }
+    DEV DShade emitter_shade(int, const DEmitter &E) const { return shade(E.prim); } // the shading record of emitter ei's shape
 };
 struct LdsTables {
     uint32_t shade_off, bsdf_off, emit_off; // float offsets into lds_x, multiples of 4
@@ -990,10 +991,13 @@ struct LdsTables {
         return e;
     }
     DEV float emitter_cdf_lo(int i) const { return lds_x[emit_off + (uint32_t) i * 8u + 4u]; }
+    DEV DShade emitter_shade(int, const DEmitter &E) const { return shade(E.prim); }
 };
 // BSDF and emitter records in LDS, shading records in device memory: for kernels whose own rows leave less LDS than the shading table
 // needs (k_mutate_bdpt at two waves per SIMD: 19.25 KB of rows; the Cornell scene's 30 shading records are 1.9 KB, its four BSDFs and one
 // emitter 224 bytes)
+// `L.shade_off` holds one shading record per EMITTER (the record of its shape, in emitter order): what a light sample needs after the
+// emitter is picked -- otherwise a dependent round trip to memory behind the pick.
 struct MixedTables {
     const DShade *sh;
     LdsTables L;
@@ -1001,12 +1005,32 @@ struct MixedTables {
     DEV DBsdf bsdf(int i) const { return L.bsdf(i); }
     DEV DEmitter emitter(int i) const { return L.emitter(i); }
     DEV float emitter_cdf_lo(int i) const { return L.emitter_cdf_lo(i); }
+    DEV DShade emitter_shade(int ei, const DEmitter &) const { return L.shade(ei); }
 };
+// The same with a fallback: scenes whose BSDF / emitter tables do not fit beside a kernel's rows read them from device memory
+// (wave-uniform `lds`). The BVH builds of k_mutate_v5: a path step's chain of dependent gathers -- shading record -> BSDF, light pick
+// -> emitter -> its shape's record -- shrinks to the shading record alone.
+struct HybridTables {
+    const DShade *sh; const DBsdf *bs; const DEmitter *em;
+    LdsTables L;
+    bool lds;
+    DEV DShade shade(int i) const { return load_global16(sh + i); }
+    DEV DBsdf bsdf(int i) const { if (lds) return L.bsdf(i); return load_global16(bs + i); }
+    DEV DEmitter emitter(int i) const { if (lds) return L.emitter(i); return load_global16(em + i); }
+    DEV float emitter_cdf_lo(int i) const { if (lds) return L.emitter_cdf_lo(i); return load_global_f32(&em[i].cdf_lo); }
+    DEV DShade emitter_shade(int ei, const DEmitter &E) const { if (lds) return L.shade(ei); return load_global16(sh + E.prim); }
+};
+DEV uint32_t small_tables_floats(const DParams &P) { return (uint32_t) P.n_emitters * 16u + (uint32_t) P.n_bsdfs * 12u + (uint32_t) P.n_emitters * 8u; }
+// emitter shape records at T.shade_off, BSDFs at T.bsdf_off, emitters at T.emit_off
 DEV void stage_bsdfs_emitters(const DParams &P, const LdsTables &T, uint32_t lane) {
     const float *src = reinterpret_cast<const float *>(P.bsdfs);
     for (uint32_t i = lane; i < (uint32_t) P.n_bsdfs * 12u; i += 64u) lds_x[T.bsdf_off + i] = src[i];
     src = reinterpret_cast<const float *>(P.emitters);
     for (uint32_t i = lane; i < (uint32_t) P.n_emitters * 8u; i += 64u) lds_x[T.emit_off + i] = src[i];
+    for (uint32_t i = lane; i < (uint32_t) P.n_emitters * 16u; i += 64u) {
+        const int prim = P.emitters[i >> 4].prim;
+        lds_x[T.shade_off + i] = reinterpret_cast<const float *>(P.shade + prim)[i & 15u];
+    }
 }
 // cooperative copy of the three tables into LDS by one wave
 DEV void stage_tables(const DParams &P, const LdsTables &T, uint32_t lane) {
@@ -1303,7 +1327,7 @@ DEV void path_step(const DParams &P, const TablesT &T, PathState &ps, SamplerT &
             const DEmitter E = T.emitter(ei);
             float emPdf = E.cdf_hi - E.cdf_lo;
             sx = (sx - E.cdf_lo) / emPdf; // sampleReuse
-            const DShade L = T.shade(E.prim);
+            const DShade L = T.emitter_shade(ei, E);
             f3 lp;
             if ((L.bsdf >> 24) == PRIM_RECTANGLE) { // rectangle.cpp:210-216
                 lp = fma3(ld3(L.eu), sx, fma3(ld3(L.ev), sy, ld3(L.origin))); // origin = corner (-1,-1), eu/ev = full edges

@@ -161,6 +161,8 @@ struct DParams {
     const DPrimBox *prims_box;   // cuboid records of the brute-force loop (n_box of them + one sentinel), tested before prims_flat
     int32_t n_box;
     int32_t n_flat_rec;          // records in prims_flat (flat records that are no cuboid's face) -- n_flat counts the flat records of `prims`
+    int32_t small_tables_lds;    // k_mutate_v5 on traversed scenes: BSDF / emitter records and the emitters' shape records are staged in LDS (they fit beside the pool)
+    int32_t pad_tables;
     float *rows;                 // k_mutate_v5 with its proposal rows in device memory ([dim][chain], as x), or NULL: rows in LDS
     int32_t boot_weighted;       // bootstrap kernels: also write each sample's luminance under the importance map, to lum_out[n + i] (two-stage MLT: seeds drawn from the chains' own target, drmlt_capi.cpp)
 };

@@ -632,6 +632,14 @@ drmlt_ctx *drmlt_create(const drmlt_config *cfg, const drmlt_scene *scene, int d
             P.rows = ctx->d_rows.as<float>();
         }
     }
+    // k_mutate_v5 on traversed scenes: room for the small tables beside the pool? LDS per wave without them: 20 480 B in the builds with
+    // 32-bit stacks and rows in LDS (none), 19.5 KB with 16-bit stacks, 11.5 / 10.8 KB with the rows in device memory (twelve waves per CU: 13 KB)
+    {
+        const size_t small = ((size_t) P.n_bsdfs * 12 + (size_t) P.n_emitters * 24) * sizeof(float);
+        const size_t room = P.rows ? (P.bvh_stack16 ? 1536 : 1024) : (P.bvh_stack16 ? 768 : 0);
+        P.small_tables_lds = (P.use_bvh && P.kernel_variant == 5 && small <= room && !getenv("DRMLT_NO_SMALL_TABLES")) ? 1 : 0;
+        P.pad_tables = 0;
+    }
     P.bvh_overflow = nullptr; P.bvh_ovf_lanes = 0;
     P.exec_order = nullptr;
     // measured (5-launch calls) on the 2000-triangle soup: 16 3.69e8, 20 3.80e8, 24 3.84e8, 28 3.84e8 mutations/s; on 50 000 triangles (32-bit

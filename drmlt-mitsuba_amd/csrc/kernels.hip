@@ -1140,6 +1140,13 @@ __global__ void __launch_bounds__(CHAIN_BLOCK, ROWS_MEM ? V5_ROWS_MEM_WAVES : 2)
     LT.bsdf_off = LT.shade_off + (uint32_t) P0.n_shade * 16u;
     LT.emit_off = LT.bsdf_off + (uint32_t) P0.n_bsdfs * 12u;
     if (LDS_TABLES) stage_tables(P0, LT, lane);
+    // traversed scenes: BSDF / emitter records and the emitters' shape records behind the pool when the launcher found room for them
+    HybridTables HT;
+    HT.L.shade_off = L.status_off + V5_SLOTS / 4u;
+    HT.L.bsdf_off = HT.L.shade_off + (uint32_t) P0.n_emitters * 16u;
+    HT.L.emit_off = HT.L.bsdf_off + (uint32_t) P0.n_bsdfs * 12u;
+    HT.lds = !FLAT && P0.small_tables_lds != 0;
+    if (HT.lds) stage_bsdfs_emitters(P0, HT.L, lane);
 
     ChainState cs;
     cs.cur.lum = P0.cur_lum[cc]; cs.cur.px = P0.cur_px[cc]; cs.cur.py = P0.cur_py[cc];
@@ -1235,7 +1242,7 @@ __global__ void __launch_bounds__(CHAIN_BLOCK, ROWS_MEM ? V5_ROWS_MEM_WAVES : 2)
                     const bool shadow_clear = st_s == RS_DONE ? pool[64u + lane] == 0.f : true;
                     status[lane] = RS_IDLE; status[64u + lane] = RS_IDLE;
                     if (LDS_TABLES) path_step<true, FEAT, SamplerT, LdsTables, false>(Ps, LT, ps, smp, h, shadow_clear, sr);
-                    else path_step<true, FEAT, SamplerT, GlobalTables, false>(Ps, GlobalTables{Ps.shade, Ps.bsdfs, Ps.emitters}, ps, smp, h, shadow_clear, sr);
+                    else { HT.sh = Ps.shade; HT.bs = Ps.bsdfs; HT.em = Ps.emitters; path_step<true, FEAT, SamplerT, HybridTables, false>(Ps, HT, ps, smp, h, shadow_clear, sr); }
                     push_c = ps.phase == PH_CLOSEST;
                     push_s = sr.valid;
                 }
@@ -1658,6 +1665,7 @@ void launch_mutate(const DParams &P, uint32_t n_mut, uint32_t mut_base, hipStrea
         const bool rows_mem = P.rows != nullptr && (!flat || P.tables_in_lds); // (drmlt_capi.cpp: chains for more than two waves per SIMD)
         size_t lds = v5_lds_bytes(rows_mem ? 0u : (uint32_t) D, (flat || P.bvh_stack16) ? V5_QCAP : V5_QCAP_STACK32, flat || P.bvh_stack16);
         if (flat && P.tables_in_lds) lds += (size_t) P.n_shade * 64 + (size_t) P.n_bsdfs * 48 + (size_t) P.n_emitters * 32;
+        if (!flat && P.small_tables_lds) lds += ((size_t) P.n_bsdfs * 12 + (size_t) P.n_emitters * 24) * sizeof(float);
         if (getenv("DRMLT_VERBOSE")) fprintf(stderr, "[drmlt] k_mutate_v5: %zu B of LDS per wave%s%s\n", lds, flat ? "" : " (+ the traversal stack)", rows_mem ? "; proposal rows in device memory, three waves per SIMD" : "");
         const dim3 g5((P.n_chains + 63) / 64);
         const bool diffuse = P.features == 8;

@@ -140,8 +140,8 @@ template <int FEAT, int OCC, bool LDS_BSDFS = false> __global__ void __launch_bo
     const uint32_t lane = threadIdx.x;
     MixedTables MT;
     MT.sh = P.shade;
-    MT.L.shade_off = 0u;
-    MT.L.bsdf_off = ((uint32_t) P.mmlt_S + (uint32_t) P.mmlt_E) * 64u + (uint32_t) bdpt_eval_lds_floats(P.max_depth);
+    MT.L.shade_off = ((uint32_t) P.mmlt_S + (uint32_t) P.mmlt_E) * 64u + (uint32_t) bdpt_eval_lds_floats(P.max_depth); // (the emitters' shape records)
+    MT.L.bsdf_off = MT.L.shade_off + (uint32_t) P.n_emitters * 16u;
     MT.L.emit_off = MT.L.bsdf_off + (uint32_t) P.n_bsdfs * 12u;
     if (LDS_BSDFS) stage_bsdfs_emitters(P, MT.L, lane);
     // Execution order (drmlt_capi.cpp: regroup_chains): which chain a lane runs. Between the launches of a call the host groups the
@@ -343,7 +343,7 @@ void launch_mutate_bdpt(const DParams &P, uint32_t n_mut, uint32_t mut_base, hip
     const dim3 grid((P.n_chains + CHAIN_BLOCK - 1) / CHAIN_BLOCK), block(CHAIN_BLOCK);
     static const int force_occ = getenv("DRMLT_BDPT_OCC") ? atoi(getenv("DRMLT_BDPT_OCC")) : 0; // diagnostic
     const bool two = force_occ ? force_occ == 2 : (!P.use_bvh && grid.x > 1024u + 256u && bdpt_lds_bytes(P) <= 20480);
-    const size_t tb = ((size_t) P.n_bsdfs * 12 + (size_t) P.n_emitters * 8) * sizeof(float);
+    const size_t tb = ((size_t) P.n_bsdfs * 12 + (size_t) P.n_emitters * (8 + 16)) * sizeof(float); // BSDFs, emitters, the emitters' shape records
     static const bool global_tables = getenv("DRMLT_BDPT_TABLES_GLOBAL") != nullptr; // A/B
     if (P.use_bvh) hipLaunchKernelGGL((k_mutate_bdpt<15, 1>), grid, block, bdpt_lds_bytes(P), st, P, n_mut, mut_base);
     else if (two && !global_tables && bdpt_lds_bytes(P) + tb <= 20480) hipLaunchKernelGGL((k_mutate_bdpt<7, 2, true>), grid, block, bdpt_lds_bytes(P) + tb, st, P, n_mut, mut_base);
