@@ -1206,6 +1206,14 @@ DEV void path_begin(const DParams &P, PathState &ps, float v0, float v1) {
 template <bool DUAL, int FEAT, class SamplerT, class TablesT, bool HAS_BEGIN = true>
 DEV void path_step(const DParams &P, const TablesT &T, PathState &ps, SamplerT &smp, const Hit &hit, bool shadow_clear,
                    ShadowRay &sr) {
+    // (a sampler whose rows live in device memory: the five components a step can draw are requested HERE, all together and ahead of the
+    // shading record's gather -- one round trip beside it instead of `need` of them behind it; what the step does not draw is not used)
+    float pre0 = 0.f, pre1 = 0.f, pre2 = 0.f, pre3 = 0.f, pre4 = 0.f;
+    if constexpr (draws_batched<SamplerT>::value) {
+        const uint32_t kmax = (uint32_t) P.eff_dim - 1u, k = ps.k;
+        pre0 = smp.next(min(k, kmax)); pre1 = smp.next(min(k + 1u, kmax)); pre2 = smp.next(min(k + 2u, kmax));
+        pre3 = smp.next(min(k + 3u, kmax)); pre4 = smp.next(min(k + 4u, kmax));
+    }
     // ---------------- part 1: digest the ray query, decide which PSS components are needed
     bool want_rr = false, want_nee = false;
     int need = 0;
@@ -1289,11 +1297,7 @@ DEV void path_step(const DParams &P, const TablesT &T, PathState &ps, SamplerT &
     // ---------------- part 2: the one place PSS components are drawn
     float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f, v4 = 0.f;
     if constexpr (draws_batched<SamplerT>::value) {
-        // a sampler whose rows live in device memory: all five loads in flight together instead of `need` round trips one after the other
-        // (the ones beyond `need` read component k again -- the same line -- and are not used)
-        const uint32_t k = ps.k;
-        v0 = smp.next(k); v1 = smp.next(need > 1 ? k + 1u : k); v2 = smp.next(need > 2 ? k + 2u : k);
-        v3 = smp.next(need > 3 ? k + 3u : k); v4 = smp.next(need > 4 ? k + 4u : k);
+        v0 = pre0; v1 = pre1; v2 = pre2; v3 = pre3; v4 = pre4;
     } else {
 #pragma nounroll
         for (int j = 0; j < need; ++j) {
