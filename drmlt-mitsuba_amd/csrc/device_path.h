@@ -303,6 +303,7 @@ struct LdsSampler {
 //   z  [D4 rows]   second-stage proposal, unwrapped
 // Same arithmetic per component as LdsSampler (and Sampler): the chains are bit-identical.
 struct RowSampler {
+    static constexpr bool batch_draws = true; // path_step: the (up to) five components of a step are read together, ahead of the hit's digestion
     uint32_t key0, key1;
     int mode, type;
     float sigma2;
@@ -397,7 +398,10 @@ template <class T> DEV T load_global16(const T *p) {
     for (unsigned i = 0; i < sizeof(T) / 16u; ++i) u.w[i] = q[i];
     return u.v;
 }
-// samplers that want the draws of a path step requested together (PoolRowSampler over rows in device memory, kernels.hip)
+// Samplers whose components are plain reads (proposal rows in LDS or in device memory) have the draws of a path step requested
+// together: a loop over `need` reads, each waited for, was `need` LDS round trips per step even with the rows in LDS (round 4: config 2
+// 2.11e9 -> 2.24e9, the 2000-triangle soup 5.82e8 -> 6.01e8; with the rows in device memory it is the difference between one and five
+// trips through the L2). The lazy samplers (Philox inside next()) keep the loop: one copy of their code.
 template <class S, class = void> struct draws_batched : std::false_type {};
 template <class S> struct draws_batched<S, std::void_t<decltype(S::batch_draws)>> : std::integral_constant<bool, S::batch_draws> {};
 DEV float load_global_f32(const float *p) { return *(const float __attribute__((address_space(1))) *) (uintptr_t) p; }
@@ -1206,8 +1210,8 @@ DEV void path_begin(const DParams &P, PathState &ps, float v0, float v1) {
 template <bool DUAL, int FEAT, class SamplerT, class TablesT, bool HAS_BEGIN = true>
 DEV void path_step(const DParams &P, const TablesT &T, PathState &ps, SamplerT &smp, const Hit &hit, bool shadow_clear,
                    ShadowRay &sr) {
-    // (a sampler whose rows live in device memory: the five components a step can draw are requested HERE, all together and ahead of the
-    // shading record's gather -- one round trip beside it instead of `need` of them behind it; what the step does not draw is not used)
+    // (row samplers: the five components a step can draw are requested HERE, all together and ahead of the shading record's gather -- one
+    // round trip beside it instead of `need` of them behind it; what the step does not draw is not used)
     float pre0 = 0.f, pre1 = 0.f, pre2 = 0.f, pre3 = 0.f, pre4 = 0.f;
     if constexpr (draws_batched<SamplerT>::value) {
         const uint32_t kmax = (uint32_t) P.eff_dim - 1u, k = ps.k;

@@ -969,7 +969,7 @@ struct RowsMem {
 
 // the proposal rows as the path step sees them: whatever stage is being evaluated sits in the one row group
 template <class Rows> struct PoolRowSampler {
-    static constexpr bool batch_draws = std::is_same<Rows, RowsMem>::value; // (device_path.h: path_step, part 2)
+    static constexpr bool batch_draws = true; // (device_path.h: path_step reads a step's components together)
     uint32_t lane;
     Rows rows;
     // Mira's ratio alone looks behind the rows (they hold z by then): the state in device memory and the first-stage draws,
