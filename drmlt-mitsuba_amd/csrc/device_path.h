@@ -354,12 +354,20 @@ struct RowSampler {
 #pragma unroll
             for (uint32_t i = 0; i < 4u; ++i) lds_x[z_off + (4u * b + i) * stride + col] = u[i];
         } else if (type == 2) {
+            // (all reads first: the writes below are to LDS too and may alias them for the compiler -- pair after pair would wait for its
+            // own reads behind the previous pair's writes)
+            float xa[4], xb[4], ya[4], yb[4];
+#pragma unroll
+            for (uint32_t i = 0; i < 4u; ++i) {
+                const uint32_t k0 = 2u * (4u * b + i), kk = k0 + 1u < D4 ? k0 : 0u;
+                xa[i] = lds_x[kk * stride + col]; xb[i] = lds_x[(kk + 1u) * stride + col];
+                ya[i] = lds_x[y_off + kk * stride + col]; yb[i] = lds_x[y_off + (kk + 1u) * stride + col];
+            }
 #pragma unroll
             for (uint32_t i = 0; i < 4u; ++i) {
                 const uint32_t k0 = 2u * (4u * b + i);
                 if (k0 + 1u < D4) {
-                    const float x0 = lds_x[k0 * stride + col], x1 = lds_x[(k0 + 1u) * stride + col];
-                    const float y0 = lds_x[y_off + k0 * stride + col], y1 = lds_x[y_off + (k0 + 1u) * stride + col];
+                    const float x0 = xa[i], x1 = xb[i], y0 = ya[i], y1 = yb[i];
                     // theta ~ wrapped Cauchy by inverse CDF (transition.h:157-173); z = y + R(theta)(x - y) (drmlt_sampler.cpp:374-391)
                     float xi = u[i], sign = 1.f;
                     if (xi < 0.5f) { xi *= 2.f; } else { sign = -1.f; xi = 2.f * (xi - 0.5f); }
@@ -373,8 +381,9 @@ struct RowSampler {
             }
         } else {
             const uint32_t k = 2u * b;
-            lds_x[z_off + k * stride + col] = lds_x[k * stride + col] + gaussian_sample(u[0], u[1], sigma2);
-            lds_x[z_off + (k + 1u) * stride + col] = lds_x[(k + 1u) * stride + col] + gaussian_sample(u[2], u[3], sigma2);
+            const float x0 = lds_x[k * stride + col], x1 = lds_x[(k + 1u) * stride + col];
+            lds_x[z_off + k * stride + col] = x0 + gaussian_sample(u[0], u[1], sigma2);
+            lds_x[z_off + (k + 1u) * stride + col] = x1 + gaussian_sample(u[2], u[3], sigma2);
         }
     }
 };

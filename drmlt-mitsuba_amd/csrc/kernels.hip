@@ -683,9 +683,12 @@ __global__ void __launch_bounds__(CHAIN_BLOCK) k_mutate_v4(DParams P, uint32_t n
                     if (valid) {
                         const float *src = &lds_x[(mode_j == SM_STAGE1 ? smp.y_off : smp.z_off) + 4u * q * S + cj];
                         float *dst = &lds_x[4u * q * S + cj];
+                        float v[4]; // (reads first: the writes may alias them for the compiler)
+#pragma unroll
+                        for (uint32_t r = 0; r < 4u; ++r) v[r] = src[(4u * q + r < D ? r : 0u) * S];
 #pragma unroll
                         for (uint32_t r = 0; r < 4u; ++r)
-                            if (4u * q + r < D) dst[r * S] = wrap01(src[r * S]);
+                            if (4u * q + r < D) dst[r * S] = wrap01(v[r]);
                     }
                 }
             }
