@@ -70,9 +70,10 @@ CONFIGS = {
     "bdpt": dict(scene=("cornell_c2", {}), res=512, chains=131072, cfg=dict(technique="bdpt", type="orbital", max_depth=8, rr_depth=5),
                  spp=256, kernel="k_mutate_bdpt", pmc="r02_bdpt_pmc.json",
                  what="Cornell box %(res)dx%(res)d, drmlt technique=bdpt type=orbital, %(chains)d chains/GPU, sampleCount %(spp)d"),
-    # BVH scenes under type = orbital run k_mutate_v5 (ray pool, 64 chains per wave): 131 072 chains put two waves on every SIMD
-    "soup": dict(scene=("triangle_soup", dict(n_tris=2000)), res=512, chains=131072,
-                 cfg=dict(technique="path", type="orbital", max_depth=8, rr_depth=5), spp=256, kernel="k_mutate_v5",
+    # BVH scenes run k_mutate_v5 (ray pool, 64 chains per wave): 196 608 chains put three waves on every SIMD (proposal rows in device
+    # memory; sampleCount 240: a whole number of mutations per chain)
+    "soup": dict(scene=("triangle_soup", dict(n_tris=2000)), res=512, chains=196608,
+                 cfg=dict(technique="path", type="orbital", max_depth=8, rr_depth=5), spp=240, kernel="k_mutate_v5",
                  pmc="r02_soup_pmc.json", ref_spp=2048,
                  what="closed room with 2000 random triangles (BVH in HBM) %(res)dx%(res)d, drmlt technique=path type=orbital, "
                       "%(chains)d chains/GPU, sampleCount %(spp)d"),

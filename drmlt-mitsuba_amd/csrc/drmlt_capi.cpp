@@ -502,11 +502,11 @@ drmlt_ctx *drmlt_create(const drmlt_config *cfg, const drmlt_scene *scene, int d
             // (k_mutate_v5, the ray-pool kernel, carries 64 chains per wave: 131 072 fill the device; it is the path technique's kernel
             // for all three types -- flat scenes included: 2.15e9 at 131 072 chains against k_mutate_v4's 1.79e9 at 65 536)
             const bool pool_kernel = !mmlt && !bdpt && cfg->algo != DRMLT_ALGO_PSSMLT && !getenv("DRMLT_KERNEL");
-            // (with its proposal rows in device memory the pool kernel runs a THIRD wave per SIMD, kernels.hip: ROWS_MEM -- 196 608 chains.
-            // It pays on traversed scenes with 32-bit stack entries, tens of thousands of primitives and more, whose node fetches the
-            // extra wave covers, + 10 ... 14 %, and on flat scenes, + 4 ... 12 %; not on small trees -- 2000 triangles: - 5 %)
+            // (with its proposal rows in device memory the pool kernel runs a THIRD wave per SIMD, kernels.hip: ROWS_MEM -- 196 608 chains:
+            // traversed scenes, whose node fetches the extra wave covers, + 4 % (2000 triangles) ... + 17 % (50 000, 1 000 000), flat
+            // scenes + 20 % -- measured with a step's components read together)
             const bool small_tables = ctx->shade.size() * 64 + bsdfs.size() * 48 + emitters.size() * 32 <= 16384; // (= P.tables_in_lds, below)
-            const bool three_waves = pool_kernel && (P.use_bvh ? !P.bvh_stack16 : small_tables);
+            const bool three_waves = pool_kernel && (P.use_bvh || small_tables);
             const uint64_t fill = mmlt ? 262144 : (three_waves ? 196608 : ((bdpt || pool_kernel) ? 131072 : 65536)); // mmlt: two rounds of waves, run in depth order
             work_units = (int) std::min<uint64_t>(fill, std::max<uint64_t>(64, budget / 64 / 64 * 64));
         }

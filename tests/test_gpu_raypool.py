@@ -189,7 +189,6 @@ def test_default_kernel_choice(pkg, native_lib, capfd):
     assert kernel_of(cornell, type="orbital", work_units=65536, sample_count=256) == ("v4", 65536)      # BASELINE configs[1]
     assert kernel_of(cornell, type="orbital", work_units=-1, sample_count=256) == ("v5", 196608)
     assert kernel_of(cornell, type="green", work_units=131072, sample_count=256) == ("v5", 131072)
-    # traversed scenes: two waves per SIMD where the stack entries are 16 bits wide (short traversals), three -- rows in device memory --
-    # where they are 32 (workUnits = -1 derives the count that fills them)
-    assert kernel_of(pkg.scenes.triangle_soup(2000, 512), type="orbital", work_units=-1, sample_count=256) == ("v5", 131072)
+    # traversed scenes: three waves per SIMD as well (workUnits = -1 derives the count that fills them)
+    assert kernel_of(pkg.scenes.triangle_soup(2000, 512), type="orbital", work_units=-1, sample_count=256) == ("v5", 196608)
     assert kernel_of(pkg.scenes.triangle_soup(40000, 512), type="orbital", work_units=-1, sample_count=256) == ("v5", 196608)

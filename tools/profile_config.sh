@@ -15,7 +15,7 @@ for cfg in "$@"; do
     2x) name=2x; spp=60;;
     5) name=c5; spp=256;;   # the bidirectional kernels cut a call into a short first launch and the rest (regrouping): a call long
     bdpt) name=bdpt; spp=256;; # enough that the chain state's load / store per launch is amortised as in a render
-    soup50k|soup1m) name=$cfg; spp=60;; # 196 608 chains: a whole number of mutations per chain
+    soup|soup50k|soup1m) name=$cfg; spp=60;; # 196 608 chains: a whole number of mutations per chain
     *) name=$cfg;;
   esac
   muts=$((512*512*spp))
