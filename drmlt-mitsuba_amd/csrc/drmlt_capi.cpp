@@ -493,7 +493,7 @@ drmlt_ctx *drmlt_create(const drmlt_config *cfg, const drmlt_scene *scene, int d
         // "derived" (workUnits = -1, the default). The reference sizes work units for its CPU scheduler -- 200 000 (path) or
         // 100 000 (mmlt, bdpt) mutations each, drmlt.cpp:434-444: a few hundred chains for a whole image. A device wants the
         // count that fills it: 196 608 or 131 072 chains for the path technique's pool kernel (64 per wave, three or two waves per SIMD:
-        // below), 131 072 for bdpt's one-chain-per-lane kernel, 262 144 for mmlt's (two rounds, so that shallow waves make room for the next), but never chains shorter than 64 mutations. An explicit workUnits is
+        // below), 131 072 for bdpt's one-chain-per-lane kernel, 1 048 576 for mmlt's (two rounds, so that shallow waves make room for the next), but never chains shorter than 64 mutations. An explicit workUnits is
         // taken as given; drmlt_config.work_units_rule = DRMLT_WORK_UNITS_REFERENCE (adaptor: workUnitsRule=reference) restores the reference's formula.
         if (cfg->work_units_rule == DRMLT_WORK_UNITS_REFERENCE) {
             const uint64_t per_unit = (mmlt || bdpt) ? 100000 : 200000;
@@ -507,7 +507,10 @@ drmlt_ctx *drmlt_create(const drmlt_config *cfg, const drmlt_scene *scene, int d
             // scenes + 20 % -- measured with a step's components read together)
             const bool small_tables = ctx->shade.size() * 64 + bsdfs.size() * 48 + emitters.size() * 32 <= 16384; // (= P.tables_in_lds, below)
             const bool three_waves = pool_kernel && (P.use_bvh || small_tables);
-            const uint64_t fill = mmlt ? 262144 : (three_waves ? 196608 : ((bdpt || pool_kernel) ? 131072 : 65536)); // mmlt: two rounds of waves, run in depth order
+            // mmlt: MANY rounds of waves, run in depth order -- the kernel holds two 64-chain waves per SIMD (131 072 chains), and the more
+            // waves queue behind them the less of a launch is its tail: 262 144 chains 2.56e9 mutations/s on BASELINE's config 5, 524 288
+            // 2.79e9, 1 048 576 2.91e9, 2 097 152 2.94e9. (bdpt, whose workspace is 2 KB per chain, loses with more than fill the device.)
+            const uint64_t fill = mmlt ? 1048576 : (three_waves ? 196608 : ((bdpt || pool_kernel) ? 131072 : 65536));
             work_units = (int) std::min<uint64_t>(fill, std::max<uint64_t>(64, budget / 64 / 64 * 64));
         }
     }

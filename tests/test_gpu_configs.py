@@ -156,11 +156,11 @@ def test_bench_config_3_full_size(pkg, native_lib):
 
 
 def test_bench_config_5_full_size_regrouped(pkg, native_lib):
-    """`bench.py --config 5`: caustic, mmlt / orbital / fixEmitterPath / acceptanceMap, 262 144 chains run in depth order and
-    regrouped by work between the launches of a call (a short first launch, then 1024-mutation launches)."""
+    """`bench.py --config 5`: caustic, mmlt / orbital / fixEmitterPath / acceptanceMap, 1 048 576 chains run in depth order and
+    regrouped by work between the launches of a call (a short first launch, then the rest)."""
     ctx, _, M, n = _run_like_bench(pkg, "5", 1024, None)
     st, film = check_invariants(ctx, M, 1.0, amap=True)
-    assert st.n_chains == 262144 and st.launches >= 2                           # the first launch of a regrouping call is short
+    assert st.n_chains == 1048576 and st.launches >= 2                          # the first launch of a regrouping call is short
     f = film.astype(np.float64)
     assert f[..., 0].sum() == pytest.approx(st.bold_acc, rel=1e-3) and f[..., 1].sum() == pytest.approx(st.second_acc, rel=1e-3)
     cur, u = ctx.chain_state(27)
