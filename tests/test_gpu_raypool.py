@@ -116,6 +116,30 @@ def test_rows_in_device_memory_run_the_same_chains(pkg, native_lib, scene, skw, 
     assert np.abs(lum(f1) - lum(f0)).sum() / lum(f0).sum() < 1e-4
 
 
+@pytest.mark.parametrize("rows_mem", [0, 1], ids=["rows-lds", "rows-mem"])
+@pytest.mark.parametrize("scene,skw,env", [("triangle_soup", dict(n_tris=2000), {}), ("caustic_c5", {}, dict(DRMLT_BVH_THRESHOLD=0))], ids=["soup", "caustic-bvh"])
+def test_small_tables_in_lds_change_nothing(pkg, native_lib, scene, skw, env, rows_mem):
+    """On traversed scenes the BSDF / emitter records and the emitters' shape records are staged in LDS when they fit beside the ray pool
+    (HybridTables); scenes whose tables do not fit read them from device memory. Both paths, forced: the same chains bit for bit."""
+    sd = pkg.scenes.SCENES[scene](res=32, **skw)
+    n_chains, n_mut = 1000, 60
+    cfg = pkg.abi.make_config(type="orbital", max_depth=8, direct_samples=-1, luminance_samples=20000, work_units=n_chains, sample_count=1)
+    res = []
+    for no_small in (None, 1):
+        extra = dict(env)
+        if no_small:
+            extra["DRMLT_NO_SMALL_TABLES"] = 1
+        ctx = ctx_with_env(pkg, cfg, sd, DRMLT_KERNEL=5, DRMLT_ROWS_MEM=rows_mem, **extra)
+        ctx.seed(0x5005)
+        ctx.run(n_chains * n_mut)
+        res.append((ctx.chain_state(34), ctx.stats(), ctx.film()))
+        ctx.close()
+    ((c0, u0), s0, f0), ((c1, u1), s1, f1) = res
+    assert np.array_equal(u1, u0) and np.array_equal(c1["luminance"], c0["luminance"])
+    assert s1.accepted == s0.accepted and s1.rays == s0.rays and s1.bvh_node_visits == s0.bvh_node_visits > 0
+    assert np.abs(lum(f1) - lum(f0)).sum() / lum(f0).sum() < 1e-4
+
+
 def test_ray_pool_kernel_with_run_ahead_and_acceptance_map(pkg, native_lib):
     sd = pkg.scenes.triangle_soup(2000, 32)
     n_chains, per_chain = 1536, 300
