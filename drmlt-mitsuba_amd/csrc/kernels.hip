@@ -999,14 +999,22 @@ template <class Rows> struct PoolRowSampler {
 };
 
 // first-stage proposal of the chain in column `col` (state column `xcol` of P.x), dimensions 4b .. 4b+3, from Philox block b
-template <class Rows> DEV void v5_fill_first(const DParams &P, const Rows &rows, uint32_t D, uint32_t col, size_t xcol, uint32_t b, uint32_t major, uint32_t chain, bool large) {
+// (the four state components of the block are read by the CALLER, one pass of the flattened loop ahead: v5_state4)
+struct State4 { float x0, x1, x2, x3; };
+DEV State4 v5_state4(const DParams &P, uint32_t D, size_t xcol, uint32_t b) {
+    const bool hi = 4u * b + 2u < D; // D is even: a block holds two pairs or, at the end of the vector, one
+    const float *xs = P.x + (size_t) (4u * b) * P.n_chains + xcol;
+    State4 X;
+    X.x0 = load_global_f32(xs); X.x1 = load_global_f32(xs + P.n_chains);
+    X.x2 = load_global_f32(xs + (hi ? 2u : 0u) * (size_t) P.n_chains); X.x3 = load_global_f32(xs + (hi ? 3u : 1u) * (size_t) P.n_chains);
+    return X;
+}
+template <class Rows> DEV void v5_fill_first(const DParams &P, const Rows &rows, uint32_t D, uint32_t col, const State4 &X, uint32_t b, uint32_t major, uint32_t chain, bool large) {
     FP_STRICT;
     const u4 r = philox4x32_10(P.key0, P.key1, b, major, chain, TAG_S1);
     const float u0 = u32_to_unit(r.x), u1 = u32_to_unit(r.y), u2 = u32_to_unit(r.z), u3 = u32_to_unit(r.w);
-    const bool hi = 4u * b + 2u < D; // D is even: a block holds two pairs or, at the end of the vector, one
-    const float *xs = P.x + (size_t) (4u * b) * P.n_chains + xcol;
-    const float x0 = load_global_f32(xs), x1 = load_global_f32(xs + P.n_chains);
-    const float x2 = load_global_f32(xs + (hi ? 2u : 0u) * (size_t) P.n_chains), x3 = load_global_f32(xs + (hi ? 3u : 1u) * (size_t) P.n_chains);
+    const bool hi = 4u * b + 2u < D;
+    const float x0 = X.x0, x1 = X.x1, x2 = X.x2, x3 = X.x3;
     float y0, y1, y2, y3;
     if (P.type == 2) { // pairwise orbital: radius from the Kelemen kernel (x 1.9), uniform angle (drmlt_sampler.cpp:354-361)
         const float d0 = kelemen_sample(u0, KELEMEN_S2 * ORBITAL_SCALE), d1 = kelemen_sample(u2, KELEMEN_S2 * ORBITAL_SCALE);
@@ -1394,16 +1402,31 @@ __global__ void __launch_bounds__(CHAIN_BLOCK, ROWS_MEM ? V5_ROWS_MEM_WAVES : 2)
                     if (kind == 1) lds_list[prefix(f1mask)] = (int) lane;
                     const uint32_t n = (uint32_t) __popcll(f1mask), total = n * (nb1 + (COIN_ROWS ? 1u : 0u));
                     const float rcp_n = 1.f / (float) n;
-                    for (uint32_t ib = 0u; ib < total; ib += 64u) {
+                    // The state components an item perturbs come from device memory (past the L2s at three waves per SIMD): the reads of pass
+                    // i + 1 are issued before pass i's arithmetic (Philox, the transition kernel) instead of behind its stores, which they could not
+                    // pass for the compiler.
+                    auto locate = [&](uint32_t ib, uint32_t &b_, uint32_t &cj_, bool &valid_) {
                         const uint32_t i = ib + lane;
-                        const bool valid = i < total;
-                        const uint32_t ii = valid ? i : 0u;
-                        const uint32_t b = (uint32_t) (((float) ii + 0.5f) * rcp_n), j = ii - b * n;
-                        const uint32_t cj = (uint32_t) lds_list[j];
+                        valid_ = i < total;
+                        const uint32_t ii = valid_ ? i : 0u;
+                        b_ = (uint32_t) (((float) ii + 0.5f) * rcp_n);
+                        cj_ = (uint32_t) lds_list[ii - b_ * n];
+                    };
+                    uint32_t b_n, cj_n; bool valid_n;
+                    locate(0u, b_n, cj_n, valid_n);
+                    State4 X_n = v5_state4(Pm, D, (size_t) wave_base + cj_n, valid_n && b_n < nb1 ? b_n : 0u);
+                    for (uint32_t ib = 0u; ib < total; ib += 64u) {
+                        const uint32_t b = b_n, cj = cj_n;
+                        const bool valid = valid_n;
+                        const State4 X = X_n;
+                        if (ib + 64u < total) {
+                            locate(ib + 64u, b_n, cj_n, valid_n);
+                            X_n = v5_state4(Pm, D, (size_t) wave_base + cj_n, valid_n && b_n < nb1 ? b_n : 0u);
+                        }
                         const uint32_t mj = (uint32_t) __shfl((int) maj_mine, (int) cj, 64);
                         const unsigned inf = (unsigned) __shfl((int) info, (int) cj, 64);
                         if (valid) {
-                            if (b < nb1) v5_fill_first(Pm, rows, D, cj, (size_t) wave_base + cj, b, mj, chain_base + cj, inf != 0u);
+                            if (b < nb1) v5_fill_first(Pm, rows, D, cj, X, b, mj, chain_base + cj, inf != 0u);
                             else {
                                 const u4 coins = philox4x32_10(Pm.key0, Pm.key1, 0u, mj + 1u, chain_base + cj, TAG_COIN);
                                 float *dst = &lds_x[L.coin_off + cj];
