@@ -61,7 +61,9 @@ CONFIGS = {
     # (7.3e8 mutations/s); 131 072 put two on a SIMD (1.3e9); 262 144 are two ROUNDS of such waves, and with the chains run in
     # order of their depth the shallow waves' slots are re-used while the deep ones still run (2.1e9; 2.5e9 since its chains run free). BASELINE's config 5
     # does not fix the chain count.
-    # (round 4: 1 048 576 chains -- what workUnits = -1 derives -- queue eight rounds of waves: the more rounds, the less of a launch is its tail)
+    # (round 4: 1 048 576 chains -- what workUnits = -1 derives for long renders, 2^35 mutations and more -- queue eight rounds of waves: the
+    # more rounds, the less of a launch is its tail; the bootstrap set of a million chains costs 2.3 s of seeding, outside the timed region,
+    # against 0.6 s at 262 144 chains = 2.56e9: DESIGN section 6)
     "5": dict(scene=("caustic_c5", {}), res=512, chains=1048576,
               cfg=dict(technique="mmlt", type="orbital", max_depth=6, fix_emitter_path=1, acceptance_map=1), spp=256,
               kernel="k_mutate_mmlt", pmc="r02_c5_pmc.json",

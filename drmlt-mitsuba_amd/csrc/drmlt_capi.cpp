@@ -493,7 +493,7 @@ drmlt_ctx *drmlt_create(const drmlt_config *cfg, const drmlt_scene *scene, int d
         // "derived" (workUnits = -1, the default). The reference sizes work units for its CPU scheduler -- 200 000 (path) or
         // 100 000 (mmlt, bdpt) mutations each, drmlt.cpp:434-444: a few hundred chains for a whole image. A device wants the
         // count that fills it: 196 608 or 131 072 chains for the path technique's pool kernel (64 per wave, three or two waves per SIMD:
-        // below), 131 072 for bdpt's one-chain-per-lane kernel, 1 048 576 for mmlt's (two rounds, so that shallow waves make room for the next), but never chains shorter than 64 mutations. An explicit workUnits is
+        // below), 131 072 for bdpt's one-chain-per-lane kernel, 262 144 or -- long renders -- 1 048 576 for mmlt's (two rounds, so that shallow waves make room for the next), but never chains shorter than 64 mutations. An explicit workUnits is
         // taken as given; drmlt_config.work_units_rule = DRMLT_WORK_UNITS_REFERENCE (adaptor: workUnitsRule=reference) restores the reference's formula.
         if (cfg->work_units_rule == DRMLT_WORK_UNITS_REFERENCE) {
             const uint64_t per_unit = (mmlt || bdpt) ? 100000 : 200000;
@@ -510,7 +510,10 @@ drmlt_ctx *drmlt_create(const drmlt_config *cfg, const drmlt_scene *scene, int d
             // mmlt: MANY rounds of waves, run in depth order -- the kernel holds two 64-chain waves per SIMD (131 072 chains), and the more
             // waves queue behind them the less of a launch is its tail: 262 144 chains 2.56e9 mutations/s on BASELINE's config 5, 524 288
             // 2.79e9, 1 048 576 2.91e9, 2 097 152 2.94e9. (bdpt, whose workspace is 2 KB per chain, loses with more than fill the device.)
-            const uint64_t fill = mmlt ? 1048576 : (three_waves ? 196608 : ((bdpt || pool_kernel) ? 131072 : 65536));
+            // The price is paid before the first mutation: 50 x maxDepth bootstrap samples per chain (drmlt.cpp:456-473) are 3e8 samples for a
+            // million chains at maxDepth 6 -- 2.3 s of seeding against 0.6 s for 262 144 chains (the resampling table is built on the host).
+            // A render gets the million chains when the 14 % are worth more than that: from 2^35 mutations (12 s of kernel time) up.
+            const uint64_t fill = mmlt ? (budget >= (1ull << 35) ? 1048576 : 262144) : (three_waves ? 196608 : ((bdpt || pool_kernel) ? 131072 : 65536));
             work_units = (int) std::min<uint64_t>(fill, std::max<uint64_t>(64, budget / 64 / 64 * 64));
         }
     }
@@ -728,8 +731,10 @@ static int seed_impl(drmlt_ctx *ctx, uint64_t seed, uint32_t chain_offset, uint3
     // generateSeeds, pathsampler.cpp:879-954: mean over non-NaN samples, CDF over the non-zero ones
     double sum = 0.0, tok = 0.0;
     std::vector<uint32_t> idx;
-    std::vector<double> cdf(1, 0.0);
+    std::vector<double> cdf;
     idx.reserve(n);
+    cdf.reserve((size_t) n + 1); // (hundreds of millions of samples with technique=mmlt's derived chain count: no reallocation on the way)
+    cdf.push_back(0.0);
     for (uint32_t i = 0; i < n; ++i) {
         float l = lum[i];
         if (std::isnan(l)) continue;
@@ -748,12 +753,25 @@ static int seed_impl(drmlt_ctx *ctx, uint64_t seed, uint32_t chain_offset, uint3
     const double norm = 1.0 / cdf.back();
     for (size_t i = 1; i < cdf.size(); ++i) cdf[i] *= norm;
     cdf.back() = 1.0;
-    std::vector<uint32_t> seed_index(n_select);
+    // One pick per chain: DiscreteDistribution::sample on the uniform of its own stream address. The picks are SORTED afterwards
+    // (PathSeedSortPredicate), so the order in which they are made is free: the uniforms are sorted first and the table is walked once,
+    // each lower_bound galloping on from the previous one -- the same entry as a search of the whole table, without a million cold binary
+    // searches through gigabytes (technique=mmlt derives a million chains and 50 x maxDepth bootstrap samples for each).
+    std::vector<double> xis(n_select);
     for (uint32_t j = 0; j < n_select; ++j) {
         uint32_t r[4];
         philox_host(P.key0, P.key1, 0u, j, P.boot_stream, TAG_SEEDSEL, r);
-        double xi = (double) ((float) (r[0] >> 8) * (1.0f / 16777216.0f));
-        auto entry = std::lower_bound(cdf.begin(), cdf.end(), xi);
+        xis[j] = (double) ((float) (r[0] >> 8) * (1.0f / 16777216.0f));
+    }
+    std::sort(xis.begin(), xis.end());
+    std::vector<uint32_t> seed_index(n_select);
+    size_t from = 0; // lower_bound of the previous (smaller or equal) uniform: the next one's is not before it
+    for (uint32_t j = 0; j < n_select; ++j) {
+        const double xi = xis[j];
+        size_t step = 1, hi = from;
+        while (hi < cdf.size() && cdf[hi] < xi) { from = hi + 1; hi += step; step *= 2; }
+        auto entry = std::lower_bound(cdf.begin() + from, cdf.begin() + std::min(hi, cdf.size()), xi);
+        from = (size_t) (entry - cdf.begin());
         size_t index = (size_t) std::max<ptrdiff_t>(0, (entry - cdf.begin()) - 1);
         index = std::min(cdf.size() - 2, index);
         while (cdf[index + 1] - cdf[index] == 0 && index < cdf.size() - 1) ++index;

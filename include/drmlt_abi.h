@@ -80,7 +80,7 @@ enum { DRMLT_FILTER_BOX = 0, DRMLT_FILTER_GAUSSIAN = 1 };
 enum { DRMLT_SEED_TARGET = 0, DRMLT_SEED_REFERENCE = 1 };
 
 /* workUnits = -1 ("derived", drmlt_config.work_units_rule; adaptor property "workUnitsRule" = "device" | "reference").
- *   DEVICE    (default) a device-filling chain count: 196 608 (path: three waves per SIMD of its pool kernel), 131 072 (bdpt), 1 048 576 (mmlt: eight rounds of waves), pssmlt 65 536; at least 64
+ *   DEVICE    (default) a device-filling chain count: 196 608 (path: three waves per SIMD of its pool kernel), 131 072 (bdpt), 262 144 (mmlt; 1 048 576 from 2^35 mutations up), pssmlt 65 536; at least 64
  *             mutations per chain.
  *   REFERENCE ceil(budget / 200 000) (path) or / 100 000 (bdpt, mmlt): drmlt.cpp:434-444 -- sized for a CPU scheduler. */
 enum { DRMLT_WORK_UNITS_DEVICE = 0, DRMLT_WORK_UNITS_REFERENCE = 1 };

@@ -110,11 +110,17 @@ def test_more_chains_than_requested_luminance_samples(pkg, native_lib):
 def test_derived_work_units_fill_the_device(pkg, native_lib):
     """workUnits = -1 (the reference default): a device-filling chain count, not the reference's few hundred CPU work units."""
     sd = pkg.scenes.cornell_c2(64)
-    for tech, typ, want in (("path", "orbital", 196608), ("path", "green", 196608), ("path", "mira", 196608), ("mmlt", "orbital", 1048576), ("bdpt", "orbital", 131072)):
-        # (path: 64 chains per wave of the ray-pool kernel, three waves per SIMD with its proposal rows in device memory; mmlt: eight rounds of waves)
+    for tech, typ, want in (("path", "orbital", 196608), ("path", "green", 196608), ("path", "mira", 196608), ("mmlt", "orbital", 262144), ("bdpt", "orbital", 131072)):
+        # (path: 64 chains per wave of the ray-pool kernel, three waves per SIMD with its proposal rows in device memory; mmlt: two rounds of waves)
         ctx = pkg.Context(pkg.abi.make_config(technique=tech, type=typ, max_depth=5, work_units=-1, sample_count=16384), sd)
         assert ctx.stats().n_chains == want
         ctx.close()
+    # mmlt in a long render (2^35 mutations and more: a 2048^2 film at 8192 mutations per pixel): eight rounds of waves -- the bootstrap set
+    # that seeds a million chains costs seconds, the shorter launch tails are worth 14 % of the rest
+    big = pkg.scenes.cornell_c2(2048)
+    ctx = pkg.Context(pkg.abi.make_config(technique="mmlt", type="orbital", max_depth=5, work_units=-1, sample_count=8192), big)
+    assert ctx.stats().n_chains == 1048576
+    ctx.close()
     ctx = pkg.Context(pkg.abi.make_config(technique="path", type="orbital", max_depth=5, work_units=-1, sample_count=16), sd)
     assert ctx.stats().n_chains == 64 * 64 * 16 // 64            # never chains shorter than 64 mutations
     ctx.close()
